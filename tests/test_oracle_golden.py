@@ -1,0 +1,77 @@
+"""Pin oracle/cris_oracle.py against fixtures produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from cris.pytorch_amd import arch, synth
+from oracle import cris_oracle as O
+
+CASES = {"tiny_b2_s64": ("tiny", 2, 64), "tiny_b3_s96": ("tiny", 3, 96), "r50_b2_s96": ("r50", 2, 96)}
+
+
+def _run_oracle(spec, batch, size):
+    clip, head = arch.specs_by_name(spec)
+    sd = arch.synthetic_state_dict(clip, head, 0)
+    img, word, mask = synth.make_batch(batch, size, head.word_len, 0, 0)
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    bnu = {}
+    pred, m, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=None, bn_updates=bnu)
+    loss.backward()
+    with torch.no_grad():
+        ev = O.cris_forward(sd, clip, head, img, word, training=False)
+    return leaf, pred, m, loss, ev, bnu
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_oracle_matches_reference(name):
+    spec, b, s = CASES[name]
+    if spec == "r50" and os.environ.get("CRIS_FAST_TESTS"):
+        pytest.skip("fast mode")
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    leaf, pred, m, loss, ev, bnu = _run_oracle(spec, b, s)
+    assert abs(loss.item() - float(g["loss"])) < 2e-5 * max(1.0, abs(float(g["loss"])))
+    np.testing.assert_allclose(pred.detach().numpy(), g["train_pred"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_array_equal(m.numpy(), g["train_mask"])          # nearest resize: index op, bit exact
+    np.testing.assert_allclose(ev.numpy(), g["eval_pred"], rtol=2e-4, atol=2e-4)
+    names = [str(x) for x in g["grad_names"]]
+    for k, ref_norm, ref_sum in zip(names, g["grad_norms"], g["grad_sums"]):
+        if ref_norm < 0:                      # reference left this parameter without a gradient
+            assert k == "backbone.logit_scale" and leaf[k].grad is None
+            continue
+        gn = float(leaf[k].grad.double().norm())
+        assert abs(gn - ref_norm) <= 2e-3 * ref_norm + 1e-7, (k, gn, ref_norm)
+    for key in g.files:
+        if key.startswith("gs:"):
+            k = key[3:]
+            flat = leaf[k].grad.flatten()
+            n = min(64, flat.numel())
+            idx = (torch.arange(n, dtype=torch.int64) * (flat.numel() - 1)) // max(n - 1, 1)
+            np.testing.assert_allclose(flat[idx].numpy(), g[key], rtol=5e-3, atol=1e-6 + 1e-3 * np.abs(g[key]).max())
+        if key.startswith("rm:"):
+            k = key[3:]
+            np.testing.assert_allclose(bnu[k[:-len(".running_mean")]][0].numpy(), g[key], rtol=1e-4, atol=1e-5)
+            np.testing.assert_allclose(bnu[k[:-len(".running_mean")]][1].numpy(), g["rv:" + k], rtol=1e-4, atol=1e-5)
+
+
+def test_tokenizer_vectors_index_ops():
+    """Index-op contract on the reference tokenizer's known answers: pad mask (segmenter.py:37) and
+    EOT select = argmax of ids (clip.py:451-452), bit exact."""
+    vec = json.load(open(os.path.join(GOLDEN, "tokenizer_vectors.json")))
+    assert vec[0]["ids"][:4] == [49406, 320, 22697, 49407]
+    for v in vec:
+        ids = torch.tensor(v["ids"])
+        assert int(ids.argmax()) == v["argmax"]
+        assert (ids == 0).int().tolist() == v["pad_mask"]
+        assert ids[v["argmax"]] == 49407 and ids[0] == 49406
+
+
+def test_state_dict_keys_match_reference():
+    ref = [l.split(" ", 1)[0] for l in open(os.path.join(GOLDEN, "state_dict_keys_r50.txt")).read().split("\n") if l]
+    tree = arch.build_param_tree(arch.CLIP_R50, arch.HEAD_R50)
+    assert list(tree.state_dict().keys()) == ref
+    assert sum(p.numel() for p in tree.parameters()) == 146849122
