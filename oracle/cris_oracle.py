@@ -177,7 +177,7 @@ def encode_image(img, sd, clip, training, bnu, taps=None):
 def encode_text(word, sd, clip, taps=None):
     B, L = word.shape
     x = sd["backbone.token_embedding.weight"][word] + sd["backbone.positional_embedding"][:L]
-    causal = torch.full((L, L), float("-inf")).triu_(1)               # clip.py:424-430
+    causal = torch.full((L, L), float("-inf"), dtype=x.dtype).triu_(1)               # clip.py:424-430
     for i in range(clip.txt_layers):
         p = "backbone.transformer.resblocks.%d" % i
         h = layer_norm(x, sd, p + ".ln_1")
@@ -226,8 +226,8 @@ def fpn(v3, v4, v5, state, sd, training, bnu, taps=None):
         taps["f5"], taps["f4"], taps["f3"], taps["aggr"] = f5, f4, f3, fq
     # CoordConv (layers.py:30-39): x varies along W, y along H, both linspace(-1,1)
     B, _, H, W = fq.shape
-    xr = torch.linspace(-1, 1, W).view(1, 1, 1, W).expand(B, 1, H, W)
-    yr = torch.linspace(-1, 1, H).view(1, 1, H, 1).expand(B, 1, H, W)
+    xr = torch.linspace(-1, 1, W).to(fq.dtype).view(1, 1, 1, W).expand(B, 1, H, W)
+    yr = torch.linspace(-1, 1, H).to(fq.dtype).view(1, 1, H, 1).expand(B, 1, H, W)
     fq = torch.cat([fq, xr, yr], 1)
     fq = conv_bn_relu(fq, sd, n + ".coordconv.0.conv1", 1, training, bnu)
     fq = conv_bn_relu(fq, sd, n + ".coordconv.1", 1, training, bnu)
@@ -272,8 +272,8 @@ def decoder(fq, word, pad_mask, sd, head, drop: DropCtx, taps=None):
     # reference model/layers.py:154-188, 224-250 ; batch-first internally ([B,T,C] == permuted [T,B,C])
     B, C, H, W = fq.shape
     L, D = word.shape[1], word.shape[2]
-    vpos = pos2d(C, H, W)[None]                      # [1, HW, C]
-    tpos = pos1d(D, L)[None]                         # [1, L, D]
+    vpos = pos2d(C, H, W)[None].to(fq.dtype)                      # [1, HW, C]
+    tpos = pos1d(D, L)[None].to(fq.dtype)                         # [1, L, D]
     vis = fq.reshape(B, C, H * W).permute(0, 2, 1)   # [B, HW, C]
     txt = word
     for i in range(head.num_layers):
@@ -335,7 +335,7 @@ def bce_with_logits_mean(x, t):
 def cris_forward(sd: Dict[str, torch.Tensor], clip, head, img, word, mask=None, training=True,
                  drop_seed: Optional[int] = None, bn_updates: Optional[dict] = None, taps: Optional[dict] = None):
     pad_mask = (word == 0)
-    v3, v4, v5 = encode_image(img.float(), sd, clip, training, bn_updates, taps)
+    v3, v4, v5 = encode_image(img.to(sd["backbone.visual.conv1.weight"].dtype), sd, clip, training, bn_updates, taps)
     wfeat, state = encode_text(word, sd, clip, taps)
     fq = fpn(v3, v4, v5, state, sd, training, bn_updates, taps)
     if taps is not None:
