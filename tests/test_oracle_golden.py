@@ -60,7 +60,8 @@ def test_oracle_matches_reference(name):
             flat = leaf[k].grad.flatten()
             n = min(64, flat.numel())
             idx = (torch.arange(n, dtype=torch.int64) * (flat.numel() - 1)) // max(n - 1, 1)
-            np.testing.assert_allclose(flat[idx].numpy(), g[key], rtol=5e-3, atol=1e-6 + 1e-2 * np.abs(g[key]).max())
+            a, r = flat[idx].double().numpy(), g[key].astype(np.float64)
+            assert np.linalg.norm(a - r) <= 1e-2 * np.linalg.norm(r) + 1e-9, (k, np.abs(a - r).max(), np.abs(r).max())
         if key.startswith("rm:"):
             k = key[3:]
             np.testing.assert_allclose(bnu[k[:-len(".running_mean")]][0].numpy(), g[key], rtol=1e-4, atol=1e-5)
