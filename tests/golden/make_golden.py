@@ -29,7 +29,7 @@ CASES = {
     # name: (spec, batch, size, dropout-free)
     "tiny_b2_s64": ("tiny", 2, 64),
     "tiny_b3_s96": ("tiny", 3, 96),
-    "r50_b2_s96": ("r50", 2, 96),
+    "r50_b2_s160": ("r50", 2, 160),
 }
 
 
