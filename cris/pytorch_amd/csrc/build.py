@@ -1,0 +1,54 @@
+"""Build libcris_hip.so for gfx950 (hipcc cross-compiles without a GPU).  In-tree output:
+cris/pytorch_amd/csrc/libcris_hip.so (git-ignored, shipped to the GPU box by gpurun)."""
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = ["api.hip", "gemm.hip", "norm.hip", "attention.hip", "elementwise.hip"]
+LIB = os.path.join(HERE, "libcris_hip.so")
+STAMP = os.path.join(HERE, ".build_stamp")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+
+
+def _digest():
+    h = hashlib.sha256()
+    for f in SOURCES + ["common.h", os.path.join("..", "..", "..", "include", "cris_hip.h")]:
+        with open(os.path.join(HERE, f), "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(HERE, src.replace(".hip", ".o"))
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(HERE, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
+        if verbose and out:
+            print(out.decode())
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stdout.decode())
+    with open(STAMP, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

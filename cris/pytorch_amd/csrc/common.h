@@ -1,0 +1,80 @@
+// Shared device helpers for libcris_hip.so (gfx950 / CDNA4 only - no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+typedef unsigned short bf16_t;                                   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;       // MFMA 16x16x32 A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) short s16x4;         // MFMA 16x16x16 A/B fragment (2 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;         // MFMA 16x16 C/D fragment
+
+#define CRIS_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {                // round to nearest even
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bflo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bfhi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// 8 bf16 <-> 8 floats
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    f[0] = bflo(v.x); f[1] = bfhi(v.x); f[2] = bflo(v.y); f[3] = bfhi(v.y);
+    f[4] = bflo(v.z); f[5] = bfhi(v.z); f[6] = bflo(v.w); f[7] = bfhi(v.w);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = pack2bf(f[0], f[1]); v.y = pack2bf(f[2], f[3]); v.z = pack2bf(f[4], f[5]); v.w = pack2bf(f[6], f[7]);
+    return v;
+}
+
+// Counter-based dropout decision (restated in oracle/dropout_hash.py - keep the two in sync).
+__device__ __forceinline__ uint32_t cris_fmix32(uint32_t v) {
+    v ^= v >> 16; v *= 0x85EBCA6Bu; v ^= v >> 13; v *= 0xC2B2AE35u; v ^= v >> 16;
+    return v;
+}
+__device__ __forceinline__ uint32_t cris_drop_key(uint32_t seed, uint32_t stream) { return seed ^ (stream * 0x9E3779B9u); }
+__device__ __forceinline__ bool cris_keep(uint32_t key, uint32_t idx, uint32_t thresh) {
+    return cris_fmix32(idx * 0x9E3779B1u + key) >= thresh;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- host side -------------------------------------------------------------------------------
+void cris_set_error(const char* fmt, ...);
+#define CRIS_CHECK_ARG(cond, msg)                                   \
+    do {                                                            \
+        if (!(cond)) {                                              \
+            cris_set_error("%s: %s", __func__, msg);                \
+            return -1;                                              \
+        }                                                           \
+    } while (0)
+#define CRIS_LAUNCH_CHECK()                                                          \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            cris_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_)); \
+            return (int)e_;                                                          \
+        }                                                                            \
+    } while (0)
+
+static inline int cris_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int cris_grid_1d(long work_items, int per_block, int cap = 8192) {
+    long g = (work_items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}

@@ -1,0 +1,718 @@
+// Data-movement / elementwise / small reduction kernels of the CRIS path (all HBM- or latency-bound).
+// bf16 tensors are accessed as 16-byte vectors (8 channels per lane) wherever the layout allows.
+#include "common.h"
+#include "../../../include/cris_hip.h"
+
+__device__ __forceinline__ void ld8f(const float* p, float* f) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void ld8bf(const bf16_t* p, float* f) { unpack8(*reinterpret_cast<const uint4*>(p), f); }
+__device__ __forceinline__ void st8bf(bf16_t* p, const float* f) { *reinterpret_cast<uint4*>(p) = pack8(f); }
+
+#define GRID_STRIDE(idx, total) \
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (total); idx += (long)gridDim.x * blockDim.x)
+
+// ------------------------------------------------------------------------------------------------
+// stem im2col: fp32 NCHW -> bf16 [B*OH*OW][32], k = ci*9 + kh*3 + kw (3x3, stride 2, pad 1)
+// ------------------------------------------------------------------------------------------------
+__global__ void stem_im2col_kernel(const float* __restrict__ img, int Bn, int H, int W, int OH, int OW, bf16_t* __restrict__ out) {
+    const long total = (long)Bn * OH * OW * 4;
+    GRID_STRIDE(idx, total) {
+        const int kc = (int)(idx & 3);
+        const long m = idx >> 2;
+        const int ow = (int)(m % OW);
+        const int oh = (int)((m / OW) % OH);
+        const int b = (int)(m / ((long)OW * OH));
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kc * 8 + j;
+            float x = 0.f;
+            if (k < 27) {
+                const int ci = k / 9, t = k - ci * 9;
+                const int kh = t / 3, kw = t - kh * 3;
+                const int ih = oh * 2 + kh - 1, iw = ow * 2 + kw - 1;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) x = img[(((size_t)b * 3 + ci) * H + ih) * W + iw];
+            }
+            v[j] = x;
+        }
+        st8bf(out + m * 32 + kc * 8, v);
+    }
+}
+
+extern "C" int cris_stem_im2col(const float* img, int Bn, int H, int W, cris_bf16* out, void* stream) {
+    CRIS_CHECK_ARG(img && out && Bn > 0 && H > 0 && W > 0, "bad args");
+    const int OH = (H + 2 - 3) / 2 + 1, OW = (W + 2 - 3) / 2 + 1;
+    const long total = (long)Bn * OH * OW * 4;
+    hipLaunchKernelGGL(stem_im2col_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, img, Bn, H, W, OH, OW, out);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// 2x2 average pool
+// ------------------------------------------------------------------------------------------------
+__global__ void avgpool2_fwd_kernel(const bf16_t* __restrict__ x, int ldx, int xcoff, int Bn, int H, int W, int C,
+                                    bf16_t* __restrict__ y, int ldy, int ycoff) {
+    const int CV = C >> 3, OH = H >> 1, OW = W >> 1;
+    const long total = (long)Bn * OH * OW * CV;
+    GRID_STRIDE(idx, total) {
+        const int cv = (int)(idx % CV);
+        const long mo = idx / CV;
+        const int ow = (int)(mo % OW);
+        const int oh = (int)((mo / OW) % OH);
+        const int b = (int)(mo / ((long)OW * OH));
+        float o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t[8];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                ld8bf(x + (((size_t)b * H + oh * 2 + dy) * W + ow * 2 + dx) * ldx + xcoff + cv * 8, t);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += t[j];
+            }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
+        st8bf(y + (size_t)mo * ldy + ycoff + cv * 8, o);
+    }
+}
+
+extern "C" int cris_avgpool2_fwd(const cris_bf16* x, int ldx, int xcoff, int Bn, int H, int W, int C, cris_bf16* y,
+                                 int ldy, int ycoff, void* stream) {
+    CRIS_CHECK_ARG(x && y && !(H & 1) && !(W & 1) && !(C & 7) && !(ldx & 7) && !(ldy & 7) && !(xcoff & 7) && !(ycoff & 7), "bad args");
+    const long total = (long)Bn * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(avgpool2_fwd_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, xcoff,
+                       Bn, H, W, C, y, ldy, ycoff);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void avgpool2_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, int dycoff, int Bn, int H, int W, int C,
+                                    bf16_t* __restrict__ dx, int lddx, int dxcoff, int accum) {
+    const int CV = C >> 3, OH = H >> 1, OW = W >> 1;
+    const long total = (long)Bn * H * W * CV;
+    GRID_STRIDE(idx, total) {
+        const int cv = (int)(idx % CV);
+        const long m = idx / CV;
+        const int w = (int)(m % W);
+        const int h = (int)((m / W) % H);
+        const int b = (int)(m / ((long)W * H));
+        float g[8];
+        ld8bf(dy + (((size_t)b * OH + (h >> 1)) * OW + (w >> 1)) * lddy + dycoff + cv * 8, g);
+        bf16_t* d = dx + (size_t)m * lddx + dxcoff + cv * 8;
+        float o[8];
+        if (accum) ld8bf(d, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (accum ? o[j] : 0.f) + 0.25f * g[j];
+        st8bf(d, o);
+    }
+}
+
+extern "C" int cris_avgpool2_bwd(const cris_bf16* dy, int lddy, int dycoff, int Bn, int H, int W, int C, cris_bf16* dx,
+                                 int lddx, int dxcoff, int accum, void* stream) {
+    CRIS_CHECK_ARG(dy && dx && !(H & 1) && !(W & 1) && !(C & 7) && !(lddx & 7) && !(lddy & 7) && !(dxcoff & 7) && !(dycoff & 7), "bad args");
+    const long total = (long)Bn * H * W * (C / 8);
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dycoff,
+                       Bn, H, W, C, dx, lddx, dxcoff, accum);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// x2 bilinear upsample, align_corners=False:  src = max(0, (dst+0.5)/2 - 0.5)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void up2_src(int dst, int n_in, int& i0, int& i1, float& l1) {
+    float s = (dst + 0.5f) * 0.5f - 0.5f;
+    s = fmaxf(s, 0.f);
+    i0 = (int)s;
+    i1 = i0 < n_in - 1 ? i0 + 1 : i0;
+    l1 = s - (float)i0;
+}
+
+__global__ void upsample2_fwd_kernel(const bf16_t* __restrict__ x, int ldx, int xcoff, int Bn, int H, int W, int C,
+                                     bf16_t* __restrict__ y, int ldy, int ycoff) {
+    const int CV = C >> 3, OH = H * 2, OW = W * 2;
+    const long total = (long)Bn * OH * OW * CV;
+    GRID_STRIDE(idx, total) {
+        const int cv = (int)(idx % CV);
+        const long mo = idx / CV;
+        const int ow = (int)(mo % OW);
+        const int oh = (int)((mo / OW) % OH);
+        const int b = (int)(mo / ((long)OW * OH));
+        int y0, y1, x0, x1;
+        float ly, lx;
+        up2_src(oh, H, y0, y1, ly);
+        up2_src(ow, W, x0, x1, lx);
+        const bf16_t* base = x + (size_t)b * H * W * ldx + xcoff + cv * 8;
+        float a[8], bb[8], c[8], d[8], o[8];
+        ld8bf(base + ((size_t)y0 * W + x0) * ldx, a);
+        ld8bf(base + ((size_t)y0 * W + x1) * ldx, bb);
+        ld8bf(base + ((size_t)y1 * W + x0) * ldx, c);
+        ld8bf(base + ((size_t)y1 * W + x1) * ldx, d);
+        const float w00 = (1.f - ly) * (1.f - lx), w01 = (1.f - ly) * lx, w10 = ly * (1.f - lx), w11 = ly * lx;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = w00 * a[j] + w01 * bb[j] + w10 * c[j] + w11 * d[j];
+        st8bf(y + (size_t)mo * ldy + ycoff + cv * 8, o);
+    }
+}
+
+extern "C" int cris_upsample2_fwd(const cris_bf16* x, int ldx, int xcoff, int Bn, int H, int W, int C, cris_bf16* y,
+                                  int ldy, int ycoff, void* stream) {
+    CRIS_CHECK_ARG(x && y && !(C & 7) && !(ldx & 7) && !(ldy & 7) && !(xcoff & 7) && !(ycoff & 7), "bad args");
+    const long total = (long)Bn * H * W * 4 * (C / 8);
+    hipLaunchKernelGGL(upsample2_fwd_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx, xcoff,
+                       Bn, H, W, C, y, ldy, ycoff);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void upsample2_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, int dycoff, int Bn, int H, int W, int C,
+                                     bf16_t* __restrict__ dx, int lddx, int dxcoff, int accum) {
+    // gather form: input pixel (iy,ix) collects from output rows/cols 2i-2 .. 2i+2 whose source taps hit it
+    const int CV = C >> 3, OH = H * 2, OW = W * 2;
+    const long total = (long)Bn * H * W * CV;
+    GRID_STRIDE(idx, total) {
+        const int cv = (int)(idx % CV);
+        const long m = idx / CV;
+        const int ix = (int)(m % W);
+        const int iy = (int)((m / W) % H);
+        const int b = (int)(m / ((long)W * H));
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bf16_t* base = dy + (size_t)b * OH * OW * lddy + dycoff + cv * 8;
+        for (int oy = max(0, 2 * iy - 2); oy <= min(OH - 1, 2 * iy + 2); ++oy) {
+            int y0, y1; float ly;
+            up2_src(oy, H, y0, y1, ly);
+            float wy = 0.f;
+            if (y0 == iy) wy += 1.f - ly;
+            if (y1 == iy) wy += ly;
+            if (wy == 0.f) continue;
+            for (int ox = max(0, 2 * ix - 2); ox <= min(OW - 1, 2 * ix + 2); ++ox) {
+                int x0, x1; float lx;
+                up2_src(ox, W, x0, x1, lx);
+                float wx = 0.f;
+                if (x0 == ix) wx += 1.f - lx;
+                if (x1 == ix) wx += lx;
+                if (wx == 0.f) continue;
+                float g[8];
+                ld8bf(base + ((size_t)oy * OW + ox) * lddy, g);
+                const float w = wy * wx;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += w * g[j];
+            }
+        }
+        bf16_t* d = dx + (size_t)m * lddx + dxcoff + cv * 8;
+        if (accum) {
+            float o[8];
+            ld8bf(d, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += o[j];
+        }
+        st8bf(d, acc);
+    }
+}
+
+extern "C" int cris_upsample2_bwd(const cris_bf16* dy, int lddy, int dycoff, int Bn, int H, int W, int C, cris_bf16* dx,
+                                  int lddx, int dxcoff, int accum, void* stream) {
+    CRIS_CHECK_ARG(dy && dx && !(C & 7) && !(lddx & 7) && !(lddy & 7) && !(dxcoff & 7) && !(dycoff & 7), "bad args");
+    const long total = (long)Bn * H * W * (C / 8);
+    hipLaunchKernelGGL(upsample2_bwd_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, dy, lddy, dycoff,
+                       Bn, H, W, C, dx, lddx, dxcoff, accum);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CoordConv channels: x = linspace(-1,1,W)[w], y = linspace(-1,1,H)[h]  (torch.linspace symmetric formula)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float linspace_m1_1(int i, int n) {
+    if (n == 1) return -1.f;
+    const float step = 2.f / (float)(n - 1);
+    return i < n / 2 ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
+}
+
+__global__ void fill_coords_kernel(bf16_t* x, int ldx, int coff, int nfill, int Bn, int H, int W) {
+    const long total = (long)Bn * H * W;
+    GRID_STRIDE(m, total) {
+        const int w = (int)(m % W);
+        const int h = (int)((m / W) % H);
+        bf16_t* d = x + (size_t)m * ldx + coff;
+        d[0] = f2bf(linspace_m1_1(w, W));
+        d[1] = f2bf(linspace_m1_1(h, H));
+        for (int j = 2; j < nfill; ++j) d[j] = 0;
+    }
+}
+
+extern "C" int cris_fill_coords(cris_bf16* x, int ldx, int coff, int nfill, int Bn, int H, int W, void* stream) {
+    CRIS_CHECK_ARG(x && nfill >= 2, "bad args");
+    hipLaunchKernelGGL(fill_coords_kernel, dim3(cris_grid_1d((long)Bn * H * W, 256)), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       coff, nfill, Bn, H, W);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adds / casts
+// ------------------------------------------------------------------------------------------------
+__global__ void add_bf16_kernel(const bf16_t* a, int lda, int acoff, const bf16_t* b, int ldb, int bcoff, bf16_t* y, int ldy,
+                                int ycoff, int M, int C) {
+    const int CV = C >> 3;
+    const long total = (long)M * CV;
+    GRID_STRIDE(idx, total) {
+        const int cv = (int)(idx % CV);
+        const long m = idx / CV;
+        float u[8], v[8];
+        ld8bf(a + (size_t)m * lda + acoff + cv * 8, u);
+        if (b) {
+            ld8bf(b + (size_t)m * ldb + bcoff + cv * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) u[j] += v[j];
+        }
+        st8bf(y + (size_t)m * ldy + ycoff + cv * 8, u);
+    }
+}
+
+extern "C" int cris_add_bf16(const cris_bf16* a, int lda, int acoff, const cris_bf16* b, int ldb, int bcoff, cris_bf16* y,
+                             int ldy, int ycoff, int M, int C, void* stream) {
+    CRIS_CHECK_ARG(a && y && !(C & 7) && !(lda & 7) && !(ldy & 7) && !(acoff & 7) && !(ycoff & 7) && (!b || (!(ldb & 7) && !(bcoff & 7))), "bad args");
+    hipLaunchKernelGGL(add_bf16_kernel, dim3(cris_grid_1d((long)M * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream, a, lda,
+                       acoff, b, ldb, bcoff, y, ldy, ycoff, M, C);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void add_rowtable_kernel(const bf16_t* a, int lda, const float* table, int trows, bf16_t* y, int ldy, int M, int C) {
+    const int CV = C >> 3;
+    const long total = (long)M * CV;
+    GRID_STRIDE(idx, total) {
+        const int cv = (int)(idx % CV);
+        const long m = idx / CV;
+        float u[8], v[8];
+        ld8bf(a + (size_t)m * lda + cv * 8, u);
+        ld8f(table + (size_t)(m % trows) * C + cv * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) u[j] += v[j];
+        st8bf(y + (size_t)m * ldy + cv * 8, u);
+    }
+}
+
+extern "C" int cris_add_rowtable(const cris_bf16* a, int lda, const float* table, int trows, cris_bf16* y, int ldy, int M,
+                                 int C, void* stream) {
+    CRIS_CHECK_ARG(a && table && y && trows > 0 && !(C & 7) && !(lda & 7) && !(ldy & 7), "bad args");
+    hipLaunchKernelGGL(add_rowtable_kernel, dim3(cris_grid_1d((long)M * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream, a,
+                       lda, table, trows, y, ldy, M, C);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void cast_f32_bf16_kernel(const float* x, bf16_t* y, long n) {
+    GRID_STRIDE(i, n) y[i] = f2bf(x[i]);
+}
+extern "C" int cris_cast_f32_bf16(const float* x, cris_bf16* y, long n, void* stream) {
+    CRIS_CHECK_ARG(x && y && n > 0, "bad args");
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(cris_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* x, float* y, long n, int accum) {
+    GRID_STRIDE(i, n) y[i] = (accum ? y[i] : 0.f) + bf2f(x[i]);
+}
+extern "C" int cris_cast_bf16_f32(const cris_bf16* x, float* y, long n, int accum, void* stream) {
+    CRIS_CHECK_ARG(x && y && n > 0, "bad args");
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(cris_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, accum);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void memset_f32_kernel(float* p, float v, long n) {
+    GRID_STRIDE(i, n) p[i] = v;
+}
+extern "C" int cris_memset_f32(float* p, float v, long n, void* stream) {
+    CRIS_CHECK_ARG(p && n > 0, "bad args");
+    hipLaunchKernelGGL(memset_f32_kernel, dim3(cris_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, p, v, n);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// embedding
+// ------------------------------------------------------------------------------------------------
+__global__ void embed_fwd_kernel(const int64_t* tokens, const float* table, const float* pos, int Bn, int L, int D, float* out) {
+    const int DV = D >> 2;
+    const long total = (long)Bn * L * DV;
+    GRID_STRIDE(idx, total) {
+        const int dv = (int)(idx % DV);
+        const long r = idx / DV;
+        const int l = (int)(r % L);
+        const int64_t tok = tokens[r];
+        const float4 e = *reinterpret_cast<const float4*>(table + (size_t)tok * D + dv * 4);
+        const float4 q = *reinterpret_cast<const float4*>(pos + (size_t)l * D + dv * 4);
+        *reinterpret_cast<float4*>(out + (size_t)r * D + dv * 4) = make_float4(e.x + q.x, e.y + q.y, e.z + q.z, e.w + q.w);
+    }
+}
+extern "C" int cris_embed_fwd(const int64_t* tokens, const float* table, const float* pos, int Bn, int L, int D, float* out,
+                              void* stream) {
+    CRIS_CHECK_ARG(tokens && table && pos && out && !(D & 3), "bad args");
+    hipLaunchKernelGGL(embed_fwd_kernel, dim3(cris_grid_1d((long)Bn * L * (D / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                       tokens, table, pos, Bn, L, D, out);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void embed_bwd_kernel(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos) {
+    const long total = (long)Bn * L * D;
+    GRID_STRIDE(idx, total) {
+        const int d = (int)(idx % D);
+        const long r = idx / D;
+        const int l = (int)(r % L);
+        const float g = dx[idx];
+        atomicAdd(dtable + (size_t)tokens[r] * D + d, g);
+        atomicAdd(dpos + (size_t)l * D + d, g);
+    }
+}
+extern "C" int cris_embed_bwd(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos,
+                              void* stream) {
+    CRIS_CHECK_ARG(tokens && dx && dtable && dpos, "bad args");
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(cris_grid_1d((long)Bn * L * D, 256)), dim3(256), 0, (hipStream_t)stream, tokens, dx,
+                       Bn, L, D, dtable, dpos);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// EOT select: argmax over token ids (first max wins), gather that row
+__global__ void eot_gather_kernel(const int64_t* tokens, const bf16_t* x, int L, int D, bf16_t* out, int* eot_index) {
+    __shared__ int s_idx;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int best = 0;
+        int64_t bv = tokens[(size_t)b * L];
+        for (int l = 1; l < L; ++l) {
+            const int64_t v = tokens[(size_t)b * L + l];
+            if (v > bv) { bv = v; best = l; }
+        }
+        s_idx = best;
+        eot_index[b] = best;
+    }
+    __syncthreads();
+    const bf16_t* src = x + ((size_t)b * L + s_idx) * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) out[(size_t)b * D + d] = src[d];
+}
+extern "C" int cris_eot_gather(const int64_t* tokens, const cris_bf16* x, int Bn, int L, int D, cris_bf16* out, int* eot_index,
+                               void* stream) {
+    CRIS_CHECK_ARG(tokens && x && out && eot_index, "bad args");
+    hipLaunchKernelGGL(eot_gather_kernel, dim3(Bn), dim3(256), 0, (hipStream_t)stream, tokens, x, L, D, out, eot_index);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void eot_scatter_add_kernel(const int* eot_index, const bf16_t* g, int L, int D, bf16_t* dx) {
+    const int b = blockIdx.x;
+    bf16_t* dst = dx + ((size_t)b * L + eot_index[b]) * D;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) dst[d] = f2bf(bf2f(dst[d]) + bf2f(g[(size_t)b * D + d]));
+}
+extern "C" int cris_eot_scatter_add(const int* eot_index, const cris_bf16* dstate_rows, int Bn, int L, int D, cris_bf16* dx,
+                                    void* stream) {
+    CRIS_CHECK_ARG(eot_index && dstate_rows && dx, "bad args");
+    hipLaunchKernelGGL(eot_scatter_add_kernel, dim3(Bn), dim3(256), 0, (hipStream_t)stream, eot_index, dstate_rows, L, D, dx);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// attnpool positional embedding resize (constant linear map R [T][G*G]) and helpers
+// ------------------------------------------------------------------------------------------------
+__global__ void posresize_fwd_kernel(const float* R, const float* pos, int T, int GG, int C, float* posr) {
+    const long total = (long)T * C;
+    GRID_STRIDE(idx, total) {
+        const int c = (int)(idx % C);
+        const int t = (int)(idx / C);
+        float s = 0.f;
+        for (int j = 0; j < GG; ++j) s += R[t * GG + j] * pos[(size_t)(1 + j) * C + c];
+        posr[idx] = s;
+    }
+}
+extern "C" int cris_posresize_fwd(const float* R, const float* pos, int T, int G, int C, float* posr, void* stream) {
+    CRIS_CHECK_ARG(R && pos && posr, "bad args");
+    hipLaunchKernelGGL(posresize_fwd_kernel, dim3(cris_grid_1d((long)T * C, 256)), dim3(256), 0, (hipStream_t)stream, R, pos, T,
+                       G * G, C, posr);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void posresize_bwd_kernel(const float* R, const float* dposr, int T, int GG, int C, float* dpos) {
+    const long total = (long)GG * C;
+    GRID_STRIDE(idx, total) {
+        const int c = (int)(idx % C);
+        const int j = (int)(idx / C);
+        float s = 0.f;
+        for (int t = 0; t < T; ++t) s += R[t * GG + j] * dposr[(size_t)t * C + c];
+        dpos[(size_t)(1 + j) * C + c] += s;
+    }
+}
+extern "C" int cris_posresize_bwd(const float* R, const float* dposr, int T, int G, int C, float* dpos, void* stream) {
+    CRIS_CHECK_ARG(R && dposr && dpos, "bad args");
+    hipLaunchKernelGGL(posresize_bwd_kernel, dim3(cris_grid_1d((long)G * G * C, 256)), dim3(256), 0, (hipStream_t)stream, R,
+                       dposr, T, G * G, C, dpos);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void batch_rowsum_kernel(const bf16_t* dx, int ldx, int Bn, int T, int C, float* out) {
+    const long total = (long)T * C;
+    GRID_STRIDE(idx, total) {
+        const int c = (int)(idx % C);
+        const int t = (int)(idx / C);
+        float s = 0.f;
+        for (int b = 0; b < Bn; ++b) s += bf2f(dx[((size_t)b * T + t) * ldx + c]);
+        out[idx] = s;
+    }
+}
+extern "C" int cris_batch_rowsum(const cris_bf16* dx, int ldx, int Bn, int T, int C, float* out, void* stream) {
+    CRIS_CHECK_ARG(dx && out, "bad args");
+    hipLaunchKernelGGL(batch_rowsum_kernel, dim3(cris_grid_1d((long)T * C, 256)), dim3(256), 0, (hipStream_t)stream, dx, ldx, Bn,
+                       T, C, out);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// text-to-pixel dynamic 3x3 conv (groups = batch): pred[b,oh,ow] = sum_{c,kh,kw} x[b,oh+kh-1,ow+kw-1,c] w[b][c*9+kh*3+kw] + bias[b]
+// one lane = 8 channels; LP = C/8 lanes cooperate on a pixel (LP power of two <= 64)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dynconv_fwd_kernel(const bf16_t* __restrict__ x, int H, int W, int C, const float* __restrict__ wb,
+                                                          int ldwb, float* __restrict__ pred, int pix_per_block) {
+    const int b = blockIdx.y;
+    const int LP = C >> 3;
+    const int cl = threadIdx.x % LP, sub = threadIdx.x / LP, nsub = 256 / LP;
+    float w[9][8];
+    const float* wp = wb + (size_t)b * ldwb;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[t][j] = wp[(cl * 8 + j) * 9 + t];
+    const float bias = wp[C * 9];
+    const int HW = H * W;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    for (int pb = p0; pb < p1; pb += nsub) {
+        const int pix = pb + sub;
+        float acc = 0.f;
+        if (pix < p1) {
+            const int oh = pix / W, ow = pix - oh * W;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ih = oh + kh - 1, iw = ow + kw - 1;
+                    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                        float v[8];
+                        ld8bf(x + (((size_t)b * H + ih) * W + iw) * C + cl * 8, v);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) acc += v[j] * w[kh * 3 + kw][j];
+                    }
+                }
+        }
+        for (int o = LP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (cl == 0 && pix < p1) pred[(size_t)b * HW + pix] = acc + bias;
+    }
+}
+
+extern "C" int cris_dynconv_fwd(const cris_bf16* x, int Bn, int H, int W, int C, const float* wb, int ldwb, float* pred,
+                                void* stream) {
+    const int LP = C / 8;
+    CRIS_CHECK_ARG(x && wb && pred && !(C & 7) && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "C/8 must be a power of two <= 64");
+    const int ppb = 256;
+    dim3 grid(cris_cdiv(H * W, ppb), Bn);
+    hipLaunchKernelGGL(dynconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, C, wb, ldwb, pred, ppb);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void dynconv_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dpred, int H, int W, int C,
+                                                          const float* __restrict__ wb, int ldwb, bf16_t* __restrict__ dx,
+                                                          float* __restrict__ dwb, int pix_per_block) {
+    extern __shared__ float sdw[];              // [C*9 + 1]
+    const int b = blockIdx.y;
+    const int LP = C >> 3;
+    const int cl = threadIdx.x % LP, sub = threadIdx.x / LP, nsub = 256 / LP;
+    for (int i = threadIdx.x; i < C * 9 + 1; i += 256) sdw[i] = 0.f;
+    __syncthreads();
+    float w[9][8], dw[9][8];
+    const float* wp = wb + (size_t)b * ldwb;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            w[t][j] = wp[(cl * 8 + j) * 9 + t];
+            dw[t][j] = 0.f;
+        }
+    float dbias = 0.f;
+    const int HW = H * W;
+    const float* dp = dpred + (size_t)b * HW;
+    const int p0 = blockIdx.x * pix_per_block;
+    const int p1 = min(HW, p0 + pix_per_block);
+    for (int pix = p0 + sub; pix < p1; pix += nsub) {
+        const int ph = pix / W, pw = pix - ph * W;
+        // (1) dx at this pixel: sum over taps of dpred[ph-kh+1, pw-kw+1] * w[tap]
+        // (2) dw[tap] += dpred[ph,pw] * x[ph+kh-1, pw+kw-1]
+        float gx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const float g0 = dp[pix];
+        if (cl == 0) dbias += g0;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int oh = ph - kh + 1, ow = pw - kw + 1;
+                if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
+                    const float g = dp[oh * W + ow];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) gx[j] += g * w[kh * 3 + kw][j];
+                }
+                const int ih = ph + kh - 1, iw = pw + kw - 1;
+                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+                    float v[8];
+                    ld8bf(x + (((size_t)b * H + ih) * W + iw) * C + cl * 8, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) dw[kh * 3 + kw][j] += g0 * v[j];
+                }
+            }
+        st8bf(dx + ((size_t)b * HW + pix) * C + cl * 8, gx);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(&sdw[(cl * 8 + j) * 9 + t], dw[t][j]);
+    if (cl == 0) atomicAdd(&sdw[C * 9], dbias);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 9 + 1; i += 256) atomicAdd(dwb + (size_t)b * ldwb + i, sdw[i]);
+}
+
+extern "C" int cris_dynconv_bwd(const cris_bf16* x, const float* dpred, int Bn, int H, int W, int C, const float* wb, int ldwb,
+                                cris_bf16* dx, float* dwb, void* stream) {
+    const int LP = C / 8;
+    CRIS_CHECK_ARG(x && dpred && wb && dx && dwb && !(C & 7) && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "bad args");
+    const int ppb = 512;
+    dim3 grid(cris_cdiv(H * W, ppb), Bn);
+    hipLaunchKernelGGL(dynconv_bwd_kernel, grid, dim3(256), (size_t)(C * 9 + 1) * sizeof(float), (hipStream_t)stream, x, dpred, H, W,
+                       C, wb, ldwb, dx, dwb, ppb);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mask resize (nearest), BCE with logits (mean), train metric
+// ------------------------------------------------------------------------------------------------
+__global__ void mask_resize_kernel(const float* mask, int Bn, int IH, int IW, int OH, int OW, float* out) {
+    const float sh = (float)IH / (float)OH, sw = (float)IW / (float)OW;
+    const long total = (long)Bn * OH * OW;
+    GRID_STRIDE(idx, total) {
+        const int ow = (int)(idx % OW);
+        const int oh = (int)((idx / OW) % OH);
+        const int b = (int)(idx / ((long)OW * OH));
+        const int ih = min((int)floorf(oh * sh), IH - 1);
+        const int iw = min((int)floorf(ow * sw), IW - 1);
+        out[idx] = mask[((size_t)b * IH + ih) * IW + iw];
+    }
+}
+extern "C" int cris_mask_resize_nearest(const float* mask, int Bn, int IH, int IW, int OH, int OW, float* out, void* stream) {
+    CRIS_CHECK_ARG(mask && out, "bad args");
+    hipLaunchKernelGGL(mask_resize_kernel, dim3(cris_grid_1d((long)Bn * OH * OW, 256)), dim3(256), 0, (hipStream_t)stream, mask, Bn,
+                       IH, IW, OH, OW, out);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* x, const float* t, long n, float* loss_accum) {
+    __shared__ float sw[4];
+    float s = 0.f;
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        s += fmaxf(v, 0.f) - v * t[i] + log1pf(__expf(-fabsf(v)));
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss_accum, (sw[0] + sw[1] + sw[2] + sw[3]) / (float)n);
+}
+extern "C" int cris_bce_fwd(const float* logits, const float* target, long n, float* loss_accum, void* stream) {
+    CRIS_CHECK_ARG(logits && target && loss_accum && n > 0, "bad args");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(cris_grid_1d(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, logits, target, n, loss_accum);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void bce_bwd_kernel(const float* x, const float* t, long n, const float* gscale, float* dx) {
+    const float g = (gscale ? gscale[0] : 1.f) / (float)n;
+    GRID_STRIDE(i, n) {
+        const float v = x[i];
+        dx[i] = (1.f / (1.f + __expf(-v)) - t[i]) * g;
+    }
+}
+extern "C" int cris_bce_bwd(const float* logits, const float* target, long n, const float* gscale, float* dlogits, void* stream) {
+    CRIS_CHECK_ARG(logits && target && dlogits && n > 0, "bad args");
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(cris_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, logits, target, n, gscale, dlogits);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void train_metric_kernel(const float* x, const float* t, int Bn, int HW, float thr, float pr_iou, float* out) {
+    __shared__ float si[4], su[4];
+    const int b = blockIdx.x;
+    float inter = 0.f, uni = 0.f;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        const bool o = 1.f / (1.f + __expf(-x[(size_t)b * HW + i])) >= thr;
+        const bool g = t[(size_t)b * HW + i] != 0.f;
+        inter += (o && g) ? 1.f : 0.f;
+        uni += (o || g) ? 1.f : 0.f;
+    }
+    inter = wave_sum(inter);
+    uni = wave_sum(uni);
+    if ((threadIdx.x & 63) == 0) { si[threadIdx.x >> 6] = inter; su[threadIdx.x >> 6] = uni; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float iou = (si[0] + si[1] + si[2] + si[3]) / (su[0] + su[1] + su[2] + su[3] + 1e-6f);
+        atomicAdd(out, 100.f * iou / (float)Bn);
+        atomicAdd(out + 1, (iou > pr_iou ? 100.f : 0.f) / (float)Bn);
+    }
+}
+extern "C" int cris_train_metric(const float* logits, const float* target, int Bn, int HW, float thr, float pr_iou, float* out,
+                                 void* stream) {
+    CRIS_CHECK_ARG(logits && target && out, "bad args");
+    hipLaunchKernelGGL(train_metric_kernel, dim3(Bn), dim3(256), 0, (hipStream_t)stream, logits, target, Bn, HW, thr, pr_iou, out);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fused multi-tensor Adam (torch.optim.Adam, non-amsgrad)
+// ------------------------------------------------------------------------------------------------
+#define ADAM_ELEMS 8192
+__global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restrict__ tab, int n_desc, float beta1, float beta2, float eps,
+                                                   float wd, float bc1, float bc2, float gscale) {
+    int lo = 0, hi = n_desc - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block_start <= bid) lo = mid; else hi = mid - 1;
+    }
+    const cris_adam_desc d = tab[lo];
+    const long base = (long)(bid - d.block_start) * ADAM_ELEMS;
+    const float step = d.lr / bc1;
+    const float rsb2 = rsqrtf(bc2);
+    for (int e = threadIdx.x; e < ADAM_ELEMS; e += 256) {
+        const long i = base + e;
+        if (i >= d.n) break;
+        float g = d.g[i] * gscale;
+        float p = d.p[i];
+        if (wd != 0.f) g += wd * p;
+        const float m = beta1 * d.m[i] + (1.f - beta1) * g;
+        const float v = beta2 * d.v[i] + (1.f - beta2) * g * g;
+        d.m[i] = m;
+        d.v[i] = v;
+        d.p[i] = p - step * m / (sqrtf(v) * rsb2 + eps);
+    }
+}
+extern "C" int cris_adam_block_elems(void) { return ADAM_ELEMS; }
+extern "C" int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
+                              float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
+    CRIS_CHECK_ARG(dev_table && n_desc > 0 && total_blocks > 0, "empty table");
+    hipLaunchKernelGGL(adam_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dev_table, n_desc, beta1, beta2, eps,
+                       weight_decay, bias_corr1, bias_corr2, grad_scale);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}

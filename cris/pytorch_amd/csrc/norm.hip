@@ -1,0 +1,598 @@
+// BatchNorm (training statistics) and LayerNorm kernels for gfx950.  All HBM-bound: 16-byte vector
+// accesses (8 bf16 channels per lane), per-channel reductions accumulated in registers then LDS then one
+// global atomic per channel per block.
+#include "common.h"
+#include "../../../include/cris_hip.h"
+
+// ------------------------------------------------------------------------------------------------
+// BN coefficients
+// ------------------------------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, float count, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, float momentum, float eps, int C,
+                                   float* scale, float* shift, float* mean_o, float* invstd_o) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float mean = sum[c] / count;
+    float var = sumsq[c] / count - mean * mean;
+    var = fmaxf(var, 0.f);
+    const float inv = rsqrtf(var + eps);
+    const float sc = gamma[c] * inv;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    mean_o[c] = mean;
+    invstd_o[c] = inv;
+    if (rmean) {
+        const float unb = count > 1.f ? var * (count / (count - 1.f)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+    }
+}
+
+extern "C" int cris_bn_finalize(const float* sum, const float* sumsq, float count, const float* gamma,
+                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                int C, float* scale, float* shift, float* mean, float* invstd, void* stream) {
+    CRIS_CHECK_ARG(sum && sumsq && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0.f, "bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sum, sumsq, count,
+                       gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void bn_eval_kernel(const float* gamma, const float* beta, const float* rmean, const float* rvar, float eps,
+                               int C, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * rsqrtf(rvar[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+extern "C" int cris_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                   const float* running_var, float eps, int C, float* scale, float* shift, void* stream) {
+    CRIS_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bad args");
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(cris_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, C, scale, shift);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN apply (+ second branch, identity, ReLU, multiplier, 2x2 average pool, output statistics)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load8f(const float* p, float* f) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+__device__ __forceinline__ void load8bf(const bf16_t* p, float* f) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    unpack8(v, f);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const cris_bn_apply_params p) {
+    extern __shared__ float sstat[];                 // [2*C] when osum
+    const int CV = p.C >> 3;
+    const int OH = p.pool ? p.H / 2 : p.H, OW = p.pool ? p.W / 2 : p.W;
+    const long total = (long)p.Bn * OH * OW * CV;
+    if (p.osum) {
+        for (int i = threadIdx.x; i < 2 * p.C; i += blockDim.x) sstat[i] = 0.f;
+        __syncthreads();
+    }
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % CV);
+        const int mo = (int)(idx / CV);
+        const int c0 = cv * 8;
+        float sc[8], sh[8], o[8];
+        load8f(p.scale + c0, sc);
+        load8f(p.shift + c0, sh);
+        if (!p.pool) {
+            float y[8];
+            load8bf(p.y + (size_t)mo * p.ldy + p.y_coff + c0, y);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = y[j] * sc[j] + sh[j];
+            if (p.y2) {
+                float y2[8], s2[8], h2[8];
+                load8bf(p.y2 + (size_t)mo * p.ldy2 + p.y2_coff + c0, y2);
+                load8f(p.scale2 + c0, s2);
+                load8f(p.shift2 + c0, h2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += y2[j] * s2[j] + h2[j];
+            }
+            if (p.ident) {
+                float id[8];
+                load8bf(p.ident + (size_t)mo * p.ldi + p.i_coff + c0, id);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] += id[j];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f);
+            }
+            if (p.mul) {
+                const int b = mo / (p.H * p.W);
+                float mu[8];
+                load8f(p.mul + (size_t)b * p.C + c0, mu);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] *= mu[j];
+            }
+        } else {
+            const int b = mo / (OH * OW);
+            const int r = mo - b * OH * OW;
+            const int oh = r / OW, ow = r - oh * OW;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const size_t m = ((size_t)b * p.H + (oh * 2 + dy)) * p.W + (ow * 2 + dx);
+                    float y[8];
+                    load8bf(p.y + m * p.ldy + p.y_coff + c0, y);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float a = y[j] * sc[j] + sh[j];
+                        if (p.relu) a = fmaxf(a, 0.f);
+                        o[j] += a;
+                    }
+                }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
+        }
+        const uint4 packed = pack8(o);
+        *reinterpret_cast<uint4*>(p.z + (size_t)mo * p.ldz + p.z_coff + c0) = packed;
+        if (p.osum) {
+            float q[8];
+            unpack8(packed, q);                     // statistics of what the next layer actually reads
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&sstat[c0 + j], q[j]);
+                atomicAdd(&sstat[p.C + c0 + j], q[j] * q[j]);
+            }
+        }
+    }
+    if (p.osum) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.C; i += blockDim.x) {
+            atomicAdd(p.osum + i, sstat[i]);
+            atomicAdd(p.osq + i, sstat[p.C + i]);
+        }
+    }
+}
+
+extern "C" int cris_bn_apply(const cris_bn_apply_params* pp, void* stream) {
+    const cris_bn_apply_params& p = *pp;
+    CRIS_CHECK_ARG(p.y && p.scale && p.shift && p.z, "null operand");
+    CRIS_CHECK_ARG((p.C & 7) == 0 && (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && (p.ldz & 7) == 0 && (p.z_coff & 7) == 0,
+                   "channels / ld / offsets must be multiples of 8");
+    CRIS_CHECK_ARG(!p.pool || (!(p.H & 1) && !(p.W & 1) && !p.y2 && !p.ident && !p.mul), "pool needs even H,W and a plain BN");
+    CRIS_CHECK_ARG(!p.y2 || ((p.ldy2 & 7) == 0 && (p.y2_coff & 7) == 0 && p.scale2 && p.shift2), "branch 2");
+    CRIS_CHECK_ARG(!p.ident || ((p.ldi & 7) == 0 && (p.i_coff & 7) == 0), "identity ld/offset");
+    CRIS_CHECK_ARG(!p.osum || (p.osq && p.C <= 4096), "output statistics");
+    const long rows = (long)p.Bn * (p.pool ? (p.H / 2) * (p.W / 2) : p.H * p.W);
+    const long total = rows * (p.C >> 3);
+    const int cap = p.osum ? 512 : 8192;
+    const int grid = cris_grid_1d(total, 256, cap);
+    const size_t shm = p.osum ? (size_t)2 * p.C * sizeof(float) : 0;
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), shm, (hipStream_t)stream, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN backward: reduce (sum g, sum g*xhat [, branch 2]) then apply
+// ------------------------------------------------------------------------------------------------
+// gradient entering the BN output at full-resolution row m, channels c0..c0+7; also xhat (and xhat2)
+__device__ __forceinline__ void bn_bwd_point(const cris_bn_bwd_params& p, int m, int c0, float* g, float* xh, float* xh2,
+                                             bool want_dmul) {
+    float y[8], mean[8], inv[8];
+    load8bf(p.y + (size_t)m * p.ldy + p.y_coff + c0, y);
+    load8f(p.mean + c0, mean);
+    load8f(p.invstd + c0, inv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) xh[j] = (y[j] - mean[j]) * inv[j];
+    if (p.y2) {
+        float y2[8], m2[8], i2[8];
+        load8bf(p.y2 + (size_t)m * p.ldy2 + p.y2_coff + c0, y2);
+        load8f(p.mean2 + c0, m2);
+        load8f(p.invstd2 + c0, i2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xh2[j] = (y2[j] - m2[j]) * i2[j];
+    }
+    const int HW = p.H * p.W;
+    int mo = m;
+    float gscale = 1.f;
+    if (p.pool) {
+        const int b = m / HW;
+        const int r = m - b * HW;
+        const int h = r / p.W, w = r - h * p.W;
+        mo = (b * (p.H / 2) + (h >> 1)) * (p.W / 2) + (w >> 1);
+        gscale = 0.25f;
+    }
+    float dz[8];
+    load8bf(p.dz + (size_t)mo * p.lddz + p.dz_coff + c0, dz);
+    // ReLU mask
+    bool pos[8];
+    if (!p.relu) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pos[j] = true;
+    } else if (!p.pool && (p.y2 || p.z)) {
+        float z[8];
+        load8bf(p.z + (size_t)m * p.ldz + p.z_coff + c0, z);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pos[j] = z[j] > 0.f;
+    } else {
+        float sc[8], sh[8];
+        load8f(p.scale + c0, sc);
+        load8f(p.shift + c0, sh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pos[j] = (y[j] * sc[j] + sh[j]) > 0.f;
+    }
+    if (p.mul) {
+        const int b = m / HW;
+        float mu[8], sc[8], sh[8];
+        load8f(p.mul + (size_t)b * p.C + c0, mu);
+        if (want_dmul && p.dmul) {
+            load8f(p.scale + c0, sc);
+            load8f(p.shift + c0, sh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float a = fmaxf(y[j] * sc[j] + sh[j], 0.f);
+                if (a > 0.f) atomicAdd(p.dmul + (size_t)b * p.C + c0 + j, dz[j] * a);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dz[j] *= mu[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = pos[j] ? dz[j] * gscale : 0.f;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_params p, int rows_per_block) {
+    extern __shared__ float sred[];                // [4*C]
+    const int CV = p.C >> 3;
+    const int M = p.Bn * p.H * p.W;
+    const int nsum = p.y2 ? 4 : 2;
+    for (int i = threadIdx.x; i < nsum * p.C; i += 256) sred[i] = 0.f;
+    __syncthreads();
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    // thread -> fixed channel vector, strided rows (register accumulation)
+    for (int cvb = 0; cvb < CV; cvb += 256) {
+        const int cvn = min(256, CV - cvb);
+        const int RS = 256 / cvn;
+        const int cv = cvb + (int)threadIdx.x % cvn;
+        const int rsub = threadIdx.x / cvn;
+        if (rsub >= RS) continue;
+        float a0[8], a1[8], a3[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a0[j] = a1[j] = a3[j] = 0.f;
+        for (int m = r0 + rsub; m < r1; m += RS) {
+            float g[8], xh[8], xh2[8];
+            bn_bwd_point(p, m, cv * 8, g, xh, xh2, true);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a0[j] += g[j];
+                a1[j] += g[j] * xh[j];
+                if (p.y2) a3[j] += g[j] * xh2[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            atomicAdd(&sred[cv * 8 + j], a0[j]);
+            atomicAdd(&sred[p.C + cv * 8 + j], a1[j]);
+            if (p.y2) {
+                atomicAdd(&sred[2 * p.C + cv * 8 + j], a0[j]);
+                atomicAdd(&sred[3 * p.C + cv * 8 + j], a3[j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nsum * p.C; i += 256) atomicAdd(p.sums + i, sred[i]);
+}
+
+extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
+    const cris_bn_bwd_params& p = *pp;
+    CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums, "null operand");
+    CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 8192, "C");
+    CRIS_CHECK_ARG(!p.relu || p.pool || p.z || (p.scale && p.shift), "relu mask source");
+    CRIS_CHECK_ARG(!p.pool || (p.scale && p.shift && !p.y2 && !p.mul), "pool backward needs scale/shift, plain BN");
+    const int M = p.Bn * p.H * p.W;
+    int blocks = 1024;
+    int rpb = cris_cdiv(M, blocks);
+    if (rpb < 16) rpb = 16;
+    blocks = cris_cdiv(M, rpb);
+    const size_t shm = (size_t)(p.y2 ? 4 : 2) * p.C * sizeof(float);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), shm, (hipStream_t)stream, p, rpb);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_params p) {
+    const int CV = p.C >> 3;
+    const long total = (long)p.Bn * p.H * p.W * CV;
+    const float invc = 1.0f / p.count;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % CV);
+        const int m = (int)(idx / CV);
+        const int c0 = cv * 8;
+        float g[8], xh[8], xh2[8];
+        bn_bwd_point(p, m, c0, g, xh, xh2, false);
+        float s0[8], s1[8], sc[8], o[8];
+        load8f(p.sums + c0, s0);
+        load8f(p.sums + p.C + c0, s1);
+        load8f(p.scale + c0, sc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = sc[j] * (g[j] - s0[j] * invc - xh[j] * s1[j] * invc);
+        *reinterpret_cast<uint4*>(p.dy + (size_t)m * p.lddy + p.dy_coff + c0) = pack8(o);
+        if (p.y2 && p.dy2) {
+            float s3[8], sc2[8];
+            load8f(p.sums + 3 * p.C + c0, s3);
+            load8f(p.scale2 + c0, sc2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = sc2[j] * (g[j] - s0[j] * invc - xh2[j] * s3[j] * invc);
+            *reinterpret_cast<uint4*>(p.dy2 + (size_t)m * p.lddy2 + p.dy2_coff + c0) = pack8(o);
+        }
+        if (p.dident) {
+            bf16_t* dst = p.dident + (size_t)m * p.lddi + p.di_coff + c0;
+            if (p.dident_accum) {
+                float old[8];
+                load8bf(dst, old);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] += old[j];
+            }
+            *reinterpret_cast<uint4*>(dst) = pack8(g);
+        }
+    }
+}
+
+extern "C" int cris_bn_bwd_apply(const cris_bn_bwd_params* pp, void* stream) {
+    const cris_bn_bwd_params& p = *pp;
+    CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums && p.scale && p.dy, "null operand");
+    CRIS_CHECK_ARG((p.C & 7) == 0 && (p.lddy & 7) == 0 && (p.dy_coff & 7) == 0 && p.count > 0.f, "geometry");
+    const long total = (long)p.Bn * p.H * p.W * (p.C >> 3);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, up to 4 x 8 channels per lane (C <= 2048)
+// ------------------------------------------------------------------------------------------------
+#define LN_MAXV 4
+
+template <bool WANT_MASK>
+__device__ __forceinline__ void ln_load_row(const void* x, int x_f32, size_t rowoff, int C, int lane, int in_relu,
+                                            uint32_t in_thresh, float in_scale, uint32_t in_key, uint32_t row,
+                                            float (&v)[LN_MAXV][8], float (&mask_out)[LN_MAXV][8]) {
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c0 = (lane + 64 * i) * 8;
+        if (c0 < C) {
+            if (x_f32) load8f(reinterpret_cast<const float*>(x) + rowoff + c0, v[i]);
+            else load8bf(reinterpret_cast<const bf16_t*>(x) + rowoff + c0, v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float m = 1.f;
+                if (in_relu && !(v[i][j] > 0.f)) m = 0.f;
+                if (in_thresh) m = cris_keep(in_key, row * (uint32_t)C + (uint32_t)(c0 + j), in_thresh) ? m * in_scale : 0.f;
+                v[i][j] *= m;
+                if (WANT_MASK) mask_out[i][j] = m;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[i][j] = 0.f;
+                if (WANT_MASK) mask_out[i][j] = 0.f;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const cris_ln_fwd_params p) {
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    const uint32_t in_key = cris_drop_key(p.in_seed, p.in_stream);
+    const uint32_t out_key = cris_drop_key(p.out_seed, p.out_stream);
+    const float in_scale = p.in_thresh ? 1.f / (1.f - p.in_drop_p) : 1.f;
+    const float out_scale = p.out_thresh ? 1.f / (1.f - p.out_drop_p) : 1.f;
+    const float invC = 1.f / (float)p.C;
+    for (int row = wave_g; row < p.rows; row += nwaves) {
+        float v[LN_MAXV][8];
+        ln_load_row<false>(p.x, p.x_f32, (size_t)row * p.ldx, p.C, lane, p.in_relu, p.in_thresh, in_scale, in_key, (uint32_t)row,
+                           v, v);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[i][j];
+        const float mean = wave_sum(s) * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c0 = (lane + 64 * i) * 8;
+            if (c0 < p.C) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = v[i][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) * invC + p.eps);
+        if (lane == 0) {
+            p.mean[row] = mean;
+            p.rstd[row] = rstd;
+        }
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c0 = (lane + 64 * i) * 8;
+            if (c0 >= p.C) continue;
+            float ga[8], be[8], o[8];
+            load8f(p.gamma + c0, ga);
+            load8f(p.beta + c0, be);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * ga[j] + be[j];
+            const size_t oo = (size_t)row * p.C + c0;
+            if (p.y) *reinterpret_cast<uint4*>(p.y + oo) = pack8(o);
+            if (p.ypos) {
+                float pe[8], t[8];
+                load8f(p.pos + (size_t)(row % p.pos_rows) * p.C + c0, pe);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = o[j] + pe[j];
+                *reinterpret_cast<uint4*>(p.ypos + oo) = pack8(t);
+            }
+            if (p.out_f32) {
+                float r[8];
+                if (p.resid) load8f(p.resid + oo, r);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) r[j] = 0.f;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float t = o[j];
+                    if (p.out_thresh) t = cris_keep(out_key, (uint32_t)row * (uint32_t)p.C + (uint32_t)(c0 + j), p.out_thresh) ? t * out_scale : 0.f;
+                    r[j] += t;
+                }
+                *reinterpret_cast<float4*>(p.out_f32 + oo) = make_float4(r[0], r[1], r[2], r[3]);
+                *reinterpret_cast<float4*>(p.out_f32 + oo + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            }
+        }
+    }
+}
+
+extern "C" int cris_ln_fwd(const cris_ln_fwd_params* pp, void* stream) {
+    const cris_ln_fwd_params& p = *pp;
+    CRIS_CHECK_ARG(p.x && p.gamma && p.beta && p.mean && p.rstd && p.rows > 0, "null operand");
+    CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 64 * 8 * LN_MAXV && (p.ldx & 7) == 0, "C must be a multiple of 8, <= 2048");
+    CRIS_CHECK_ARG(!p.ypos || (p.pos && p.pos_rows > 0), "ypos needs pos");
+    CRIS_CHECK_ARG((long)p.rows * p.C < (1L << 32), "dropout index overflow");
+    const int grid = cris_grid_1d(p.rows, 4, 2048);
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p) {
+    __shared__ float sg[2][64 * 8 * LN_MAXV];        // dgamma / dbeta block accumulators
+    const int lane = threadIdx.x & 63;
+    const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    for (int i = threadIdx.x; i < 2 * 64 * 8 * LN_MAXV; i += 256) (&sg[0][0])[i] = 0.f;
+    __syncthreads();
+    const uint32_t in_key = cris_drop_key(p.in_seed, p.in_stream);
+    const uint32_t out_key = cris_drop_key(p.out_seed, p.out_stream);
+    const float in_scale = p.in_thresh ? 1.f / (1.f - p.in_drop_p) : 1.f;
+    const float out_scale = p.out_thresh ? 1.f / (1.f - p.out_drop_p) : 1.f;
+    const float invC = 1.f / (float)p.C;
+    float dga[LN_MAXV][8], dbe[LN_MAXV][8];
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dga[i][j] = dbe[i][j] = 0.f;
+
+    for (int row = wave_g; row < p.rows; row += nwaves) {
+        float v[LN_MAXV][8], msk[LN_MAXV][8];
+        ln_load_row<true>(p.x, p.x_f32, (size_t)row * p.ldx, p.C, lane, p.in_relu, p.in_thresh, in_scale, in_key, (uint32_t)row,
+                          v, msk);
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        float a[LN_MAXV][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c0 = (lane + 64 * i) * 8;
+            if (c0 < p.C) {
+                const size_t oo = (size_t)row * p.C + c0;
+                float g[8], t[8], ga[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g[j] = 0.f;
+                if (p.dy) {
+                    load8bf(p.dy + oo, t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += t[j];
+                }
+                if (p.dypos) {
+                    load8bf(p.dypos + oo, t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) g[j] += t[j];
+                }
+                if (p.dout_f32) {
+                    load8f(p.dout_f32 + oo, t);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        float d = t[j];
+                        if (p.out_thresh) d = cris_keep(out_key, (uint32_t)row * (uint32_t)p.C + (uint32_t)(c0 + j), p.out_thresh) ? d * out_scale : 0.f;
+                        g[j] += d;
+                    }
+                }
+                load8f(p.gamma + c0, ga);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (v[i][j] - mean) * rstd;
+                    v[i][j] = xh;
+                    dga[i][j] += g[j] * xh;
+                    dbe[i][j] += g[j];
+                    a[i][j] = g[j] * ga[j];
+                    s1 += a[i][j];
+                    s2 += a[i][j] * xh;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[i][j] = 0.f;
+            }
+        }
+        const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int i = 0; i < LN_MAXV; ++i) {
+            const int c0 = (lane + 64 * i) * 8;
+            if (c0 >= p.C) continue;
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = rstd * (a[i][j] - m1 - v[i][j] * m2) * msk[i][j];
+            const size_t xo = (size_t)row * p.ldx + c0;
+            if (p.dx_f32) {
+                float* d = reinterpret_cast<float*>(p.dx) + xo;
+                if (p.dx_accum) {
+                    float old[8];
+                    load8f(d, old);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] += old[j];
+                }
+                *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
+                *reinterpret_cast<float4*>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            } else {
+                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.dx) + xo) = pack8(o);
+            }
+        }
+    }
+    // parameter gradients: registers -> LDS (4 waves) -> global atomics
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c0 = (lane + 64 * i) * 8;
+        if (c0 < p.C) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                atomicAdd(&sg[0][c0 + j], dga[i][j]);
+                atomicAdd(&sg[1][c0 + j], dbe[i][j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < p.C; c += 256) {
+        if (p.dgamma) atomicAdd(p.dgamma + c, sg[0][c]);
+        if (p.dbeta) atomicAdd(p.dbeta + c, sg[1][c]);
+    }
+}
+
+extern "C" int cris_ln_bwd(const cris_ln_bwd_params* pp, void* stream) {
+    const cris_ln_bwd_params& p = *pp;
+    CRIS_CHECK_ARG(p.x && p.gamma && p.mean && p.rstd && p.dx && p.rows > 0, "null operand");
+    CRIS_CHECK_ARG(p.dy || p.dypos || p.dout_f32, "no incoming gradient");
+    CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 64 * 8 * LN_MAXV && (p.ldx & 7) == 0, "C must be a multiple of 8, <= 2048");
+    CRIS_CHECK_ARG(!p.dx_accum || p.dx_f32, "accumulate only into fp32");
+    const int grid = cris_grid_1d(p.rows, 4, 256);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}

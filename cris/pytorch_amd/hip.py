@@ -1,0 +1,240 @@
+"""ctypes binding of libcris_hip.so (include/cris_hip.h).
+
+`import torch` happens first so the library binds to torch's bundled libamdhip64 (one HIP runtime in
+the process).  The product path FAILS LOUDLY when the library is missing or was
+not built - there is no CPU / eager fallback anywhere in cris.pytorch_amd.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcris_hip.so")
+
+P, I, L, F, U = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
+
+
+class ConvGemmParams(C.Structure):
+    _fields_ = [("A", P), ("Wt", P), ("bias", P), ("resid", P), ("out", P), ("outT", P), ("colsum", P), ("colsq", P),
+                ("T_sec_stride", L),
+                ("lda", I), ("a_coff", I),
+                ("Bn", I), ("H", I), ("W", I), ("C", I),
+                ("OH", I), ("OW", I), ("KH", I), ("KW", I), ("stride", I), ("pad", I),
+                ("ldb", I),
+                ("M", I), ("N", I), ("K", I),
+                ("act", I),
+                ("ldr", I), ("r_coff", I), ("resid_f32", I),
+                ("ldc", I), ("c_coff", I), ("out_f32", I),
+                ("T_L", I), ("T_Lpad", I), ("T_E", I),
+                ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U)]
+
+
+class WgradParams(C.Structure):
+    _fields_ = [("dY", P), ("X", P), ("dW", P),
+                ("ldy", I), ("y_coff", I), ("N_ld", I),
+                ("ldx", I), ("x_coff", I),
+                ("Bn", I), ("H", I), ("W", I), ("C", I),
+                ("OH", I), ("OW", I), ("KH", I), ("KW", I), ("stride", I), ("pad", I),
+                ("M", I), ("N", I), ("K", I),
+                ("C_real", I), ("splits", I)]
+
+
+class PackDesc(C.Structure):
+    _fields_ = [("src", P), ("dstF", P), ("dstD", P),
+                ("N", I), ("Cin", I), ("taps", I), ("Cpad", I), ("Npad", I), ("src_transposed", I),
+                ("block_start", I), ("pad_", I)]
+
+
+class BnApplyParams(C.Structure):
+    _fields_ = [("y", P), ("ldy", I), ("y_coff", I),
+                ("scale", P), ("shift", P),
+                ("y2", P), ("ldy2", I), ("y2_coff", I),
+                ("scale2", P), ("shift2", P),
+                ("ident", P), ("ldi", I), ("i_coff", I),
+                ("mul", P),
+                ("osum", P), ("osq", P),
+                ("z", P), ("ldz", I), ("z_coff", I),
+                ("Bn", I), ("H", I), ("W", I), ("C", I),
+                ("relu", I), ("pool", I)]
+
+
+class BnBwdParams(C.Structure):
+    _fields_ = [("dz", P), ("lddz", I), ("dz_coff", I),
+                ("z", P), ("ldz", I), ("z_coff", I),
+                ("y", P), ("ldy", I), ("y_coff", I),
+                ("scale", P), ("shift", P), ("mean", P), ("invstd", P),
+                ("y2", P), ("ldy2", I), ("y2_coff", I),
+                ("mean2", P), ("invstd2", P), ("scale2", P),
+                ("mul", P),
+                ("sums", P),
+                ("dmul", P),
+                ("dy", P), ("lddy", I), ("dy_coff", I),
+                ("dy2", P), ("lddy2", I), ("dy2_coff", I),
+                ("dident", P), ("lddi", I), ("di_coff", I),
+                ("dident_accum", I),
+                ("Bn", I), ("H", I), ("W", I), ("C", I),
+                ("relu", I), ("pool", I),
+                ("count", F)]
+
+
+class LnFwdParams(C.Structure):
+    _fields_ = [("x", P), ("x_f32", I), ("ldx", I),
+                ("gamma", P), ("beta", P),
+                ("pos", P), ("pos_rows", I),
+                ("resid", P),
+                ("y", P), ("ypos", P), ("out_f32", P),
+                ("mean", P), ("rstd", P),
+                ("rows", I), ("C", I),
+                ("in_relu", I),
+                ("in_drop_p", F), ("in_thresh", U), ("in_seed", U), ("in_stream", U),
+                ("out_drop_p", F), ("out_thresh", U), ("out_seed", U), ("out_stream", U),
+                ("eps", F)]
+
+
+class LnBwdParams(C.Structure):
+    _fields_ = [("x", P), ("x_f32", I), ("ldx", I),
+                ("gamma", P),
+                ("mean", P), ("rstd", P),
+                ("dy", P), ("dypos", P), ("dout_f32", P),
+                ("dgamma", P), ("dbeta", P),
+                ("dx", P), ("dx_f32", I), ("dx_accum", I),
+                ("rows", I), ("C", I),
+                ("in_relu", I),
+                ("in_drop_p", F), ("in_thresh", U), ("in_seed", U), ("in_stream", U),
+                ("out_drop_p", F), ("out_thresh", U), ("out_seed", U), ("out_stream", U)]
+
+
+class AttnParams(C.Structure):
+    _fields_ = [("Q", P), ("ldq", I),
+                ("K", P), ("ldk", I),
+                ("V", P), ("ldv", I),
+                ("Vt", P), ("Kt", P), ("Qt", P), ("Lk_pad", I), ("Lq_pad", I),
+                ("key_tokens", P),
+                ("O", P), ("ldo", I),
+                ("lse", P),
+                ("dO", P), ("lddo", I), ("dOt", P),
+                ("delta", P),
+                ("dQ", P), ("lddq", I),
+                ("dK", P), ("lddk", I),
+                ("dV", P), ("lddv", I),
+                ("B", I), ("Hn", I), ("Lq", I), ("Lk", I),
+                ("causal", I),
+                ("scale", F),
+                ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U)]
+
+
+class AdamDesc(C.Structure):
+    _fields_ = [("p", P), ("g", P), ("m", P), ("v", P),
+                ("n", L),
+                ("lr", F), ("pad_", F),
+                ("block_start", I), ("pad2_", I)]
+
+
+STRUCTS = {
+    "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_pack_desc": PackDesc,
+    "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
+    "cris_ln_bwd_params": LnBwdParams, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc,
+}
+
+# name -> (restype, argtypes); struct launchers take (struct*, stream)
+_SIGS = {
+    "cris_last_error": (C.c_char_p, []),
+    "cris_abi_version": (I, []),
+    "cris_sizeof": (I, [C.c_char_p]),
+    "cris_echo_conv_gemm": (L, [P]),
+    "cris_conv_gemm": (I, [P, P]),
+    "cris_conv_wgrad": (I, [P, P]),
+    "cris_pack_weights": (I, [P, I, I, P]),
+    "cris_pack_blocks": (I, [P]),
+    "cris_pack_block_elems": (I, []),
+    "cris_colsum_bf16": (I, [P, I, I, I, I, P, P]),
+    "cris_bn_finalize": (I, [P, P, F, P, P, P, P, F, F, I, P, P, P, P, P]),
+    "cris_bn_eval_coeffs": (I, [P, P, P, P, F, I, P, P, P]),
+    "cris_bn_apply": (I, [P, P]),
+    "cris_bn_bwd_reduce": (I, [P, P]),
+    "cris_bn_bwd_apply": (I, [P, P]),
+    "cris_ln_fwd": (I, [P, P]),
+    "cris_ln_bwd": (I, [P, P]),
+    "cris_attn_fwd": (I, [P, P]),
+    "cris_attn_bwd_dq": (I, [P, P]),
+    "cris_attn_bwd_dkv": (I, [P, P]),
+    "cris_stem_im2col": (I, [P, I, I, I, P, P]),
+    "cris_avgpool2_fwd": (I, [P, I, I, I, I, I, I, P, I, I, P]),
+    "cris_avgpool2_bwd": (I, [P, I, I, I, I, I, I, P, I, I, I, P]),
+    "cris_upsample2_fwd": (I, [P, I, I, I, I, I, I, P, I, I, P]),
+    "cris_upsample2_bwd": (I, [P, I, I, I, I, I, I, P, I, I, I, P]),
+    "cris_fill_coords": (I, [P, I, I, I, I, I, I, P]),
+    "cris_add_bf16": (I, [P, I, I, P, I, I, P, I, I, I, I, P]),
+    "cris_add_rowtable": (I, [P, I, P, I, P, I, I, I, P]),
+    "cris_cast_f32_bf16": (I, [P, P, L, P]),
+    "cris_cast_bf16_f32": (I, [P, P, L, I, P]),
+    "cris_embed_fwd": (I, [P, P, P, I, I, I, P, P]),
+    "cris_embed_bwd": (I, [P, P, I, I, I, P, P, P]),
+    "cris_eot_gather": (I, [P, P, I, I, I, P, P, P]),
+    "cris_eot_scatter_add": (I, [P, P, I, I, I, P, P]),
+    "cris_posresize_fwd": (I, [P, P, I, I, I, P, P]),
+    "cris_posresize_bwd": (I, [P, P, I, I, I, P, P]),
+    "cris_batch_rowsum": (I, [P, I, I, I, I, P, P]),
+    "cris_dynconv_fwd": (I, [P, I, I, I, I, P, I, P, P]),
+    "cris_dynconv_bwd": (I, [P, P, I, I, I, I, P, I, P, P, P]),
+    "cris_mask_resize_nearest": (I, [P, I, I, I, I, I, P, P]),
+    "cris_bce_fwd": (I, [P, P, L, P, P]),
+    "cris_bce_bwd": (I, [P, P, L, P, P, P]),
+    "cris_train_metric": (I, [P, P, I, I, F, F, P, P]),
+    "cris_memset_f32": (I, [P, F, L, P]),
+    "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P]),
+    "cris_adam_block_elems": (I, []),
+}
+EXPORTS = sorted(_SIGS)
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libcris_hip.so (building is __graft_entry__.build()'s job).  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            "libcris_hip.so not found at %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU fallback for the CRIS HIP path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    for cname, st in STRUCTS.items():
+        n = lib.cris_sizeof(cname.encode())
+        if n != C.sizeof(st):
+            raise HipLibraryError("ABI mismatch: sizeof(%s) C=%d ctypes=%d" % (cname, n, C.sizeof(st)))
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().cris_last_error()
+        raise HipLibraryError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+def call(name, *args):
+    """Invoke an exported launcher and raise on a non-zero return code."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        check(rc, name)
+
+
+def ptr(t):
+    """Device (or host) address of a tensor, None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def dropout_threshold(p: float) -> int:
+    """keep iff hash >= threshold (same rule as oracle/dropout_hash.py threshold())."""
+    return min(int(p * 4294967296.0), 0xFFFFFFFF) if p > 0 else 0

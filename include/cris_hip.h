@@ -1,0 +1,289 @@
+/* libcris_hip.so - C ABI of the MI355X-native CRIS training path (gfx950 only).
+ *
+ * The reference (DerrickWang005/CRIS.pytorch) has NO native / FFI interface: every kernel it runs is a
+ * stock torch/cuDNN/cuBLAS kernel reached through torch.nn.  Each entry point below
+ * therefore replaces the torch operator(s) named in its comment, cited as reference file:line of the
+ * call site.  Conventions:
+ *   - plain pointers + sizes, no torch types; every buffer is owned by the caller (device memory from
+ *     torch's caching allocator) and no reference is kept past the call; the library never allocates or
+ *     frees device memory;
+ *   - every launcher takes the hipStream_t to launch on (as void*), is re-entrant, keeps no global mutable
+ *     state (forward runs on the Python thread, backward on autograd's worker thread);
+ *   - return 0 on success, non-zero on error; the message is available from cris_last_error()
+ *     (thread local).  No exceptions cross the ABI.
+ *   - activations are NHWC / token-major bf16 (raw uint16), parameters and statistics fp32.
+ */
+#ifndef CRIS_HIP_H
+#define CRIS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef uint16_t cris_bf16;
+
+const char* cris_last_error(void);
+int cris_abi_version(void);
+/* sizeof() of the parameter structs, so the Python mirror (ctypes) can be checked without a GPU */
+int cris_sizeof(const char* struct_name);
+/* Host-only self check of struct layout: returns a checksum of fields read through the C struct. */
+long cris_echo_conv_gemm(const void* conv_gemm_params);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+ *   out[m, n] = epilogue( sum_k A_im2col[m, k] * Wt[n, k] )
+ *   m = (b, oh, ow) over an NHWC input [Bn, H, W, lda] (channels a_coff .. a_coff+C),  k = tap*C + c.
+ * Replaces: nn.Conv2d forward everywhere (reference model/clip.py:17-42,77,165-182; model/layers.py:10,58),
+ * nn.Linear / MHA in-proj / out-proj (model/clip.py:246-251; model/layers.py:15,61,202-212), `@ text_projection`
+ * (model/clip.py:451-452); with flipped/transposed weight packs also their input-gradient (dgrad).
+ * Linear layers use Bn=M, H=W=OH=OW=KH=KW=1.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const cris_bf16* A;      /* NHWC input */
+    const cris_bf16* Wt;     /* [N][ldb], k contiguous */
+    const float* bias;       /* [N] or NULL */
+    const void* resid;       /* [M][ldr] (+r_coff) added after activation/dropout, bf16 or fp32; or NULL */
+    void* out;               /* [M][ldc] (+c_coff) bf16 or fp32; or NULL */
+    cris_bf16* outT;         /* optional head-split transposed copy, see T_* ; or NULL */
+    float* colsum;           /* optional per-column sum / sum of squares accumulators (BatchNorm statistics) */
+    float* colsq;
+    long T_sec_stride;       /* elements between consecutive T_E-wide column sections in outT */
+    int lda, a_coff;
+    int Bn, H, W, C;
+    int OH, OW, KH, KW, stride, pad;
+    int ldb;
+    int M, N, K;
+    int act;                 /* 0 none, 1 relu, 2 QuickGELU x*sigmoid(1.702x) (model/clip.py:234-236) */
+    int ldr, r_coff, resid_f32;
+    int ldc, c_coff, out_f32;
+    int T_L, T_Lpad, T_E;    /* outT[sec][(b*(T_E/64)+h)*64+d][l], m = b*T_L + l, n = sec*T_E + h*64 + d */
+    float drop_p;            /* dropout on (acc+bias, act) before the residual add; survivors scaled 1/(1-p) */
+    uint32_t drop_thresh;    /* keep iff hash >= drop_thresh; host computes min(int(p*2^32), 2^32-1); 0 = off */
+    uint32_t drop_seed, drop_stream;
+} cris_conv_gemm_params;
+int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
+
+/* Weight gradient: dW[n, c, tap] += sum_m dY[m, n] * X_im2col[m, tap*C + c]   (fp32 atomics, split over m).
+ * Replaces convolution_backward(weight) / addmm backward for every Conv2d / Linear above. */
+typedef struct {
+    const cris_bf16* dY;     /* [M][ldy] (+y_coff) */
+    const cris_bf16* X;      /* NHWC input of the forward conv */
+    float* dW;               /* parameter-layout fp32: dW[(n*C_real + c)*taps + tap] */
+    int ldy, y_coff, N_ld;   /* N_ld: columns of dY that may be read (multiple of 8, >= N) */
+    int ldx, x_coff;
+    int Bn, H, W, C;
+    int OH, OW, KH, KW, stride, pad;
+    int M, N, K;
+    int C_real;              /* channels that exist in the parameter (C may be zero padded above it) */
+    int splits;              /* grid.z; each split covers ceil(M/splits) rows rounded up to 128 */
+} cris_wgrad_params;
+int cris_conv_wgrad(const cris_wgrad_params* p, void* stream);
+
+/* Batched weight packing (fp32 parameter layout -> bf16 GEMM layouts), one launch for a table of tensors.
+ *   F layout: Wf[n][tap][Cpad]        (forward, k = tap*Cpad + c, zero padded)
+ *   D layout: Wd[c][taps-1-tap][Npad] (dgrad: conv of dY with flipped taps; for linear = transpose) */
+typedef struct {
+    const float* src;        /* [N][Cin][taps]  (or [Cin][N] when src_transposed, taps == 1) */
+    cris_bf16* dstF;         /* or NULL */
+    cris_bf16* dstD;         /* or NULL */
+    int N, Cin, taps, Cpad, Npad, src_transposed;
+    int block_start;         /* first block of this tensor in the launch grid (prefix sum) */
+    int pad_;
+} cris_pack_desc;
+int cris_pack_weights(const cris_pack_desc* dev_table, int n_desc, int total_blocks, void* stream);
+/* number of blocks a (host-side) descriptor needs: used to build block_start prefix sums on the host */
+int cris_pack_blocks(const cris_pack_desc* host_desc);
+int cris_pack_block_elems(void);
+
+/* column sums of a bf16 matrix into fp32 (bias gradients): out[n] += sum_m x[m][n] */
+int cris_colsum_bf16(const cris_bf16* x, int ldx, int coff, int M, int N, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm (training statistics), replaces native_batch_norm / its backward
+ * (reference: every nn.BatchNorm2d/1d, model/clip.py:18-41,78,173-183; model/layers.py:11,16,262).
+ * Statistics (sum, sum of squares) are produced by the conv GEMM epilogue (colsum/colsq).
+ * ---------------------------------------------------------------------------------------------- */
+int cris_bn_finalize(const float* sum, const float* sumsq, float count, const float* gamma, const float* beta,
+                     float* running_mean, float* running_var, float momentum, float eps, int C,
+                     float* scale, float* shift, float* mean, float* invstd, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int cris_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                        float eps, int C, float* scale, float* shift, void* stream);
+
+typedef struct {
+    const cris_bf16* y;  int ldy, y_coff;           /* conv output */
+    const float* scale;  const float* shift;         /* [C] */
+    const cris_bf16* y2; int ldy2, y2_coff;          /* optional second BN branch (downsample) or NULL */
+    const float* scale2; const float* shift2;
+    const cris_bf16* ident; int ldi, i_coff;         /* optional identity added before the ReLU, or NULL */
+    const float* mul;                                /* optional [Bn][C] multiplier applied after the ReLU */
+    float* osum; float* osq;                         /* optional statistics of the output (for a following BN) */
+    cris_bf16* z;        int ldz, z_coff;            /* output */
+    int Bn, H, W, C;                                 /* input geometry, M = Bn*H*W rows */
+    int relu;
+    int pool;                                        /* 1: 2x2/s2 average pool after the ReLU (H,W even) */
+} cris_bn_apply_params;
+int cris_bn_apply(const cris_bn_apply_params* p, void* stream);
+
+typedef struct {
+    const cris_bf16* dz; int lddz, dz_coff;          /* grad wrt output z (pooled resolution when pool) */
+    const cris_bf16* z;  int ldz, z_coff;            /* forward output: ReLU mask when ident/y2 are used (else recomputed) */
+    const cris_bf16* y;  int ldy, y_coff;
+    const float* scale; const float* shift; const float* mean; const float* invstd;
+    const cris_bf16* y2; int ldy2, y2_coff;          /* second branch or NULL */
+    const float* mean2; const float* invstd2; const float* scale2;
+    const float* mul;                                /* [Bn][C] or NULL (forward multiplier) */
+    float* sums;                                     /* [4*C]: sum g, sum g*xhat, (branch 2) sum g, sum g*xhat2 */
+    float* dmul;                                     /* [Bn][C] grad of mul or NULL */
+    cris_bf16* dy;  int lddy, dy_coff;               /* grad wrt y */
+    cris_bf16* dy2; int lddy2, dy2_coff;             /* grad wrt y2 or NULL */
+    cris_bf16* dident; int lddi, di_coff;            /* grad wrt identity (= masked dz) or NULL */
+    int dident_accum;                                /* 1: dident += */
+    int Bn, H, W, C;
+    int relu, pool;
+    float count;                                     /* rows entering the statistics (global count under SyncBN) */
+} cris_bn_bwd_params;
+int cris_bn_bwd_reduce(const cris_bn_bwd_params* p, void* stream);
+int cris_bn_bwd_apply(const cris_bn_bwd_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * LayerNorm (replaces native_layer_norm fwd/bwd; reference model/clip.py:226-231,247,252,381;
+ * model/layers.py:103,199-200,211,214-216) with the surrounding elementwise work fused.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const void* x; int x_f32; int ldx;               /* input rows */
+    const float* gamma; const float* beta;
+    const float* pos; int pos_rows;                  /* optional [pos_rows][C] table, row index = row % pos_rows */
+    const float* resid;                              /* optional fp32 [rows][C]: out_f32 = resid + dropout(LN(x)) */
+    cris_bf16* y;                                    /* optional bf16 LN(x) */
+    cris_bf16* ypos;                                 /* optional bf16 LN(x) + pos */
+    float* out_f32;                                  /* optional fp32 (see resid) */
+    float* mean; float* rstd;                        /* [rows] saved for backward */
+    int rows, C;
+    int in_relu;                                     /* apply ReLU to x first (bf16 input holds pre-activation) */
+    float in_drop_p; uint32_t in_thresh, in_seed, in_stream;     /* dropout on the input (FFN: LN(dropout(relu(h)))) */
+    float out_drop_p; uint32_t out_thresh, out_seed, out_stream; /* dropout on LN(x) before the residual add */
+    float eps;
+} cris_ln_fwd_params;
+int cris_ln_fwd(const cris_ln_fwd_params* p, void* stream);
+
+typedef struct {
+    const void* x; int x_f32; int ldx;
+    const float* gamma;
+    const float* mean; const float* rstd;
+    const cris_bf16* dy;                             /* optional grad wrt y */
+    const cris_bf16* dypos;                          /* optional grad wrt ypos (added to dy) */
+    const float* dout_f32;                           /* optional grad wrt out_f32 (passes the output dropout) */
+    float* dgamma; float* dbeta;                     /* accumulated (+=, atomics) */
+    void* dx; int dx_f32; int dx_accum;              /* grad wrt x: bf16 or fp32; accum: += (fp32 only) */
+    int rows, C;
+    int in_relu;
+    float in_drop_p; uint32_t in_thresh, in_seed, in_stream;
+    float out_drop_p; uint32_t out_thresh, out_seed, out_stream;
+} cris_ln_bwd_params;
+int cris_ln_bwd(const cris_ln_bwd_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Fused multi-head attention, head dim 64 (replaces bmm/baddbmm/_softmax/bernoulli_/bmm of the
+ * need_weights=True torch path, reference model/layers.py:235,240-243, and the SDPA calls of
+ * model/clip.py:119-139,259-260).  q is scaled by `scale` before QK^T; optional causal mask,
+ * key-padding mask (int64 token ids == 0 are padding: model/segmenter.py:37) and dropout on the
+ * probabilities.  Operands are read straight from L2 in MFMA fragment order: Q/K/V token-major
+ * [B*L][ld] (head h at column h*64) plus head-split transposed copies Kt/Vt/Qt/dOt
+ * [(b*H+h)*64+d][Lpad] written by the producing GEMM's epilogue (zero padded beyond L).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    const cris_bf16* Q;  int ldq;                    /* [B*Lq][ldq] */
+    const cris_bf16* K;  int ldk;                    /* [B*Lk][ldk] */
+    const cris_bf16* V;  int ldv;
+    const cris_bf16* Vt; const cris_bf16* Kt; const cris_bf16* Qt; int Lk_pad, Lq_pad;
+    const int64_t* key_tokens;                       /* [B][Lk] or NULL; token == 0 -> key masked */
+    cris_bf16* O;  int ldo;                          /* [B*Lq][ldo] */
+    float* lse;                                      /* [B*H][Lq] log-sum-exp of scaled scores */
+    /* backward */
+    const cris_bf16* dO; int lddo; const cris_bf16* dOt;   /* dOt [(b*H+h)*64+d][Lq_pad] */
+    float* delta;                                    /* [B*H][Lq] rowsum(dO*O), written by bwd_dq */
+    cris_bf16* dQ; int lddq;
+    cris_bf16* dK; int lddk;
+    cris_bf16* dV; int lddv;
+    int B, Hn, Lq, Lk;
+    int causal;
+    float scale;
+    float drop_p; uint32_t drop_thresh, drop_seed, drop_stream;
+} cris_attn_params;
+int cris_attn_fwd(const cris_attn_params* p, void* stream);
+int cris_attn_bwd_dq(const cris_attn_params* p, void* stream);
+int cris_attn_bwd_dkv(const cris_attn_params* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Elementwise / data movement kernels
+ * ---------------------------------------------------------------------------------------------- */
+/* stem: fp32 NCHW image -> bf16 im2col rows [B*OH*OW][32] for the 3x3/s2/p1 conv (k = ci*9 + kh*3 + kw, 27..31 zero)
+ * (reference model/clip.py:165-170,215: x.type(dtype) + conv1) */
+int cris_stem_im2col(const float* img, int Bn, int H, int W, cris_bf16* out, void* stream);
+/* 2x2/s2 average pool, NHWC bf16 (avg_pool2d: model/clip.py:23,35,184; model/layers.py:297) */
+int cris_avgpool2_fwd(const cris_bf16* x, int ldx, int xcoff, int Bn, int H, int W, int C, cris_bf16* y, int ldy,
+                      int ycoff, void* stream);
+int cris_avgpool2_bwd(const cris_bf16* dy, int lddy, int dycoff, int Bn, int H, int W, int C, cris_bf16* dx, int lddx,
+                      int dxcoff, int accum, void* stream);
+/* x2 bilinear upsample, align_corners=False (F.interpolate / nn.Upsample: model/layers.py:54,56,293,304) */
+int cris_upsample2_fwd(const cris_bf16* x, int ldx, int xcoff, int Bn, int H, int W, int C, cris_bf16* y, int ldy,
+                       int ycoff, void* stream);
+int cris_upsample2_bwd(const cris_bf16* dy, int lddy, int dycoff, int Bn, int H, int W, int C, cris_bf16* dx,
+                       int lddx, int dxcoff, int accum, void* stream);
+/* CoordConv coordinate channels (model/layers.py:30-39): x at column coff, y at coff+1, zeros up to coff+nfill */
+int cris_fill_coords(cris_bf16* x, int ldx, int coff, int nfill, int Bn, int H, int W, void* stream);
+/* generic strided bf16 ops: y (=|+=) a [+ b] ;  and y = a + f32 table[row % trows] */
+int cris_add_bf16(const cris_bf16* a, int lda, int acoff, const cris_bf16* b, int ldb, int bcoff, cris_bf16* y,
+                  int ldy, int ycoff, int M, int C, void* stream);
+int cris_add_rowtable(const cris_bf16* a, int lda, const float* table, int trows, cris_bf16* y, int ldy, int M,
+                      int C, void* stream);
+int cris_cast_f32_bf16(const float* x, cris_bf16* y, long n, void* stream);
+int cris_cast_bf16_f32(const cris_bf16* x, float* y, long n, int accum, void* stream);
+/* token embedding + positional embedding (model/clip.py:440-443) and its backward (embedding_dense_backward) */
+int cris_embed_fwd(const int64_t* tokens, const float* table, const float* pos, int Bn, int L, int D, float* out,
+                   void* stream);
+int cris_embed_bwd(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos,
+                   void* stream);
+/* rows x[b*L + argmax_l tokens[b,:]] -> bf16 (EOT feature select, model/clip.py:451-452; first max wins) */
+int cris_eot_gather(const int64_t* tokens, const cris_bf16* x, int Bn, int L, int D, cris_bf16* out, int* eot_index,
+                    void* stream);
+int cris_eot_scatter_add(const int* eot_index, const cris_bf16* dstate_rows, int Bn, int L, int D, cris_bf16* dx,
+                         void* stream);
+/* posr[t][c] = sum_j R[t][j] * pos[1+j][c] (bicubic resize of the attnpool positional embedding as a
+ * constant linear map, model/clip.py:80-108) and its transpose for the gradient */
+int cris_posresize_fwd(const float* R, const float* pos, int T, int G, int C, float* posr, void* stream);
+int cris_posresize_bwd(const float* R, const float* dposr, int T, int G, int C, float* dpos, void* stream);
+/* dposr[t][c] = sum_b dx[b*T+t][c] */
+int cris_batch_rowsum(const cris_bf16* dx, int ldx, int Bn, int T, int C, float* out, void* stream);
+/* text-to-pixel dynamic conv (grouped conv2d, groups = B: model/layers.py:71-84), fp32 logits out */
+int cris_dynconv_fwd(const cris_bf16* x, int Bn, int H, int W, int C, const float* wb, int ldwb, float* pred,
+                     void* stream);
+int cris_dynconv_bwd(const cris_bf16* x, const float* dpred, int Bn, int H, int W, int C, const float* wb, int ldwb,
+                     cris_bf16* dx, float* dwb, void* stream);
+/* nearest mask resize + BCE-with-logits mean (model/segmenter.py:56-59) and gradient.
+ * loss_accum[0] += sum(loss_i)/n ; grad = (sigmoid(x) - t)/n * (*gscale or 1) */
+int cris_mask_resize_nearest(const float* mask, int Bn, int IH, int IW, int OH, int OW, float* out, void* stream);
+int cris_bce_fwd(const float* logits, const float* target, long n, float* loss_accum, void* stream);
+int cris_bce_bwd(const float* logits, const float* target, long n, const float* gscale, float* dlogits, void* stream);
+/* trainMetricGPU (utils/misc.py:114-129): out[0] += 100*mean IoU, out[1] += 100*mean(IoU > pr_iou) */
+int cris_train_metric(const float* logits, const float* target, int Bn, int HW, float thr, float pr_iou, float* out,
+                      void* stream);
+/* elementwise multiply by per-(batch,channel) scalar handled inside cris_bn_apply (mul) */
+int cris_memset_f32(float* p, float v, long n, void* stream);
+
+/* fused multi-tensor Adam (torch.optim.Adam semantics, train.py:105-107): table of {p,g,m,v,n} */
+typedef struct {
+    float* p; const float* g; float* m; float* v;
+    long n;
+    float lr; float pad_;
+    int block_start; int pad2_;
+} cris_adam_desc;
+int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
+                   float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+int cris_adam_block_elems(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
