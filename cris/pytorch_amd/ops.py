@@ -1,0 +1,455 @@
+"""Thin functional wrappers: torch tensors (device memory only) -> C-ABI launchers of libcris_hip.so.
+
+No arithmetic happens in Python/torch here; torch supplies buffers (`torch.empty/zeros`) and the
+current HIP stream.  Every function launches on `torch.cuda.current_stream()`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import hip
+from .hip import ptr
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+@dataclass(frozen=True)
+class Geom:
+    """im2col geometry of an NHWC input [Bn, H, W, C] -> rows (b, oh, ow), k = tap*C + c."""
+    Bn: int
+    H: int
+    W: int
+    C: int
+    KH: int = 1
+    KW: int = 1
+    stride: int = 1
+    pad: int = 0
+
+    @property
+    def OH(self):
+        return (self.H + 2 * self.pad - self.KH) // self.stride + 1
+
+    @property
+    def OW(self):
+        return (self.W + 2 * self.pad - self.KW) // self.stride + 1
+
+    @property
+    def M(self):
+        return self.Bn * self.OH * self.OW
+
+    @property
+    def K(self):
+        return self.KH * self.KW * self.C
+
+    @staticmethod
+    def linear(M: int, C: int) -> "Geom":
+        return Geom(M, 1, 1, C)
+
+
+@dataclass(frozen=True)
+class Drop:
+    p: float
+    seed: int
+    stream: int
+
+    @property
+    def thresh(self):
+        return hip.dropout_threshold(self.p)
+
+
+NO_DROP = Drop(0.0, 0, 0)
+
+
+def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None, act=0, resid=None, ldr=None, r_coff=0,
+              out=None, ldc=None, c_coff=0, outT=None, T_L=0, T_Lpad=0, T_E=0, T_sec_stride=0, colsum=None, colsq=None,
+              drop: Drop = NO_DROP):
+    """out[M,N] = epi(A_im2col @ Wt^T).  A bf16 NHWC buffer (row stride lda), Wt bf16 [N][ldb]."""
+    p = hip.ConvGemmParams()
+    p.A, p.Wt, p.bias = ptr(A), ptr(Wt), ptr(bias)
+    p.lda = lda if lda is not None else A.shape[-1]
+    p.a_coff = a_coff
+    p.Bn, p.H, p.W, p.C = g.Bn, g.H, g.W, g.C
+    p.OH, p.OW, p.KH, p.KW, p.stride, p.pad = g.OH, g.OW, g.KH, g.KW, g.stride, g.pad
+    p.ldb = ldb if ldb is not None else Wt.shape[-1]
+    p.M, p.N, p.K = g.M, N, g.K
+    p.act = act
+    if resid is not None:
+        p.resid = ptr(resid)
+        p.ldr = ldr if ldr is not None else resid.shape[-1]
+        p.r_coff = r_coff
+        p.resid_f32 = 1 if resid.dtype == torch.float32 else 0
+    if out is not None:
+        p.out = ptr(out)
+        p.ldc = ldc if ldc is not None else out.shape[-1]
+        p.c_coff = c_coff
+        p.out_f32 = 1 if out.dtype == torch.float32 else 0
+    if outT is not None:
+        p.outT = ptr(outT)
+        p.T_L, p.T_Lpad, p.T_E, p.T_sec_stride = T_L, T_Lpad, T_E, T_sec_stride
+    if colsum is not None:
+        p.colsum, p.colsq = ptr(colsum), ptr(colsq)
+    p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
+    hip.call("cris_conv_gemm", C.byref(p), _stream())
+
+
+def wgrad_splits(M: int, N: int, K: int) -> int:
+    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+    steps = (M + 127) // 128
+    want = max(1, (1024 + tiles - 1) // tiles)
+    return max(1, min(want, (steps + 3) // 4, 512))
+
+
+def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, C_real=None, splits=None):
+    p = hip.WgradParams()
+    p.dY, p.X, p.dW = ptr(dY), ptr(X), ptr(dW)
+    p.ldy = ldy if ldy is not None else dY.shape[-1]
+    p.y_coff = y_coff
+    p.N_ld = N_ld if N_ld is not None else pad8(N)
+    p.ldx = ldx if ldx is not None else X.shape[-1]
+    p.x_coff = x_coff
+    p.Bn, p.H, p.W, p.C = g.Bn, g.H, g.W, g.C
+    p.OH, p.OW, p.KH, p.KW, p.stride, p.pad = g.OH, g.OW, g.KH, g.KW, g.stride, g.pad
+    p.M, p.N, p.K = g.M, N, g.K
+    p.C_real = C_real if C_real is not None else g.C
+    p.splits = splits if splits is not None else wgrad_splits(g.M, N, g.K)
+    hip.call("cris_conv_wgrad", C.byref(p), _stream())
+
+
+class PackTable:
+    """Device-resident table of cris_pack_desc: one launch repacks every fp32 weight into its bf16
+    forward (F) / dgrad (D) layouts."""
+
+    def __init__(self):
+        self.descs = []
+        self.keep = []       # tensors referenced by the table
+        self.dev = None
+        self.total_blocks = 0
+
+    def add(self, src, N, Cin, taps, Cpad=None, Npad=None, want_F=True, want_D=True, src_transposed=False):
+        Cpad = Cpad if Cpad is not None else pad8(Cin)
+        Npad = Npad if Npad is not None else pad8(N)
+        dstF = torch.zeros(N, taps * Cpad, dtype=BF16, device=src.device) if want_F else None
+        dstD = torch.zeros(Cin, taps * Npad, dtype=BF16, device=src.device) if want_D else None
+        d = hip.PackDesc()
+        d.src, d.dstF, d.dstD = ptr(src), ptr(dstF), ptr(dstD)
+        d.N, d.Cin, d.taps, d.Cpad, d.Npad, d.src_transposed = N, Cin, taps, Cpad, Npad, int(src_transposed)
+        self.descs.append(d)
+        self.keep.append((src, dstF, dstD))
+        self.dev = None
+        return dstF, dstD
+
+    def finalize(self, device):
+        lib = hip.load()
+        n = len(self.descs)
+        arr = (hip.PackDesc * n)()
+        start = 0
+        for i, d in enumerate(self.descs):
+            d.block_start = start
+            start += lib.cris_pack_blocks(C.byref(d))
+            arr[i] = d
+        self.total_blocks = start
+        raw = bytes(arr)
+        host = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+        self.dev = host.to(device)
+
+    def run(self):
+        if not self.descs:
+            return
+        if self.dev is None:
+            self.finalize(self.keep[0][0].device)
+        hip.call("cris_pack_weights", ptr(self.dev), len(self.descs), self.total_blocks, _stream())
+
+    def refresh_sources(self, new_srcs):
+        """Re-point descriptors at new parameter storage (e.g. after model.cuda())."""
+        for d, s, k in zip(self.descs, new_srcs, range(len(self.keep))):
+            d.src = ptr(s)
+            self.keep[k] = (s,) + self.keep[k][1:]
+        self.dev = None
+
+
+def colsum(x, M, N, out, ldx=None, coff=0):
+    hip.call("cris_colsum_bf16", ptr(x), ldx if ldx is not None else x.shape[-1], coff, M, N, ptr(out), _stream())
+
+
+# ---- BatchNorm ---------------------------------------------------------------------------------
+def bn_finalize(sum_, sumsq, count, gamma, beta, rmean, rvar, momentum, eps, C_, scale, shift, mean, invstd):
+    hip.call("cris_bn_finalize", ptr(sum_), ptr(sumsq), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
+             float(momentum), float(eps), C_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), _stream())
+
+
+def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, C_, scale, shift):
+    hip.call("cris_bn_eval_coeffs", ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(eps), C_, ptr(scale), ptr(shift),
+             _stream())
+
+
+def bn_apply(y, scale, shift, z, Bn, H, W, C_, *, ldy=None, y_coff=0, ldz=None, z_coff=0, relu=True, pool=False, y2=None,
+             ldy2=None, y2_coff=0, scale2=None, shift2=None, ident=None, ldi=None, i_coff=0, mul=None, osum=None, osq=None):
+    p = hip.BnApplyParams()
+    p.y, p.ldy, p.y_coff = ptr(y), ldy if ldy is not None else y.shape[-1], y_coff
+    p.scale, p.shift = ptr(scale), ptr(shift)
+    if y2 is not None:
+        p.y2, p.ldy2, p.y2_coff = ptr(y2), ldy2 if ldy2 is not None else y2.shape[-1], y2_coff
+        p.scale2, p.shift2 = ptr(scale2), ptr(shift2)
+    if ident is not None:
+        p.ident, p.ldi, p.i_coff = ptr(ident), ldi if ldi is not None else ident.shape[-1], i_coff
+    p.mul, p.osum, p.osq = ptr(mul), ptr(osum), ptr(osq)
+    p.z, p.ldz, p.z_coff = ptr(z), ldz if ldz is not None else z.shape[-1], z_coff
+    p.Bn, p.H, p.W, p.C = Bn, H, W, C_
+    p.relu, p.pool = int(relu), int(pool)
+    hip.call("cris_bn_apply", C.byref(p), _stream())
+
+
+def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, lddz=None, dz_coff=0, ldy=None, y_coff=0,
+           lddy=None, dy_coff=0, relu=True, pool=False, z=None, ldz=None, z_coff=0, y2=None, ldy2=None, y2_coff=0, mean2=None,
+           invstd2=None, scale2=None, dy2=None, lddy2=None, dy2_coff=0, mul=None, dmul=None, dident=None, lddi=None,
+           di_coff=0, dident_accum=False, between=None):
+    """reduce + apply.  `between(sums)` (optional) runs between the two launches (SyncBN all-reduce)."""
+    p = hip.BnBwdParams()
+    p.dz, p.lddz, p.dz_coff = ptr(dz), lddz if lddz is not None else dz.shape[-1], dz_coff
+    if z is not None:
+        p.z, p.ldz, p.z_coff = ptr(z), ldz if ldz is not None else z.shape[-1], z_coff
+    p.y, p.ldy, p.y_coff = ptr(y), ldy if ldy is not None else y.shape[-1], y_coff
+    p.scale, p.shift, p.mean, p.invstd = ptr(scale), ptr(shift), ptr(mean), ptr(invstd)
+    if y2 is not None:
+        p.y2, p.ldy2, p.y2_coff = ptr(y2), ldy2 if ldy2 is not None else y2.shape[-1], y2_coff
+        p.mean2, p.invstd2, p.scale2 = ptr(mean2), ptr(invstd2), ptr(scale2)
+    p.mul, p.sums, p.dmul = ptr(mul), ptr(sums), ptr(dmul)
+    p.dy, p.lddy, p.dy_coff = ptr(dy), lddy if lddy is not None else dy.shape[-1], dy_coff
+    if dy2 is not None:
+        p.dy2, p.lddy2, p.dy2_coff = ptr(dy2), lddy2 if lddy2 is not None else dy2.shape[-1], dy2_coff
+    if dident is not None:
+        p.dident, p.lddi, p.di_coff = ptr(dident), lddi if lddi is not None else dident.shape[-1], di_coff
+        p.dident_accum = int(dident_accum)
+    p.Bn, p.H, p.W, p.C = Bn, H, W, C_
+    p.relu, p.pool = int(relu), int(pool)
+    p.count = float(count)
+    s = _stream()
+    hip.call("cris_bn_bwd_reduce", C.byref(p), s)
+    if between is not None:
+        between(sums)
+    hip.call("cris_bn_bwd_apply", C.byref(p), s)
+
+
+# ---- LayerNorm ---------------------------------------------------------------------------------
+def ln_fwd(x, gamma, beta, rows, C_, mean, rstd, *, ldx=None, y=None, ypos=None, pos=None, pos_rows=0, resid=None,
+           out_f32=None, in_relu=False, in_drop: Drop = NO_DROP, out_drop: Drop = NO_DROP, eps=1e-5):
+    p = hip.LnFwdParams()
+    p.x, p.x_f32, p.ldx = ptr(x), int(x.dtype == torch.float32), ldx if ldx is not None else C_
+    p.gamma, p.beta = ptr(gamma), ptr(beta)
+    p.pos, p.pos_rows = ptr(pos), pos_rows
+    p.resid, p.y, p.ypos, p.out_f32 = ptr(resid), ptr(y), ptr(ypos), ptr(out_f32)
+    p.mean, p.rstd = ptr(mean), ptr(rstd)
+    p.rows, p.C, p.in_relu = rows, C_, int(in_relu)
+    p.in_drop_p, p.in_thresh, p.in_seed, p.in_stream = in_drop.p, in_drop.thresh, in_drop.seed & 0xFFFFFFFF, in_drop.stream
+    p.out_drop_p, p.out_thresh, p.out_seed, p.out_stream = out_drop.p, out_drop.thresh, out_drop.seed & 0xFFFFFFFF, out_drop.stream
+    p.eps = eps
+    hip.call("cris_ln_fwd", C.byref(p), _stream())
+
+
+def ln_bwd(x, gamma, mean, rstd, rows, C_, dx, *, ldx=None, dy=None, dypos=None, dout_f32=None, dgamma=None, dbeta=None,
+           dx_accum=False, in_relu=False, in_drop: Drop = NO_DROP, out_drop: Drop = NO_DROP):
+    p = hip.LnBwdParams()
+    p.x, p.x_f32, p.ldx = ptr(x), int(x.dtype == torch.float32), ldx if ldx is not None else C_
+    p.gamma, p.mean, p.rstd = ptr(gamma), ptr(mean), ptr(rstd)
+    p.dy, p.dypos, p.dout_f32 = ptr(dy), ptr(dypos), ptr(dout_f32)
+    p.dgamma, p.dbeta = ptr(dgamma), ptr(dbeta)
+    p.dx, p.dx_f32, p.dx_accum = ptr(dx), int(dx.dtype == torch.float32), int(dx_accum)
+    p.rows, p.C, p.in_relu = rows, C_, int(in_relu)
+    p.in_drop_p, p.in_thresh, p.in_seed, p.in_stream = in_drop.p, in_drop.thresh, in_drop.seed & 0xFFFFFFFF, in_drop.stream
+    p.out_drop_p, p.out_thresh, p.out_seed, p.out_stream = out_drop.p, out_drop.thresh, out_drop.seed & 0xFFFFFFFF, out_drop.stream
+    hip.call("cris_ln_bwd", C.byref(p), _stream())
+
+
+# ---- attention ---------------------------------------------------------------------------------
+def attn_params(Q, K, V, Vt, B, Hn, Lq, Lk, Lk_pad, scale, *, ldq=None, ldk=None, ldv=None, Kt=None, Qt=None, Lq_pad=0,
+                key_tokens=None, causal=False, drop: Drop = NO_DROP):
+    p = hip.AttnParams()
+    p.Q, p.ldq = ptr(Q), ldq if ldq is not None else Q.shape[-1]
+    p.K, p.ldk = ptr(K), ldk if ldk is not None else K.shape[-1]
+    p.V, p.ldv = ptr(V), ldv if ldv is not None else V.shape[-1]
+    p.Vt, p.Kt, p.Qt, p.Lk_pad, p.Lq_pad = ptr(Vt), ptr(Kt), ptr(Qt), Lk_pad, Lq_pad
+    p.key_tokens = ptr(key_tokens)
+    p.B, p.Hn, p.Lq, p.Lk, p.causal, p.scale = B, Hn, Lq, Lk, int(causal), float(scale)
+    p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
+    return p
+
+
+def attn_fwd(p, O, lse, ldo=None):
+    p.O, p.ldo, p.lse = ptr(O), ldo if ldo is not None else O.shape[-1], ptr(lse)
+    hip.call("cris_attn_fwd", C.byref(p), _stream())
+
+
+def attn_bwd(p, O, lse, dO, dOt, delta, dQ, dK, dV, *, ldo=None, lddo=None, lddq=None, lddk=None, lddv=None):
+    p.O, p.ldo, p.lse = ptr(O), ldo if ldo is not None else O.shape[-1], ptr(lse)
+    p.dO, p.lddo, p.dOt, p.delta = ptr(dO), lddo if lddo is not None else dO.shape[-1], ptr(dOt), ptr(delta)
+    p.dQ, p.lddq = ptr(dQ), lddq if lddq is not None else dQ.shape[-1]
+    p.dK, p.lddk = ptr(dK), lddk if lddk is not None else dK.shape[-1]
+    p.dV, p.lddv = ptr(dV), lddv if lddv is not None else dV.shape[-1]
+    s = _stream()
+    hip.call("cris_attn_bwd_dq", C.byref(p), s)
+    hip.call("cris_attn_bwd_dkv", C.byref(p), s)
+
+
+# ---- elementwise -------------------------------------------------------------------------------
+def stem_im2col(img, out):
+    Bn, _, H, W = img.shape
+    hip.call("cris_stem_im2col", ptr(img), Bn, H, W, ptr(out), _stream())
+
+
+def avgpool2_fwd(x, Bn, H, W, C_, y, ldx=None, xcoff=0, ldy=None, ycoff=0):
+    hip.call("cris_avgpool2_fwd", ptr(x), ldx if ldx is not None else x.shape[-1], xcoff, Bn, H, W, C_, ptr(y),
+             ldy if ldy is not None else y.shape[-1], ycoff, _stream())
+
+
+def avgpool2_bwd(dy, Bn, H, W, C_, dx, lddy=None, dycoff=0, lddx=None, dxcoff=0, accum=False):
+    hip.call("cris_avgpool2_bwd", ptr(dy), lddy if lddy is not None else dy.shape[-1], dycoff, Bn, H, W, C_, ptr(dx),
+             lddx if lddx is not None else dx.shape[-1], dxcoff, int(accum), _stream())
+
+
+def upsample2_fwd(x, Bn, H, W, C_, y, ldx=None, xcoff=0, ldy=None, ycoff=0):
+    hip.call("cris_upsample2_fwd", ptr(x), ldx if ldx is not None else x.shape[-1], xcoff, Bn, H, W, C_, ptr(y),
+             ldy if ldy is not None else y.shape[-1], ycoff, _stream())
+
+
+def upsample2_bwd(dy, Bn, H, W, C_, dx, lddy=None, dycoff=0, lddx=None, dxcoff=0, accum=False):
+    hip.call("cris_upsample2_bwd", ptr(dy), lddy if lddy is not None else dy.shape[-1], dycoff, Bn, H, W, C_, ptr(dx),
+             lddx if lddx is not None else dx.shape[-1], dxcoff, int(accum), _stream())
+
+
+def fill_coords(x, ldx, coff, nfill, Bn, H, W):
+    hip.call("cris_fill_coords", ptr(x), ldx, coff, nfill, Bn, H, W, _stream())
+
+
+def add_bf16(a, y, M, C_, b=None, lda=None, acoff=0, ldb=None, bcoff=0, ldy=None, ycoff=0):
+    hip.call("cris_add_bf16", ptr(a), lda if lda is not None else a.shape[-1], acoff, ptr(b),
+             (ldb if ldb is not None else (b.shape[-1] if b is not None else 0)), bcoff, ptr(y),
+             ldy if ldy is not None else y.shape[-1], ycoff, M, C_, _stream())
+
+
+def add_rowtable(a, table, trows, y, M, C_, lda=None, ldy=None):
+    hip.call("cris_add_rowtable", ptr(a), lda if lda is not None else a.shape[-1], ptr(table), trows, ptr(y),
+             ldy if ldy is not None else y.shape[-1], M, C_, _stream())
+
+
+def cast_f32_bf16(x, y):
+    hip.call("cris_cast_f32_bf16", ptr(x), ptr(y), x.numel(), _stream())
+
+
+def cast_bf16_f32(x, y, accum=False):
+    hip.call("cris_cast_bf16_f32", ptr(x), ptr(y), x.numel(), int(accum), _stream())
+
+
+def embed_fwd(tokens, table, pos, out):
+    Bn, L = tokens.shape
+    hip.call("cris_embed_fwd", ptr(tokens), ptr(table), ptr(pos), Bn, L, table.shape[1], ptr(out), _stream())
+
+
+def embed_bwd(tokens, dx, dtable, dpos):
+    Bn, L = tokens.shape
+    hip.call("cris_embed_bwd", ptr(tokens), ptr(dx), Bn, L, dtable.shape[1], ptr(dtable), ptr(dpos), _stream())
+
+
+def eot_gather(tokens, x, D, out, eot_index):
+    Bn, L = tokens.shape
+    hip.call("cris_eot_gather", ptr(tokens), ptr(x), Bn, L, D, ptr(out), ptr(eot_index), _stream())
+
+
+def eot_scatter_add(eot_index, drows, Bn, L, D, dx):
+    hip.call("cris_eot_scatter_add", ptr(eot_index), ptr(drows), Bn, L, D, ptr(dx), _stream())
+
+
+def posresize_fwd(R, pos, T, G, C_, posr):
+    hip.call("cris_posresize_fwd", ptr(R), ptr(pos), T, G, C_, ptr(posr), _stream())
+
+
+def posresize_bwd(R, dposr, T, G, C_, dpos):
+    hip.call("cris_posresize_bwd", ptr(R), ptr(dposr), T, G, C_, ptr(dpos), _stream())
+
+
+def batch_rowsum(dx, Bn, T, C_, out, ldx=None):
+    hip.call("cris_batch_rowsum", ptr(dx), ldx if ldx is not None else dx.shape[-1], Bn, T, C_, ptr(out), _stream())
+
+
+def dynconv_fwd(x, Bn, H, W, C_, wb, pred):
+    hip.call("cris_dynconv_fwd", ptr(x), Bn, H, W, C_, ptr(wb), wb.shape[-1], ptr(pred), _stream())
+
+
+def dynconv_bwd(x, dpred, Bn, H, W, C_, wb, dx, dwb):
+    hip.call("cris_dynconv_bwd", ptr(x), ptr(dpred), Bn, H, W, C_, ptr(wb), wb.shape[-1], ptr(dx), ptr(dwb), _stream())
+
+
+def mask_resize_nearest(mask, OH, OW, out):
+    Bn, _, IH, IW = mask.shape
+    hip.call("cris_mask_resize_nearest", ptr(mask), Bn, IH, IW, OH, OW, ptr(out), _stream())
+
+
+def bce_fwd(logits, target, loss_accum):
+    hip.call("cris_bce_fwd", ptr(logits), ptr(target), logits.numel(), ptr(loss_accum), _stream())
+
+
+def bce_bwd(logits, target, gscale, dlogits):
+    hip.call("cris_bce_bwd", ptr(logits), ptr(target), logits.numel(), ptr(gscale), ptr(dlogits), _stream())
+
+
+def train_metric(logits, target, Bn, HW, out, thr=0.35, pr_iou=0.5):
+    hip.call("cris_train_metric", ptr(logits), ptr(target), Bn, HW, float(thr), float(pr_iou), ptr(out), _stream())
+
+
+def memset_f32(t, v=0.0):
+    hip.call("cris_memset_f32", ptr(t), float(v), t.numel(), _stream())
+
+
+class AdamTable:
+    """Device table of {p, g, m, v, n, lr}: one launch = torch.optim.Adam.step() over every tensor."""
+
+    def __init__(self, params, grads, lrs):
+        lib = hip.load()
+        be = lib.cris_adam_block_elems()
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
+        self.params, self.grads, self.lrs = list(params), list(grads), list(lrs)
+        n = len(self.params)
+        self.arr = (hip.AdamDesc * n)()
+        start = 0
+        for i, (p, g) in enumerate(zip(self.params, self.grads)):
+            d = self.arr[i]
+            d.p, d.g, d.m, d.v, d.n, d.lr = ptr(p), ptr(g), ptr(self.m[i]), ptr(self.v[i]), p.numel(), self.lrs[i]
+            d.block_start = start
+            start += (p.numel() + be - 1) // be
+        self.total_blocks = start
+        self.n = n
+        self.dev = None
+        self.step_count = 0
+        self._upload(self.params[0].device)
+
+    def _upload(self, device):
+        self.dev = torch.frombuffer(bytearray(bytes(self.arr)), dtype=torch.uint8).to(device)
+
+    def set_lrs(self, lrs):
+        self.lrs = list(lrs)
+        for i, lr in enumerate(self.lrs):
+            self.arr[i].lr = lr
+        self._upload(self.params[0].device)
+
+    def step(self, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+        self.step_count += 1
+        bc1 = 1.0 - beta1 ** self.step_count
+        bc2 = 1.0 - beta2 ** self.step_count
+        hip.call("cris_adam_step", ptr(self.dev), self.n, self.total_blocks, beta1, beta2, eps, weight_decay, bc1, bc2,
+                 grad_scale, _stream())

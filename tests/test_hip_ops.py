@@ -1,0 +1,645 @@
+"""GPU parity tests, kernel by kernel: every C-ABI launcher vs a plain torch fp32 statement of the same
+op on the same (bf16-rounded) inputs.  Tolerances: bf16 outputs -> relative L2 error <= 1e-2 (one bf16
+rounding of an fp32-accumulated result is 2^-9 ~ 2e-3 per element); fp32 outputs of bf16 MFMA products ->
+5e-3; pure fp32 kernels -> 1e-5.  Index/mask decisions (dropout keep, nearest resize, EOT argmax) are
+bit exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from cris.pytorch_amd import ops  # noqa: E402
+from cris.pytorch_amd.ops import Geom, Drop  # noqa: E402
+from oracle import dropout_hash  # noqa: E402
+
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def bf(x):
+    return x.to(DEV).to(BF).contiguous()
+
+
+def relerr(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def check(a, b, tol, what=""):
+    e = relerr(a, b)
+    assert math.isfinite(e) and e <= tol, "%s rel L2 err %.3e > %.1e" % (what, e, tol)
+
+
+def keep_mask(seed, stream, shape, p):
+    n = int(np.prod(shape))
+    return torch.from_numpy(dropout_hash.keep_mask(seed, stream, n, p)).view(*shape).to(DEV)
+
+
+# ----------------------------------------------------------------------------------------------------
+# implicit GEMM
+# ----------------------------------------------------------------------------------------------------
+def conv_ref(x_nhwc, w, stride, pad):
+    """x [B,H,W,C] fp32, w [N,C,KH,KW] fp32 -> [B*OH*OW, N] fp32"""
+    y = F.conv2d(x_nhwc.permute(0, 3, 1, 2), w, stride=stride, padding=pad)
+    return y.permute(0, 2, 3, 1).reshape(-1, w.shape[0])
+
+
+def pack_F(w, Cpad=None):
+    """[N,C,KH,KW] -> [N, taps*Cpad] (k = tap*Cpad + c)"""
+    N, C_, KH, KW = w.shape
+    Cpad = Cpad or C_
+    out = torch.zeros(N, KH * KW, Cpad)
+    out[:, :, :C_] = w.permute(0, 2, 3, 1).reshape(N, KH * KW, C_)
+    return out.reshape(N, KH * KW * Cpad)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=12, W=12, C=64, N=128, k=1),
+    dict(B=2, H=12, W=12, C=64, N=64, k=3),
+    dict(B=1, H=20, W=20, C=32, N=32, k=3),          # BN=64 path, K=288 (tail in the K loop)
+    dict(B=2, H=9, W=9, C=136, N=72, k=3),           # C not a multiple of 64: chunks straddle taps; N tail
+    dict(B=3, H=8, W=10, C=24, N=200, k=3, stride=2),
+    dict(B=8, H=1, W=1, C=1024, N=2305, k=1),        # proj.txt shape: M=8, N tail
+    dict(B=700, H=1, W=1, C=512, N=1536, k=1),       # linear
+])
+def test_conv_gemm_plain(case):
+    B, H, W, C_, N, k = case["B"], case["H"], case["W"], case["C"], case["N"], case["k"]
+    stride = case.get("stride", 1)
+    pad = k // 2
+    x = rnd(B, H, W, C_).to(BF).float()
+    w = (rnd(N, C_, k, k, seed=1) / math.sqrt(C_ * k * k)).to(BF).float()
+    g = Geom(B, H, W, C_, k, k, stride, pad)
+    out = torch.empty(g.M, N, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), bf(pack_F(w)), g, N, out=out)
+    ref = conv_ref(x, w, stride, pad)
+    check(out, ref, 6e-3, "conv_gemm %s" % case)
+
+
+def test_conv_gemm_epilogues():
+    M, K, N = 300, 256, 192
+    x = rnd(M, K).to(BF).float()
+    w = (rnd(N, K, seed=1) / math.sqrt(K)).to(BF).float()
+    bias = rnd(N, seed=2)
+    res32 = rnd(M, N, seed=3)
+    resbf = rnd(M, N, seed=4).to(BF).float()
+    g = Geom.linear(M, K)
+    base = x @ w.t() + bias
+    # fp32 out, fp32 residual, QuickGELU
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=2, resid=res32.to(DEV), out=out)
+    check(out, base * torch.sigmoid(1.702 * base) + res32, 3e-3, "quickgelu+resid f32")
+    # bf16 out into a column slice of a wider buffer, bf16 residual, relu
+    wide = torch.zeros(M, N + 64, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=1, resid=bf(resbf), out=wide, ldc=N + 64, c_coff=64)
+    check(wide[:, 64:], torch.relu(base) + resbf, 6e-3, "relu+resid bf16 slice")
+    assert float(wide[:, :64].float().abs().max()) == 0.0
+    # column statistics
+    cs = torch.zeros(N, device=DEV)
+    cq = torch.zeros(N, device=DEV)
+    out2 = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, out=out2, colsum=cs, colsq=cq)
+    y = x @ w.t()
+    check(cs, y.sum(0), 3e-3, "colsum")
+    check(cq, (y * y).sum(0), 3e-3, "colsq")
+    # dropout (mask is an index op: exact), then residual
+    p, seed, stream = 0.1, 1234, 7
+    out3 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), resid=res32.to(DEV), out=out3, drop=Drop(p, seed, stream))
+    km = keep_mask(seed, stream, (M, N), p).cpu()
+    ref = base * km / (1 - p) + res32
+    check(out3, ref, 3e-3, "dropout epilogue")
+    dropped = (out3.cpu() - res32).abs() < 1e-12
+    assert bool((dropped == ~km).all()), "dropout keep decisions differ from the hash oracle"
+
+
+@pytest.mark.parametrize("L,B", [(24, 3), (17, 2)])
+def test_conv_gemm_transposed_store(L, B):
+    """head-split transposed copy written by the epilogue: outT[sec][(b*H+h)*64+d][l]"""
+    E, secs = 128, 3
+    M, K, N = B * L, 64, E * secs
+    x = rnd(M, K).to(BF).float()
+    w = (rnd(N, K, seed=1) / math.sqrt(K)).to(BF).float()
+    Lpad = ops.pad32(L)
+    Hh = E // 64
+    outT = torch.zeros(secs, B * Hh * 64, Lpad, dtype=BF, device=DEV)
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), Geom.linear(M, K), N, out=out, outT=outT, T_L=L, T_Lpad=Lpad, T_E=E,
+                  T_sec_stride=B * Hh * 64 * Lpad)
+    y = out.float().cpu()                                    # [B*L, secs*E]
+    ref = y.view(B, L, secs, Hh, 64).permute(2, 0, 3, 4, 1)   # [secs, B, Hh, 64, L]
+    got = outT.float().cpu().view(secs, B, Hh, 64, Lpad)
+    assert torch.equal(got[..., :L], ref.contiguous())
+    assert float(got[..., L:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=12, W=12, C=64, N=128, k=1),
+    dict(B=2, H=12, W=12, C=64, N=64, k=3),
+    dict(B=1, H=20, W=20, C=32, N=32, k=3),
+    dict(B=2, H=9, W=9, C=136, N=72, k=3, C_real=130),
+    dict(B=8, H=1, W=1, C=1024, N=2305, k=1),
+    dict(B=1500, H=1, W=1, C=40, N=24, k=1),
+])
+def test_conv_wgrad(case):
+    B, H, W, C_, N, k = case["B"], case["H"], case["W"], case["C"], case["N"], case["k"]
+    C_real = case.get("C_real", C_)
+    pad = k // 2
+    x = rnd(B, H, W, C_).to(BF).float()
+    if C_real < C_:
+        x[..., C_real:] = 0
+    g = Geom(B, H, W, C_, k, k, 1, pad)
+    Nld = ops.pad8(N)
+    dy = torch.zeros(g.M, Nld)
+    dy[:, :N] = rnd(g.M, N, seed=5)
+    dy = dy.to(BF).float()
+    dW = torch.zeros(N, C_real, k, k, device=DEV)
+    ops.conv_wgrad(bf(dy), bf(x), g, N, dW, C_real=C_real)
+    # reference: autograd of conv2d wrt weight
+    wt = torch.zeros(N, C_real, k, k, requires_grad=True)
+    y = F.conv2d(x[..., :C_real].permute(0, 3, 1, 2), wt, padding=pad)
+    y.backward(dy[:, :N].reshape(B, g.OH, g.OW, N).permute(0, 3, 1, 2))
+    check(dW, wt.grad, 3e-3, "wgrad %s" % case)
+
+
+def test_pack_weights():
+    tab = ops.PackTable()
+    w3 = rnd(24, 20, 3, 3).to(DEV)               # conv: Cin 20 -> Cpad 24
+    wl = rnd(40, 72, seed=1).to(DEV)             # linear [N, K]
+    wt = rnd(64, 48, seed=2).to(DEV)             # used as x @ wt (text_projection): src [Cin=64][N=48]
+    f3, d3 = tab.add(w3.view(24, 20, 9), 24, 20, 9, Cpad=24)
+    fl, dl = tab.add(wl.view(40, 72, 1), 40, 72, 1)
+    ft, dt = tab.add(wt, 48, 64, 1, src_transposed=True)
+    tab.run()
+    torch.cuda.synchronize()
+    w3b = w3.to(BF).float().cpu()
+    ref_f3 = torch.zeros(24, 9, 24)
+    ref_f3[:, :, :20] = w3b.permute(0, 2, 3, 1).reshape(24, 9, 20)
+    assert torch.equal(f3.float().cpu().view(24, 9, 24), ref_f3)
+    ref_d3 = w3b.flip(2, 3).permute(1, 2, 3, 0).reshape(20, 9, 24)      # [c][flipped tap][n]
+    assert torch.equal(d3.float().cpu().view(20, 9, 24), ref_d3)
+    wlb = wl.to(BF).float().cpu()
+    assert torch.equal(fl.float().cpu(), wlb)
+    assert torch.equal(dl.float().cpu(), wlb.t().contiguous())
+    wtb = wt.to(BF).float().cpu()
+    assert torch.equal(ft.float().cpu(), wtb.t().contiguous())
+    assert torch.equal(dt.float().cpu(), wtb)
+
+
+def test_dgrad_via_packed_weights():
+    """input gradient of a 3x3 conv = the same implicit GEMM over dY with the D-layout pack"""
+    B, H, W, C_, N = 2, 10, 10, 32, 48
+    w = (rnd(N, C_, 3, 3) / math.sqrt(C_ * 9)).to(BF).float()
+    dy = rnd(B, H, W, N, seed=3).to(BF).float()
+    tab = ops.PackTable()
+    _, wd = tab.add(w.to(DEV).view(N, C_, 9), N, C_, 9, want_F=False)
+    tab.run()
+    dx = torch.empty(B * H * W, C_, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(dy), wd, Geom(B, H, W, N, 3, 3, 1, 1), C_, out=dx)
+    x = torch.zeros(B, C_, H, W, requires_grad=True)
+    F.conv2d(x, w, padding=1).backward(dy.permute(0, 3, 1, 2))
+    check(dx, x.grad.permute(0, 2, 3, 1).reshape(-1, C_), 6e-3, "dgrad")
+
+
+def test_colsum():
+    x = rnd(1000, 72).to(BF).float()
+    out = torch.zeros(72, device=DEV)
+    ops.colsum(bf(x), 1000, 72, out)
+    check(out, x.sum(0), 1e-5, "colsum_bf16")
+
+
+# ----------------------------------------------------------------------------------------------------
+# BatchNorm
+# ----------------------------------------------------------------------------------------------------
+def _bn_setup(B, H, W, C_, seed=0):
+    y = (rnd(B, H, W, C_, seed=seed) * 1.5 + 0.3).to(BF).float()
+    gamma = rnd(C_, seed=seed + 1) * 0.2 + 1.0
+    beta = rnd(C_, seed=seed + 2) * 0.1
+    return y, gamma, beta
+
+
+def _bn_coeffs(y2d, gamma, beta, rm=None, rv=None):
+    C_ = y2d.shape[1]
+    M = y2d.shape[0]
+    s = y2d.sum(0).to(DEV)
+    q = (y2d * y2d).sum(0).to(DEV)
+    outs = [torch.empty(C_, device=DEV) for _ in range(4)]
+    ops.bn_finalize(s, q, M, gamma.to(DEV), beta.to(DEV), rm, rv, 0.1, 1e-5, C_, *outs)
+    return outs
+
+
+def test_bn_finalize_and_running_stats():
+    y, gamma, beta = _bn_setup(2, 6, 6, 40)
+    y2 = y.reshape(-1, 40)
+    rm = torch.zeros(40, device=DEV) + 0.5
+    rv = torch.ones(40, device=DEV) * 2
+    scale, shift, mean, invstd = _bn_coeffs(y2, gamma, beta, rm, rv)
+    m = y2.mean(0)
+    v = y2.var(0, unbiased=False)
+    check(mean, m, 1e-5)
+    check(invstd, torch.rsqrt(v + 1e-5), 1e-4)
+    check(scale, gamma * torch.rsqrt(v + 1e-5), 1e-4)
+    check(shift, beta - m * gamma * torch.rsqrt(v + 1e-5), 1e-3)
+    check(rm, 0.9 * 0.5 + 0.1 * m, 1e-5)
+    check(rv, 0.9 * 2 + 0.1 * y2.var(0, unbiased=True), 1e-4)
+
+
+@pytest.mark.parametrize("variant", ["plain", "pool", "ident", "two", "mul"])
+def test_bn_apply_and_backward(variant):
+    B, H, W, C_ = 2, 8, 8, 48
+    y, gamma, beta = _bn_setup(B, H, W, C_)
+    y2d = y.reshape(-1, C_)
+    M = y2d.shape[0]
+    scale, shift, mean, invstd = _bn_coeffs(y2d, gamma, beta)
+    yl = y.clone().requires_grad_(True)
+    gl, bl = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+
+    def tbn(t, g_, b_):
+        return F.batch_norm(t.permute(0, 3, 1, 2), None, None, g_, b_, True, 0.1, 1e-5).permute(0, 2, 3, 1)
+
+    kw, bkw = {}, {}
+    extra_leaves = {}
+    if variant == "plain":
+        ref = torch.relu(tbn(yl, gl, bl))
+    elif variant == "pool":
+        ref = F.avg_pool2d(torch.relu(tbn(yl, gl, bl)).permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+        kw["pool"] = True
+    elif variant == "ident":
+        idt = rnd(B, H, W, C_, seed=9).to(BF).float()
+        il = idt.clone().requires_grad_(True)
+        extra_leaves["ident"] = il
+        ref = torch.relu(tbn(yl, gl, bl) + il)
+        kw.update(ident=bf(idt))
+    elif variant == "two":
+        y2, gamma2, beta2 = _bn_setup(B, H, W, C_, seed=20)
+        sc2, sh2, mean2, inv2 = _bn_coeffs(y2.reshape(-1, C_), gamma2, beta2)
+        y2l = y2.clone().requires_grad_(True)
+        g2l, b2l = gamma2.clone().requires_grad_(True), beta2.clone().requires_grad_(True)
+        extra_leaves.update(y2=y2l, g2=g2l, b2=b2l)
+        ref = torch.relu(tbn(yl, gl, bl) + tbn(y2l, g2l, b2l))
+        kw.update(y2=bf(y2), scale2=sc2, shift2=sh2)
+    elif variant == "mul":
+        mul = torch.relu(rnd(B, C_, seed=11)) + 0.1
+        ml = mul.clone().requires_grad_(True)
+        extra_leaves["mul"] = ml
+        ref = torch.relu(tbn(yl, gl, bl)) * ml[:, None, None, :]
+        kw.update(mul=mul.to(DEV))
+    OHo, OWo = (H // 2, W // 2) if variant == "pool" else (H, W)
+    z = torch.empty(B * OHo * OWo, C_, dtype=BF, device=DEV)
+    osum = torch.zeros(C_, device=DEV)
+    osq = torch.zeros(C_, device=DEV)
+    if variant == "mul":
+        kw.update(osum=osum, osq=osq)
+    ops.bn_apply(bf(y), scale, shift, z, B, H, W, C_, relu=True, **kw)
+    check(z, ref.reshape(-1, C_), 6e-3, "bn_apply " + variant)
+    if variant == "mul":
+        zz = z.float().cpu()
+        check(osum, zz.sum(0), 1e-4, "osum")
+        check(osq, (zz * zz).sum(0), 1e-4, "osq")
+
+    # backward
+    dz = rnd(B, OHo, OWo, C_, seed=30).to(BF).float()
+    (ref * dz).sum().backward()
+    sums = torch.zeros(4 * C_, device=DEV)
+    dy = torch.empty(M, C_, dtype=BF, device=DEV)
+    if variant == "pool":
+        bkw.update(pool=True)
+    if variant == "ident":
+        bkw.update(z=z, dident=torch.empty(M, C_, dtype=BF, device=DEV))
+    if variant == "two":
+        bkw.update(z=z, y2=bf(y2), mean2=mean2, invstd2=inv2, scale2=sc2, dy2=torch.empty(M, C_, dtype=BF, device=DEV))
+    if variant == "mul":
+        bkw.update(mul=mul.to(DEV), dmul=torch.zeros(B, C_, device=DEV))
+    ops.bn_bwd(bf(dz), bf(y), scale, shift, mean, invstd, sums, dy, B, H, W, C_, M, relu=True, **bkw)
+    check(dy, yl.grad.reshape(-1, C_), 1.5e-2, "bn dy " + variant)
+    check(sums[:C_], bl.grad, 5e-3, "dbeta " + variant)
+    check(sums[C_:2 * C_], gl.grad, 5e-3, "dgamma " + variant)
+    if variant == "ident":
+        check(bkw["dident"], extra_leaves["ident"].grad.reshape(-1, C_), 1e-2, "dident")
+    if variant == "two":
+        check(bkw["dy2"], extra_leaves["y2"].grad.reshape(-1, C_), 1.5e-2, "dy2")
+        check(sums[3 * C_:], extra_leaves["g2"].grad, 5e-3, "dgamma2")
+    if variant == "mul":
+        check(bkw["dmul"], extra_leaves["mul"].grad, 5e-3, "dmul")
+
+
+# ----------------------------------------------------------------------------------------------------
+# LayerNorm
+# ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C_", [128, 512, 2048])
+def test_layernorm_variants(C_):
+    rows, T = 70, 10
+    x32 = rnd(rows, C_) * 2 + 0.5
+    gamma = rnd(C_, seed=1) * 0.2 + 1
+    beta = rnd(C_, seed=2) * 0.1
+    pos = rnd(T, C_, seed=3)
+    resid = rnd(rows, C_, seed=4)
+    mean = torch.empty(rows, device=DEV)
+    rstd = torch.empty(rows, device=DEV)
+    # (a) fp32 in -> y, ypos
+    y = torch.empty(rows, C_, dtype=BF, device=DEV)
+    ypos = torch.empty(rows, C_, dtype=BF, device=DEV)
+    ops.ln_fwd(x32.to(DEV), gamma.to(DEV), beta.to(DEV), rows, C_, mean, rstd, y=y, ypos=ypos, pos=pos.to(DEV), pos_rows=T)
+    xl = x32.clone().requires_grad_(True)
+    gl, bl = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xl, (C_,), gl, bl, 1e-5)
+    check(y, ref, 6e-3, "ln y")
+    check(ypos, ref + pos.repeat(rows // T, 1), 6e-3, "ln ypos")
+    dy = rnd(rows, C_, seed=5).to(BF).float()
+    dyp = rnd(rows, C_, seed=6).to(BF).float()
+    (ref * (dy + dyp)).sum().backward()
+    dx = torch.zeros(rows, C_, device=DEV) + 1.0
+    dg = torch.zeros(C_, device=DEV)
+    db = torch.zeros(C_, device=DEV)
+    ops.ln_bwd(x32.to(DEV), gamma.to(DEV), mean, rstd, rows, C_, dx, dy=bf(dy), dypos=bf(dyp), dgamma=dg, dbeta=db, dx_accum=True)
+    check(dx - 1.0, xl.grad, 2e-3, "ln dx (accum f32)")
+    check(dg, gl.grad, 1e-3, "ln dgamma")
+    check(db, bl.grad, 1e-3, "ln dbeta")
+    # (b) bf16 pre-activation in, relu + input dropout (FFN norm), bf16 dx
+    p, seed = 0.1, 77
+    h = (rnd(rows, C_, seed=8) * 1.5).to(BF).float()
+    km = keep_mask(seed, 4, (rows, C_), p).cpu().float()
+    hl = h.clone().requires_grad_(True)
+    ref2 = F.layer_norm(torch.relu(hl) * km / (1 - p), (C_,), gamma, beta, 1e-5)
+    y2 = torch.empty(rows, C_, dtype=BF, device=DEV)
+    ops.ln_fwd(bf(h), gamma.to(DEV), beta.to(DEV), rows, C_, mean, rstd, y=y2, in_relu=True, in_drop=Drop(p, seed, 4))
+    check(y2, ref2, 6e-3, "ln(relu,dropout)")
+    (ref2 * dy).sum().backward()
+    dh = torch.empty(rows, C_, dtype=BF, device=DEV)
+    ops.ln_bwd(bf(h), gamma.to(DEV), mean, rstd, rows, C_, dh, dy=bf(dy), in_relu=True, in_drop=Drop(p, seed, 4))
+    check(dh, hl.grad, 8e-3, "ln(relu,dropout) dx")
+    # (c) bf16 in -> resid + dropout(LN(x)) in fp32 (post-attention norms)
+    a = rnd(rows, C_, seed=9).to(BF).float()
+    km2 = keep_mask(seed, 1, (rows, C_), p).cpu().float()
+    al = a.clone().requires_grad_(True)
+    ref3 = resid + F.layer_norm(al, (C_,), gamma, beta, 1e-5) * km2 / (1 - p)
+    o3 = torch.empty(rows, C_, device=DEV)
+    ops.ln_fwd(bf(a), gamma.to(DEV), beta.to(DEV), rows, C_, mean, rstd, resid=resid.to(DEV), out_f32=o3, out_drop=Drop(p, seed, 1))
+    check(o3, ref3, 2e-3, "resid + drop(LN)")
+    do = rnd(rows, C_, seed=10)
+    (ref3 * do).sum().backward()
+    da = torch.empty(rows, C_, dtype=BF, device=DEV)
+    ops.ln_bwd(bf(a), gamma.to(DEV), mean, rstd, rows, C_, da, dout_f32=do.to(DEV), out_drop=Drop(p, seed, 1))
+    check(da, al.grad, 8e-3, "resid-drop LN dx")
+
+
+# ----------------------------------------------------------------------------------------------------
+# attention
+# ----------------------------------------------------------------------------------------------------
+def _head_T(x, B, L, Hn, Lpad):
+    """[B*L, Hn*64] -> [(b*Hn+h)*64+d][Lpad] zero padded"""
+    t = x.view(B, L, Hn, 64).permute(0, 2, 3, 1).reshape(B * Hn * 64, L)
+    out = torch.zeros(B * Hn * 64, Lpad, dtype=x.dtype, device=x.device)
+    out[:, :L] = t
+    return out.contiguous()
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=2, Hn=2, Lq=100, Lk=100, p=0.1),                  # decoder self-attention style, dropout
+    dict(B=2, Hn=2, Lq=70, Lk=17, pad=True, p=0.1),          # cross attention, key padding
+    dict(B=3, Hn=2, Lq=17, Lk=17, causal=True, p=0.0),       # text
+    dict(B=1, Hn=4, Lq=169, Lk=169, p=0.0),                  # attnpool
+])
+def test_attention_fwd_bwd(case):
+    B, Hn, Lq, Lk, p = case["B"], case["Hn"], case["Lq"], case["Lk"], case["p"]
+    causal = case.get("causal", False)
+    E = Hn * 64
+    scale = 64 ** -0.5
+    q = rnd(B * Lq, E).to(BF).float()
+    k = rnd(B * Lk, E, seed=1).to(BF).float()
+    v = rnd(B * Lk, E, seed=2).to(BF).float()
+    toks = None
+    if case.get("pad"):
+        toks = torch.ones(B, Lk, dtype=torch.int64)
+        toks[0, 9:] = 0
+        toks[1, 14:] = 0
+    seed, stream = 4321, 2
+    Lkp, Lqp = ops.pad32(Lk), ops.pad32(Lq)
+    qd, kd, vd = bf(q), bf(k), bf(v)
+    prm = ops.attn_params(qd, kd, vd, _head_T(vd, B, Lk, Hn, Lkp), B, Hn, Lq, Lk, Lkp, scale, Kt=_head_T(kd, B, Lk, Hn, Lkp),
+                          Qt=_head_T(qd, B, Lq, Hn, Lqp), Lq_pad=Lqp, key_tokens=None if toks is None else toks.to(DEV),
+                          causal=causal, drop=Drop(p, seed, stream))
+    O = torch.empty(B * Lq, E, dtype=BF, device=DEV)
+    lse = torch.empty(B * Hn, Lq, device=DEV)
+    ops.attn_fwd(prm, O, lse)
+    # reference
+    ql, kl, vl = [t.clone().requires_grad_(True) for t in (q, k, v)]
+    qh = ql.view(B, Lq, Hn, 64).transpose(1, 2) * scale
+    kh = kl.view(B, Lk, Hn, 64).transpose(1, 2)
+    vh = vl.view(B, Lk, Hn, 64).transpose(1, 2)
+    s = qh @ kh.transpose(-1, -2)
+    if causal:
+        s = s + torch.full((Lq, Lk), float("-inf")).triu_(1)
+    if toks is not None:
+        s = s.masked_fill((toks == 0)[:, None, None, :], float("-inf"))
+    pr = torch.softmax(s, -1)
+    check(lse, torch.logsumexp(s, -1).reshape(B * Hn, Lq), 2e-3, "lse")
+    if p > 0:
+        km = keep_mask(seed, stream, (B, Hn, Lq, Lk), p).cpu().float()
+        pr = pr * km / (1 - p)
+    o = (pr @ vh).transpose(1, 2).reshape(B * Lq, E)
+    check(O, o, 1e-2, "attn fwd %s" % case)
+    do = rnd(B * Lq, E, seed=7).to(BF).float()
+    (o * do).sum().backward()
+    dod = bf(do)
+    dQ = torch.empty_like(qd)
+    dK = torch.empty_like(kd)
+    dV = torch.empty_like(vd)
+    delta = torch.empty(B * Hn, Lq, device=DEV)
+    ops.attn_bwd(prm, O, lse, dod, _head_T(dod, B, Lq, Hn, Lqp), delta, dQ, dK, dV)
+    check(dV, vl.grad, 1.5e-2, "dV")
+    check(dQ, ql.grad, 1.5e-2, "dQ")
+    check(dK, kl.grad, 1.5e-2, "dK")
+
+
+# ----------------------------------------------------------------------------------------------------
+# elementwise
+# ----------------------------------------------------------------------------------------------------
+def test_stem_im2col_matches_conv():
+    B, H, W = 2, 20, 28
+    img = rnd(B, 3, H, W)
+    w = rnd(16, 3, 3, 3, seed=1).to(BF).float()
+    col = torch.empty(B * (H // 2) * (W // 2), 32, dtype=BF, device=DEV)
+    ops.stem_im2col(img.to(DEV), col)
+    wp = torch.zeros(16, 32)
+    wp[:, :27] = w.reshape(16, 27)
+    out = col.float().cpu() @ wp.t()
+    ref = F.conv2d(img.to(BF).float(), w, stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, 16)
+    check(out, ref, 1e-5, "stem im2col")
+
+
+def test_pool_and_upsample():
+    B, H, W, C_ = 2, 6, 10, 24
+    x = rnd(B, H, W, C_).to(BF).float()
+    y = torch.empty(B * (H // 2) * (W // 2), C_, dtype=BF, device=DEV)
+    ops.avgpool2_fwd(bf(x), B, H, W, C_, y)
+    check(y, F.avg_pool2d(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1).reshape(-1, C_), 4e-3, "avgpool")
+    up = torch.empty(B * H * 2 * W * 2, C_ + 8, dtype=BF, device=DEV)
+    ops.upsample2_fwd(bf(x), B, H, W, C_, up, ldy=C_ + 8, ycoff=8)
+    xl = x.clone().requires_grad_(True)
+    ref = F.interpolate(xl.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear").permute(0, 2, 3, 1)
+    check(up[:, 8:], ref.reshape(-1, C_), 4e-3, "upsample2")
+    g = rnd(B, 2 * H, 2 * W, C_, seed=3).to(BF).float()
+    (ref * g).sum().backward()
+    dx = torch.empty(B * H * W, C_, dtype=BF, device=DEV)
+    ops.upsample2_bwd(bf(g), B, H, W, C_, dx)
+    check(dx, xl.grad.reshape(-1, C_), 5e-3, "upsample2 bwd")
+    gp = rnd(B, H // 2, W // 2, C_, seed=4).to(BF).float()
+    dxp = torch.empty(B * H * W, C_, dtype=BF, device=DEV)
+    ops.avgpool2_bwd(bf(gp), B, H, W, C_, dxp)
+    refp = F.interpolate(gp.permute(0, 3, 1, 2), scale_factor=2, mode="nearest").permute(0, 2, 3, 1) * 0.25
+    check(dxp, refp.reshape(-1, C_), 4e-3, "avgpool bwd")
+
+
+def test_coords_adds_casts():
+    B, H, W = 2, 5, 7
+    buf = torch.ones(B * H * W, 16, dtype=BF, device=DEV)
+    ops.fill_coords(buf, 16, 8, 8, B, H, W)
+    got = buf.float().cpu().view(B, H, W, 16)
+    xr = torch.linspace(-1, 1, W).to(BF).float()
+    yr = torch.linspace(-1, 1, H).to(BF).float()
+    assert torch.equal(got[..., 8], xr.view(1, 1, W).expand(B, H, W))
+    assert torch.equal(got[..., 9], yr.view(1, H, 1).expand(B, H, W))
+    assert float(got[..., 10:].abs().max()) == 0 and float((got[..., :8] - 1).abs().max()) == 0
+    a = rnd(30, 16).to(BF).float()
+    b = rnd(30, 16, seed=1).to(BF).float()
+    y = torch.empty(30, 16, dtype=BF, device=DEV)
+    ops.add_bf16(bf(a), y, 30, 16, b=bf(b))
+    check(y, a + b, 4e-3)
+    tab = rnd(6, 16, seed=2)
+    ops.add_rowtable(bf(a), tab.to(DEV), 6, y, 30, 16)
+    check(y, a + tab.repeat(5, 1), 4e-3)
+    f = rnd(1000)
+    o = torch.empty(1000, dtype=BF, device=DEV)
+    ops.cast_f32_bf16(f.to(DEV), o)
+    assert torch.equal(o.cpu(), f.to(BF))
+    acc = torch.ones(1000, device=DEV)
+    ops.cast_bf16_f32(o, acc, accum=True)
+    check(acc, f.to(BF).float() + 1, 1e-6)
+
+
+def test_embedding_and_eot():
+    B, L, D, V = 3, 9, 64, 500
+    toks = torch.tensor([[400, 5, 7, 499, 0, 0, 0, 0, 0], [400, 3, 499, 0, 0, 0, 0, 0, 0], [400, 1, 2, 3, 4, 5, 6, 499, 0]])
+    table = rnd(V, D)
+    pos = rnd(77, D, seed=1)
+    out = torch.empty(B * L, D, device=DEV)
+    ops.embed_fwd(toks.to(DEV), table.to(DEV), pos.to(DEV), out)
+    assert torch.equal(out.cpu(), (table[toks] + pos[:L]).reshape(B * L, D))
+    dx = rnd(B * L, D, seed=2)
+    dt = torch.zeros(V, D, device=DEV)
+    dp = torch.zeros(77, D, device=DEV)
+    ops.embed_bwd(toks.to(DEV), dx.to(DEV), dt, dp)
+    rt = torch.zeros(V, D).index_add_(0, toks.flatten(), dx)
+    check(dt, rt, 1e-6)
+    check(dp[:L], dx.view(B, L, D).sum(0), 1e-6)
+    x = rnd(B * L, D, seed=3).to(BF)
+    rows = torch.empty(B, D, dtype=BF, device=DEV)
+    idx = torch.empty(B, dtype=torch.int32, device=DEV)
+    ops.eot_gather(toks.to(DEV), x.to(DEV), D, rows, idx)
+    assert idx.cpu().tolist() == toks.argmax(-1).tolist() == [3, 2, 7]
+    assert torch.equal(rows.cpu(), x.view(B, L, D)[torch.arange(B), toks.argmax(-1)])
+    dxx = torch.zeros(B * L, D, dtype=BF, device=DEV)
+    ops.eot_scatter_add(idx, rows, B, L, D, dxx)
+    ref = torch.zeros(B, L, D, dtype=BF)
+    ref[torch.arange(B), toks.argmax(-1)] = x.view(B, L, D)[torch.arange(B), toks.argmax(-1)]
+    assert torch.equal(dxx.cpu().view(B, L, D), ref)
+
+
+def test_posresize_and_rowsum():
+    from cris.pytorch_amd.tables import bicubic_resize_matrix
+    G, H, W, C_ = 7, 13, 13, 32
+    pos = rnd(G * G + 1, C_)
+    R = torch.from_numpy(bicubic_resize_matrix(G, H, W)).float()
+    ref = F.interpolate(pos[1:].reshape(1, G, G, C_).permute(0, 3, 1, 2), size=(H, W), mode="bicubic", align_corners=False)
+    ref = ref.flatten(2)[0].t()                                       # [HW, C]
+    posr = torch.empty(H * W, C_, device=DEV)
+    ops.posresize_fwd(R.to(DEV), pos.to(DEV), H * W, G, C_, posr)
+    check(posr, ref, 1e-5, "bicubic pos resize")
+    d = rnd(H * W, C_, seed=1)
+    dpos = torch.zeros(G * G + 1, C_, device=DEV)
+    ops.posresize_bwd(R.to(DEV), d.to(DEV), H * W, G, C_, dpos)
+    check(dpos[1:], R.t() @ d, 1e-5)
+    assert float(dpos[0].abs().max()) == 0
+    dx = rnd(3 * 20, 16, seed=2).to(BF)
+    out = torch.empty(20, 16, device=DEV)
+    ops.batch_rowsum(dx.to(DEV), 3, 20, 16, out)
+    check(out, dx.float().view(3, 20, 16).sum(0), 1e-6)
+
+
+@pytest.mark.parametrize("C_", [64, 256])
+def test_dynconv(C_):
+    B, H, W = 3, 12, 14
+    x = rnd(B, H, W, C_).to(BF).float()
+    wb = rnd(B, C_ * 9 + 1, seed=1) * 0.05
+    pred = torch.empty(B, H * W, device=DEV)
+    ops.dynconv_fwd(bf(x), B, H, W, C_, wb.to(DEV), pred)
+    xl = x.clone().requires_grad_(True)
+    wl = wb.clone().requires_grad_(True)
+    ref = F.conv2d(xl.permute(0, 3, 1, 2).reshape(1, B * C_, H, W), wl[:, :-1].reshape(B, C_, 3, 3), padding=1, groups=B,
+                   bias=wl[:, -1])[0]
+    check(pred, ref.reshape(B, H * W), 1e-4, "dynconv fwd")
+    dp = rnd(B, H, W, seed=2)
+    (ref * dp).sum().backward()
+    dx = torch.empty(B * H * W, C_, dtype=BF, device=DEV)
+    dwb = torch.zeros(B, C_ * 9 + 1, device=DEV)
+    ops.dynconv_bwd(bf(x), dp.to(DEV), B, H, W, C_, wb.to(DEV), dx, dwb)
+    check(dx, xl.grad.reshape(-1, C_), 5e-3, "dynconv dx")
+    check(dwb, wl.grad, 1e-4, "dynconv dw")
+
+
+def test_loss_mask_metric():
+    B, S, O_ = 3, 64, 16
+    mask = (torch.rand(B, 1, S, S, generator=torch.Generator().manual_seed(0)) > 0.5).float()
+    out = torch.empty(B, 1, O_, O_, device=DEV)
+    ops.mask_resize_nearest(mask.to(DEV), O_, O_, out)
+    assert torch.equal(out.cpu(), F.interpolate(mask, (O_, O_), mode="nearest"))
+    mask2 = (torch.rand(2, 1, 50, 70, generator=torch.Generator().manual_seed(1)) > 0.5).float()
+    out2 = torch.empty(2, 1, 13, 23, device=DEV)
+    ops.mask_resize_nearest(mask2.to(DEV), 13, 23, out2)
+    assert torch.equal(out2.cpu(), F.interpolate(mask2, (13, 23), mode="nearest"))
+    x = rnd(B, 1, O_, O_) * 3
+    t = out.cpu()
+    loss = torch.zeros(1, device=DEV)
+    ops.bce_fwd(x.to(DEV), out, loss)
+    xl = x.clone().requires_grad_(True)
+    ref = F.binary_cross_entropy_with_logits(xl, t)
+    assert abs(float(loss) - float(ref)) < 1e-5
+    (ref * 3.0).backward()
+    dx = torch.empty(B, 1, O_, O_, device=DEV)
+    ops.bce_bwd(x.to(DEV), out, torch.tensor([3.0], device=DEV), dx)
+    check(dx, xl.grad, 1e-5)
+    met = torch.zeros(2, device=DEV)
+    ops.train_metric(x.to(DEV), out, B, O_ * O_, met)
+    o = (torch.sigmoid(x.flatten(1)) >= 0.35)
+    tt = t.flatten(1).bool()
+    ious = (o & tt).sum(1) / ((o | tt).sum(1) + 1e-6)
+    assert abs(float(met[0]) - float(100 * ious.mean())) < 1e-3
+    assert abs(float(met[1]) - float(100 * (ious > 0.5).float().mean())) < 1e-3
+
+
+def test_adam_matches_torch():
+    ps = [rnd(1000), rnd(33, 7, seed=1), rnd(20000, seed=2)]
+    gs = [rnd(*p.shape, seed=5) for p in ps]
+    dev_p = [p.clone().to(DEV) for p in ps]
+    dev_g = [g.clone().to(DEV) for g in gs]
+    tab = ops.AdamTable(dev_p, dev_g, [1e-3, 1e-3, 1e-4])
+    ref_p = [torch.nn.Parameter(p.clone()) for p in ps]
+    opt = torch.optim.Adam([{"params": ref_p[:2], "lr": 1e-3}, {"params": ref_p[2:], "lr": 1e-4}])
+    for step in range(3):
+        for rp, g in zip(ref_p, gs):
+            rp.grad = g * (step + 1)
+        for dg, g in zip(dev_g, gs):
+            dg.copy_(g * (step + 1))
+        opt.step()
+        tab.step()
+    for dp, rp in zip(dev_p, ref_p):
+        check(dp, rp.data, 1e-6, "adam")
