@@ -324,6 +324,67 @@ extern "C" int cris_cast_bf16_f32(const cris_bf16* x, float* y, long n, int accu
     CRIS_LAUNCH_CHECK();
     return 0;
 }
+// QuickGELU (reference model/clip.py:234-236) on a bf16 pre-activation, and its gradient
+__global__ void quickgelu_fwd_kernel(const bf16_t* x, bf16_t* y, long nvec) {
+    GRID_STRIDE(i, nvec) {
+        float v[8];
+        ld8bf(x + i * 8, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
+        st8bf(y + i * 8, v);
+    }
+}
+extern "C" int cris_quickgelu_fwd(const cris_bf16* x, cris_bf16* y, long n, void* stream) {
+    CRIS_CHECK_ARG(x && y && n > 0 && !(n & 7), "n must be a multiple of 8");
+    hipLaunchKernelGGL(quickgelu_fwd_kernel, dim3(cris_grid_1d(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n / 8);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void quickgelu_bwd_kernel(const bf16_t* x, const bf16_t* dy, bf16_t* dx, long nvec) {
+    GRID_STRIDE(i, nvec) {
+        float v[8], g[8];
+        ld8bf(x + i * 8, v);
+        ld8bf(dy + i * 8, g);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float s = 1.f / (1.f + __expf(-1.702f * v[j]));
+            g[j] *= s * (1.f + 1.702f * v[j] * (1.f - s));
+        }
+        st8bf(dx + i * 8, g);
+    }
+}
+extern "C" int cris_quickgelu_bwd(const cris_bf16* x, const cris_bf16* dy, cris_bf16* dx, long n, void* stream) {
+    CRIS_CHECK_ARG(x && dy && dx && n > 0 && !(n & 7), "n must be a multiple of 8");
+    hipLaunchKernelGGL(quickgelu_bwd_kernel, dim3(cris_grid_1d(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, n / 8);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+// y(bf16) = dropout_mask(idx) ? x * 1/(1-p) : 0  (gradient of an output dropout applied to an fp32 stream)
+__global__ void cast_drop_kernel(const float* x, bf16_t* y, long n, float scale, uint32_t thresh, uint32_t key) {
+    GRID_STRIDE(i, n) {
+        float v = x[i];
+        if (thresh) v = cris_keep(key, (uint32_t)i, thresh) ? v * scale : 0.f;
+        y[i] = f2bf(v);
+    }
+}
+extern "C" int cris_cast_f32_bf16_drop(const float* x, cris_bf16* y, long n, float drop_p, uint32_t drop_thresh, uint32_t seed,
+                                       uint32_t stream_id, void* stream) {
+    CRIS_CHECK_ARG(x && y && n > 0 && n < (1L << 32), "bad args");
+    const float scale = drop_thresh ? 1.f / (1.f - drop_p) : 1.f;
+    hipLaunchKernelGGL(cast_drop_kernel, dim3(cris_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, scale, drop_thresh,
+                       seed ^ (stream_id * 0x9E3779B9u));
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void axpy_f32_kernel(float* dst, const float* src, float alpha, long n) {
+    GRID_STRIDE(i, n) dst[i] += alpha * src[i];
+}
+extern "C" int cris_axpy_f32(float* dst, const float* src, float alpha, long n, void* stream) {
+    CRIS_CHECK_ARG(dst && src && n > 0, "bad args");
+    hipLaunchKernelGGL(axpy_f32_kernel, dim3(cris_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, dst, src, alpha, n);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
 __global__ void memset_f32_kernel(float* p, float v, long n) {
     GRID_STRIDE(i, n) p[i] = v;
 }

@@ -169,6 +169,10 @@ _SIGS = {
     "cris_add_rowtable": (I, [P, I, P, I, P, I, I, I, P]),
     "cris_cast_f32_bf16": (I, [P, P, L, P]),
     "cris_cast_bf16_f32": (I, [P, P, L, I, P]),
+    "cris_cast_f32_bf16_drop": (I, [P, P, L, F, U, U, U, P]),
+    "cris_axpy_f32": (I, [P, P, F, L, P]),
+    "cris_quickgelu_fwd": (I, [P, P, L, P]),
+    "cris_quickgelu_bwd": (I, [P, P, P, L, P]),
     "cris_embed_fwd": (I, [P, P, P, I, I, I, P, P]),
     "cris_embed_bwd": (I, [P, P, I, I, I, P, P, P]),
     "cris_eot_gather": (I, [P, P, I, I, I, P, P, P]),

@@ -355,6 +355,23 @@ def cast_bf16_f32(x, y, accum=False):
     hip.call("cris_cast_bf16_f32", ptr(x), ptr(y), x.numel(), int(accum), _stream())
 
 
+def cast_f32_bf16_drop(x, y, drop: Drop):
+    hip.call("cris_cast_f32_bf16_drop", ptr(x), ptr(y), x.numel(), drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream,
+             _stream())
+
+
+def axpy_f32(dst, src, alpha=1.0):
+    hip.call("cris_axpy_f32", ptr(dst), ptr(src), float(alpha), dst.numel(), _stream())
+
+
+def quickgelu_fwd(x, y):
+    hip.call("cris_quickgelu_fwd", ptr(x), ptr(y), x.numel(), _stream())
+
+
+def quickgelu_bwd(x, dy, dx):
+    hip.call("cris_quickgelu_bwd", ptr(x), ptr(dy), ptr(dx), x.numel(), _stream())
+
+
 def embed_fwd(tokens, table, pos, out):
     Bn, L = tokens.shape
     hip.call("cris_embed_fwd", ptr(tokens), ptr(table), ptr(pos), Bn, L, table.shape[1], ptr(out), _stream())

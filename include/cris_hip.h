@@ -240,6 +240,13 @@ int cris_add_rowtable(const cris_bf16* a, int lda, const float* table, int trows
                       int C, void* stream);
 int cris_cast_f32_bf16(const float* x, cris_bf16* y, long n, void* stream);
 int cris_cast_bf16_f32(const cris_bf16* x, float* y, long n, int accum, void* stream);
+/* y = bf16(dropout(x)) over a flat fp32 tensor (gradient of nn.Dropout on the residual branches, model/layers.py:217-219) */
+int cris_cast_f32_bf16_drop(const float* x, cris_bf16* y, long n, float drop_p, uint32_t drop_thresh, uint32_t seed,
+                            uint32_t stream_id, void* stream);
+int cris_axpy_f32(float* dst, const float* src, float alpha, long n, void* stream);
+/* QuickGELU x*sigmoid(1.702x) on a stored bf16 pre-activation (model/clip.py:234-236) */
+int cris_quickgelu_fwd(const cris_bf16* x, cris_bf16* y, long n, void* stream);
+int cris_quickgelu_bwd(const cris_bf16* x, const cris_bf16* dy, cris_bf16* dx, long n, void* stream);
 /* token embedding + positional embedding (model/clip.py:440-443) and its backward (embedding_dense_backward) */
 int cris_embed_fwd(const int64_t* tokens, const float* table, const float* pos, int Bn, int L, int D, float* out,
                    void* stream);

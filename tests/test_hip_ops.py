@@ -424,8 +424,10 @@ def test_attention_fwd_bwd(case):
     seed, stream = 4321, 2
     Lkp, Lqp = ops.pad32(Lk), ops.pad32(Lq)
     qd, kd, vd = bf(q), bf(k), bf(v)
-    prm = ops.attn_params(qd, kd, vd, _head_T(vd, B, Lk, Hn, Lkp), B, Hn, Lq, Lk, Lkp, scale, Kt=_head_T(kd, B, Lk, Hn, Lkp),
-                          Qt=_head_T(qd, B, Lq, Hn, Lqp), Lq_pad=Lqp, key_tokens=None if toks is None else toks.to(DEV),
+    # the params struct holds raw pointers: keep every operand alive until the launches are done
+    vt, kt, qt = _head_T(vd, B, Lk, Hn, Lkp), _head_T(kd, B, Lk, Hn, Lkp), _head_T(qd, B, Lq, Hn, Lqp)
+    toks_d = None if toks is None else toks.to(DEV)
+    prm = ops.attn_params(qd, kd, vd, vt, B, Hn, Lq, Lk, Lkp, scale, Kt=kt, Qt=qt, Lq_pad=Lqp, key_tokens=toks_d,
                           causal=causal, drop=Drop(p, seed, stream))
     O = torch.empty(B * Lq, E, dtype=BF, device=DEV)
     lse = torch.empty(B * Hn, Lq, device=DEV)
@@ -454,7 +456,9 @@ def test_attention_fwd_bwd(case):
     dK = torch.empty_like(kd)
     dV = torch.empty_like(vd)
     delta = torch.empty(B * Hn, Lq, device=DEV)
-    ops.attn_bwd(prm, O, lse, dod, _head_T(dod, B, Lq, Hn, Lqp), delta, dQ, dK, dV)
+    dot = _head_T(dod, B, Lq, Hn, Lqp)
+    ops.attn_bwd(prm, O, lse, dod, dot, delta, dQ, dK, dV)
+    torch.cuda.synchronize()
     check(dV, vl.grad, 1.5e-2, "dV")
     check(dQ, ql.grad, 1.5e-2, "dQ")
     check(dK, kl.grad, 1.5e-2, "dK")
@@ -624,6 +628,31 @@ def test_loss_mask_metric():
     ious = (o & tt).sum(1) / ((o | tt).sum(1) + 1e-6)
     assert abs(float(met[0]) - float(100 * ious.mean())) < 1e-3
     assert abs(float(met[1]) - float(100 * (ious > 0.5).float().mean())) < 1e-3
+
+
+def test_quickgelu_castdrop_axpy():
+    x = (rnd(40, 64) * 2).to(BF).float()
+    y = torch.empty(40, 64, dtype=BF, device=DEV)
+    ops.quickgelu_fwd(bf(x), y)
+    xl = x.clone().requires_grad_(True)
+    ref = xl * torch.sigmoid(1.702 * xl)
+    check(y, ref, 4e-3, "quickgelu")
+    g = rnd(40, 64, seed=1).to(BF).float()
+    (ref * g).sum().backward()
+    dx = torch.empty(40, 64, dtype=BF, device=DEV)
+    ops.quickgelu_bwd(bf(x), bf(g), dx)
+    check(dx, xl.grad, 5e-3, "quickgelu bwd")
+    f = rnd(50, 32, seed=2)
+    o = torch.empty(50, 32, dtype=BF, device=DEV)
+    ops.cast_f32_bf16_drop(f.to(DEV), o, Drop(0.1, 99, 5))
+    km = keep_mask(99, 5, (50, 32), 0.1).cpu()
+    assert torch.equal(o.cpu(), (f * km / (1 - 0.1)).to(BF)) or relerr(o, f * km / 0.9) < 4e-3
+    assert bool(((o.cpu().float() == 0) | km).all()) and bool(((o.cpu().float() != 0) | ~km | (f == 0)).all())
+    a = rnd(1000, seed=3).to(DEV)
+    b = rnd(1000, seed=4).to(DEV)
+    ref2 = a + 0.5 * b
+    ops.axpy_f32(a, b, 0.5)
+    check(a, ref2, 1e-6)
 
 
 def test_adam_matches_torch():
