@@ -166,12 +166,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     const uint32_t dthr = p.drop_thresh;
     const float dscale = has_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const int Hh = p.outT ? p.T_E / 64 : 1;
+    const int part = tile_m * WAVES_M + wm;                  // statistics partial index (one per wave row-block)
+    const int part_row0 = m0 + wm * WTM;
+    const int part_cnt = max(0, min(WTM, p.M - part_row0));
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int col = n0 + wn * WTN + j * 16 + fr;
         const bool cvalid = col < p.N;
         const float bias = (p.bias && cvalid) ? p.bias[col] : 0.f;
-        float csum = 0.f, csq = 0.f;
+        float vals[FM][4];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int rowb = m0 + wm * WTM + i * 16 + fg * 4;
@@ -191,8 +194,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
                 }
                 if (!valid) x = 0.f;
                 v[r] = x;
-                csum += x;
-                csq += x * x;
+                vals[i][r] = x;
                 if (valid && p.out) {
                     const size_t oo = (size_t)m * p.ldc + p.c_coff + col;
                     if (p.out_f32) reinterpret_cast<float*>(p.out)[oo] = x;
@@ -223,17 +225,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
             }
         }
         if (p.colsum) {
-            csum += __shfl_xor(csum, 16, 64);
-            csum += __shfl_xor(csum, 32, 64);
-            csq += __shfl_xor(csq, 16, 64);
-            csq += __shfl_xor(csq, 32, 64);
+            // BatchNorm statistics, robust + deterministic: per wave row-block (sum, M2 about the block mean);
+            // cris_bn_finalize merges the blocks with Chan's formula.  No atomics, no E[x^2]-E[x]^2 cancellation.
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s1 += vals[i][r];                 // invalid rows hold 0
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mu = part_cnt > 0 ? s1 / (float)part_cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * WTM + i * 16 + fg * 4 + r;
+                    const float d = vals[i][r] - mu;
+                    q += (m < p.M) ? d * d : 0.f;
+                }
+            q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
             if (fg == 0 && cvalid) {
-                atomicAdd(p.colsum + col, csum);
-                atomicAdd(p.colsq + col, csq);
+                p.colsum[(size_t)part * p.N + col] = s1;
+                p.colsq[(size_t)part * p.N + col] = q;
             }
         }
     }
 }
+
+extern "C" int cris_conv_gemm_stat_rows(int N) { return N <= 64 ? BM / 4 : BM / 2; }
 
 extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     const cris_conv_gemm_params& p = *pp;

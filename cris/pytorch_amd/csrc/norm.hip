@@ -7,14 +7,38 @@
 // ------------------------------------------------------------------------------------------------
 // BN coefficients
 // ------------------------------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const float* sum, const float* sumsq, float count, const float* gamma,
-                                   const float* beta, float* rmean, float* rvar, float momentum, float eps, int C,
-                                   float* scale, float* shift, float* mean_o, float* invstd_o) {
+__global__ void bn_finalize_kernel(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
+                                   float count, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                   float momentum, float eps, int C, float* scale, float* shift, float* mean_o,
+                                   float* invstd_o, float* merged /* optional [2*C]: local (sum, M2) for SyncBN */,
+                                   const float* global_stats /* optional [2*C]: (sum, M2 about the global mean) */) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float mean = sum[c] / count;
-    float var = sumsq[c] / count - mean * mean;
-    var = fmaxf(var, 0.f);
+    float mean, m2;
+    if (global_stats) {
+        mean = global_stats[c] / count;
+        m2 = global_stats[C + c];
+    } else {
+        // merge per-block partials (Chan et al.): M2 = sum M2_i + n_i (mean_i - mean)^2
+        float tot = 0.f;
+        for (int i = 0; i < nparts; ++i) tot += psum[(size_t)i * C + c];
+        mean = tot / count_local;
+        m2 = 0.f;
+        const int M = (int)count_local;
+        for (int i = 0; i < nparts; ++i) {
+            const int n = min(rows_per_part, M - i * rows_per_part);
+            if (n <= 0) break;
+            const float d = psum[(size_t)i * C + c] / (float)n - mean;
+            m2 += pm2[(size_t)i * C + c] + (float)n * d * d;
+        }
+        if (merged) {                       // hand the local (sum, M2) to the SyncBN exchange; finalize runs again after it
+            merged[c] = tot;
+            merged[C + c] = m2;
+            mean_o[c] = mean;               // local mean, needed to re-centre M2 about the global mean
+            return;
+        }
+    }
+    const float var = fmaxf(m2 / count, 0.f);
     const float inv = rsqrtf(var + eps);
     const float sc = gamma[c] * inv;
     scale[c] = sc;
@@ -28,12 +52,67 @@ __global__ void bn_finalize_kernel(const float* sum, const float* sumsq, float c
     }
 }
 
-extern "C" int cris_bn_finalize(const float* sum, const float* sumsq, float count, const float* gamma,
-                                const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                                int C, float* scale, float* shift, float* mean, float* invstd, void* stream) {
-    CRIS_CHECK_ARG(sum && sumsq && gamma && beta && scale && shift && mean && invstd && C > 0 && count > 0.f, "bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sum, sumsq, count,
-                       gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd);
+extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
+                                float count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float momentum, float eps, int C, float* scale, float* shift, float* mean, float* invstd,
+                                float* merged, const float* global_stats, void* stream) {
+    CRIS_CHECK_ARG((global_stats || (psum && pm2 && nparts > 0 && rows_per_part > 0)) && gamma && beta && mean && C > 0 && count > 0.f, "bad args");
+    CRIS_CHECK_ARG(merged || (scale && shift && invstd), "bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
+                       count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
+                       merged, global_stats);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// re-centre a rank-local M2 about the global mean: m2[c] += n_local * (mean_local[c] - gsum[c]/count_global)^2
+__global__ void bn_recentre_kernel(float* m2, const float* mean_local, const float* gsum, float n_local, float count_global, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float d = mean_local[c] - gsum[c] / count_global;
+    m2[c] += n_local * d * d;
+}
+extern "C" int cris_bn_recentre(float* m2, const float* mean_local, const float* gsum, float n_local, float count_global, int C,
+                                void* stream) {
+    CRIS_CHECK_ARG(m2 && mean_local && gsum && C > 0, "bad args");
+    hipLaunchKernelGGL(bn_recentre_kernel, dim3(cris_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, m2, mean_local, gsum, n_local,
+                       count_global, C);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// per-row-block column statistics of a bf16 matrix in the same partial format as the GEMM epilogue
+__global__ void colstats_kernel(const bf16_t* x, int ldx, int coff, int M, int C, int rows_per_part, float* psum, float* pm2) {
+    const int cv = blockIdx.x * blockDim.x + threadIdx.x;
+    const int part = blockIdx.y;
+    if (cv >= (C >> 3)) return;
+    const int r0 = part * rows_per_part, r1 = min(M, r0 + rows_per_part);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0}, q[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8];
+    for (int m = r0; m < r1; ++m) {
+        unpack8(*reinterpret_cast<const uint4*>(x + (size_t)m * ldx + coff + cv * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+    const float inv = 1.f / (float)(r1 - r0);
+    for (int m = r0; m < r1; ++m) {
+        unpack8(*reinterpret_cast<const uint4*>(x + (size_t)m * ldx + coff + cv * 8), v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d = v[j] - s[j] * inv;
+            q[j] += d * d;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        psum[(size_t)part * C + cv * 8 + j] = s[j];
+        pm2[(size_t)part * C + cv * 8 + j] = q[j];
+    }
+}
+extern "C" int cris_colstats_bf16(const cris_bf16* x, int ldx, int coff, int M, int C, int rows_per_part, float* psum, float* pm2,
+                                  void* stream) {
+    CRIS_CHECK_ARG(x && psum && pm2 && M > 0 && !(C & 7) && !(ldx & 7) && !(coff & 7) && rows_per_part > 0, "bad args");
+    dim3 grid(cris_cdiv(C / 8, 64), cris_cdiv(M, rows_per_part));
+    hipLaunchKernelGGL(colstats_kernel, grid, dim3(64), 0, (hipStream_t)stream, x, ldx, coff, M, C, rows_per_part, psum, pm2);
     CRIS_LAUNCH_CHECK();
     return 0;
 }
@@ -70,14 +149,9 @@ __device__ __forceinline__ void load8bf(const bf16_t* p, float* f) {
 }
 
 __global__ __launch_bounds__(256) void bn_apply_kernel(const cris_bn_apply_params p) {
-    extern __shared__ float sstat[];                 // [2*C] when osum
     const int CV = p.C >> 3;
     const int OH = p.pool ? p.H / 2 : p.H, OW = p.pool ? p.W / 2 : p.W;
     const long total = (long)p.Bn * OH * OW * CV;
-    if (p.osum) {
-        for (int i = threadIdx.x; i < 2 * p.C; i += blockDim.x) sstat[i] = 0.f;
-        __syncthreads();
-    }
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(idx % CV);
         const int mo = (int)(idx / CV);
@@ -138,24 +212,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const cris_bn_apply_param
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
         }
-        const uint4 packed = pack8(o);
-        *reinterpret_cast<uint4*>(p.z + (size_t)mo * p.ldz + p.z_coff + c0) = packed;
-        if (p.osum) {
-            float q[8];
-            unpack8(packed, q);                     // statistics of what the next layer actually reads
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                atomicAdd(&sstat[c0 + j], q[j]);
-                atomicAdd(&sstat[p.C + c0 + j], q[j] * q[j]);
-            }
-        }
-    }
-    if (p.osum) {
-        __syncthreads();
-        for (int i = threadIdx.x; i < p.C; i += blockDim.x) {
-            atomicAdd(p.osum + i, sstat[i]);
-            atomicAdd(p.osq + i, sstat[p.C + i]);
-        }
+        *reinterpret_cast<uint4*>(p.z + (size_t)mo * p.ldz + p.z_coff + c0) = pack8(o);
     }
 }
 
@@ -167,13 +224,9 @@ extern "C" int cris_bn_apply(const cris_bn_apply_params* pp, void* stream) {
     CRIS_CHECK_ARG(!p.pool || (!(p.H & 1) && !(p.W & 1) && !p.y2 && !p.ident && !p.mul), "pool needs even H,W and a plain BN");
     CRIS_CHECK_ARG(!p.y2 || ((p.ldy2 & 7) == 0 && (p.y2_coff & 7) == 0 && p.scale2 && p.shift2), "branch 2");
     CRIS_CHECK_ARG(!p.ident || ((p.ldi & 7) == 0 && (p.i_coff & 7) == 0), "identity ld/offset");
-    CRIS_CHECK_ARG(!p.osum || (p.osq && p.C <= 4096), "output statistics");
     const long rows = (long)p.Bn * (p.pool ? (p.H / 2) * (p.W / 2) : p.H * p.W);
     const long total = rows * (p.C >> 3);
-    const int cap = p.osum ? 512 : 8192;
-    const int grid = cris_grid_1d(total, 256, cap);
-    const size_t shm = p.osum ? (size_t)2 * p.C * sizeof(float) : 0;
-    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid), dim3(256), shm, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -53,7 +53,6 @@ class BnApplyParams(C.Structure):
                 ("scale2", P), ("shift2", P),
                 ("ident", P), ("ldi", I), ("i_coff", I),
                 ("mul", P),
-                ("osum", P), ("osq", P),
                 ("z", P), ("ldz", I), ("z_coff", I),
                 ("Bn", I), ("H", I), ("W", I), ("C", I),
                 ("relu", I), ("pool", I)]
@@ -149,7 +148,10 @@ _SIGS = {
     "cris_pack_blocks": (I, [P]),
     "cris_pack_block_elems": (I, []),
     "cris_colsum_bf16": (I, [P, I, I, I, I, P, P]),
-    "cris_bn_finalize": (I, [P, P, F, P, P, P, P, F, F, I, P, P, P, P, P]),
+    "cris_conv_gemm_stat_rows": (I, [I]),
+    "cris_bn_finalize": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P, P]),
+    "cris_bn_recentre": (I, [P, P, P, F, F, I, P]),
+    "cris_colstats_bf16": (I, [P, I, I, I, I, I, P, P, P]),
     "cris_bn_eval_coeffs": (I, [P, P, P, P, F, I, P, P, P]),
     "cris_bn_apply": (I, [P, P]),
     "cris_bn_bwd_reduce": (I, [P, P]),

@@ -188,9 +188,35 @@ def colsum(x, M, N, out, ldx=None, coff=0):
 
 
 # ---- BatchNorm ---------------------------------------------------------------------------------
-def bn_finalize(sum_, sumsq, count, gamma, beta, rmean, rvar, momentum, eps, C_, scale, shift, mean, invstd):
-    hip.call("cris_bn_finalize", ptr(sum_), ptr(sumsq), float(count), ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar),
-             float(momentum), float(eps), C_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), _stream())
+def stat_rows(N: int) -> int:
+    """rows per statistics partial written by conv_gemm for an N-column output"""
+    return 32 if N <= 64 else 64
+
+
+def stat_parts(M: int, N: int) -> int:
+    return ((M + 127) // 128) * (128 // stat_rows(N))
+
+
+def new_stats(M: int, N: int, device):
+    """partials buffer [2][nparts][N] (sum, M2) for conv_gemm(colsum=st[0], colsq=st[1])"""
+    return torch.zeros(2, stat_parts(M, N), N, dtype=torch.float32, device=device)
+
+
+def bn_finalize(st, rows_per_part, count_local, count, gamma, beta, rmean, rvar, momentum, eps, C_, scale, shift, mean, invstd,
+                merged=None, global_stats=None):
+    hip.call("cris_bn_finalize", ptr(st[0]) if st is not None else None, ptr(st[1]) if st is not None else None,
+             st.shape[1] if st is not None else 0, rows_per_part, float(count_local), float(count), ptr(gamma), ptr(beta),
+             ptr(rmean), ptr(rvar), float(momentum), float(eps), C_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(merged),
+             ptr(global_stats), _stream())
+
+
+def bn_recentre(m2, mean_local, gsum, n_local, count_global, C_):
+    hip.call("cris_bn_recentre", ptr(m2), ptr(mean_local), ptr(gsum), float(n_local), float(count_global), C_, _stream())
+
+
+def colstats(x, M, C_, rows_per_part, st, ldx=None, coff=0):
+    hip.call("cris_colstats_bf16", ptr(x), ldx if ldx is not None else x.shape[-1], coff, M, C_, rows_per_part, ptr(st[0]),
+             ptr(st[1]), _stream())
 
 
 def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, C_, scale, shift):
@@ -199,7 +225,7 @@ def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, C_, scale, shift):
 
 
 def bn_apply(y, scale, shift, z, Bn, H, W, C_, *, ldy=None, y_coff=0, ldz=None, z_coff=0, relu=True, pool=False, y2=None,
-             ldy2=None, y2_coff=0, scale2=None, shift2=None, ident=None, ldi=None, i_coff=0, mul=None, osum=None, osq=None):
+             ldy2=None, y2_coff=0, scale2=None, shift2=None, ident=None, ldi=None, i_coff=0, mul=None):
     p = hip.BnApplyParams()
     p.y, p.ldy, p.y_coff = ptr(y), ldy if ldy is not None else y.shape[-1], y_coff
     p.scale, p.shift = ptr(scale), ptr(shift)
@@ -208,7 +234,7 @@ def bn_apply(y, scale, shift, z, Bn, H, W, C_, *, ldy=None, y_coff=0, ldz=None, 
         p.scale2, p.shift2 = ptr(scale2), ptr(shift2)
     if ident is not None:
         p.ident, p.ldi, p.i_coff = ptr(ident), ldi if ldi is not None else ident.shape[-1], i_coff
-    p.mul, p.osum, p.osq = ptr(mul), ptr(osum), ptr(osq)
+    p.mul = ptr(mul)
     p.z, p.ldz, p.z_coff = ptr(z), ldz if ldz is not None else z.shape[-1], z_coff
     p.Bn, p.H, p.W, p.C = Bn, H, W, C_
     p.relu, p.pool = int(relu), int(pool)

@@ -45,8 +45,9 @@ typedef struct {
     const void* resid;       /* [M][ldr] (+r_coff) added after activation/dropout, bf16 or fp32; or NULL */
     void* out;               /* [M][ldc] (+c_coff) bf16 or fp32; or NULL */
     cris_bf16* outT;         /* optional head-split transposed copy, see T_* ; or NULL */
-    float* colsum;           /* optional per-column sum / sum of squares accumulators (BatchNorm statistics) */
-    float* colsq;
+    float* colsum;           /* optional BatchNorm statistics partials [nparts][N]: per row-block column sums ...  */
+    float* colsq;            /* ... and sums of squared deviations from the block mean; nparts = ceil(M/128) * 128 /
+                                cris_conv_gemm_stat_rows(N) blocks of cris_conv_gemm_stat_rows(N) rows (deterministic, no atomics) */
     long T_sec_stride;       /* elements between consecutive T_E-wide column sections in outT */
     int lda, a_coff;
     int Bn, H, W, C;
@@ -62,6 +63,7 @@ typedef struct {
     uint32_t drop_seed, drop_stream;
 } cris_conv_gemm_params;
 int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
+int cris_conv_gemm_stat_rows(int N);
 
 /* Weight gradient: dW[n, c, tap] += sum_m dY[m, n] * X_im2col[m, tap*C + c]   (fp32 atomics, split over m).
  * Replaces convolution_backward(weight) / addmm backward for every Conv2d / Linear above. */
@@ -101,11 +103,19 @@ int cris_colsum_bf16(const cris_bf16* x, int ldx, int coff, int M, int N, float*
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm (training statistics), replaces native_batch_norm / its backward
  * (reference: every nn.BatchNorm2d/1d, model/clip.py:18-41,78,173-183; model/layers.py:11,16,262).
- * Statistics (sum, sum of squares) are produced by the conv GEMM epilogue (colsum/colsq).
+ * Statistics arrive as per-row-block partials (column sum, M2 about the block mean) from the conv GEMM
+ * epilogue or cris_colstats_bf16 and are merged with Chan's parallel-variance formula.
+ * SyncBN: call once with `merged` (local sum / M2 / mean out), all-reduce the sums, cris_bn_recentre the M2,
+ * all-reduce the M2, then call again with `global_stats`.
  * ---------------------------------------------------------------------------------------------- */
-int cris_bn_finalize(const float* sum, const float* sumsq, float count, const float* gamma, const float* beta,
-                     float* running_mean, float* running_var, float momentum, float eps, int C,
-                     float* scale, float* shift, float* mean, float* invstd, void* stream);
+int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local, float count,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                     float eps, int C, float* scale, float* shift, float* mean, float* invstd, float* merged,
+                     const float* global_stats, void* stream);
+int cris_bn_recentre(float* m2, const float* mean_local, const float* gsum, float n_local, float count_global, int C,
+                     void* stream);
+int cris_colstats_bf16(const cris_bf16* x, int ldx, int coff, int M, int C, int rows_per_part, float* psum, float* pm2,
+                       void* stream);
 /* eval mode: scale/shift from the running statistics */
 int cris_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                         float eps, int C, float* scale, float* shift, void* stream);
@@ -117,7 +127,6 @@ typedef struct {
     const float* scale2; const float* shift2;
     const cris_bf16* ident; int ldi, i_coff;         /* optional identity added before the ReLU, or NULL */
     const float* mul;                                /* optional [Bn][C] multiplier applied after the ReLU */
-    float* osum; float* osq;                         /* optional statistics of the output (for a following BN) */
     cris_bf16* z;        int ldz, z_coff;            /* output */
     int Bn, H, W, C;                                 /* input geometry, M = Bn*H*W rows */
     int relu;

@@ -102,14 +102,20 @@ def test_conv_gemm_epilogues():
     ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=1, resid=bf(resbf), out=wide, ldc=N + 64, c_coff=64)
     check(wide[:, 64:], torch.relu(base) + resbf, 6e-3, "relu+resid bf16 slice")
     assert float(wide[:, :64].float().abs().max()) == 0.0
-    # column statistics
-    cs = torch.zeros(N, device=DEV)
-    cq = torch.zeros(N, device=DEV)
+    # BatchNorm statistics partials: per 64-row block (sum, M2 about the block mean), merged by bn_finalize
+    st = ops.new_stats(M, N, DEV)
     out2 = torch.empty(M, N, dtype=BF, device=DEV)
-    ops.conv_gemm(bf(x), bf(w), g, N, out=out2, colsum=cs, colsq=cq)
-    y = x @ w.t()
-    check(cs, y.sum(0), 3e-3, "colsum")
-    check(cq, (y * y).sum(0), 3e-3, "colsq")
+    ops.conv_gemm(bf(x), bf(w + 0.05), g, N, out=out2, colsum=st[0], colsq=st[1])
+    y = x @ (w + 0.05).to(BF).float().t()
+    rows = ops.stat_rows(N)
+    for part in range((M + rows - 1) // rows):
+        blk = y[part * rows:(part + 1) * rows]
+        check(st[0][part], blk.sum(0), 3e-3, "part sum")
+        check(st[1][part], ((blk - blk.mean(0)) ** 2).sum(0), 5e-3, "part M2")
+    outs = [torch.empty(N, device=DEV) for _ in range(4)]
+    ops.bn_finalize(st, rows, M, M, torch.ones(N, device=DEV), torch.zeros(N, device=DEV), None, None, 0.1, 1e-5, N, *outs)
+    check(outs[2], y.mean(0), 3e-3, "mean from partials")
+    check(outs[3], torch.rsqrt(y.var(0, unbiased=False) + 1e-5), 3e-3, "invstd from partials")
     # dropout (mask is an index op: exact), then residual
     p, seed, stream = 0.1, 1234, 7
     out3 = torch.empty(M, N, dtype=torch.float32, device=DEV)
@@ -209,6 +215,19 @@ def test_dgrad_via_packed_weights():
     check(dx, x.grad.permute(0, 2, 3, 1).reshape(-1, C_), 6e-3, "dgrad")
 
 
+def test_bn_stats_robust_to_large_mean():
+    """|mean| >> std: E[x^2]-E[x]^2 in fp32 would lose the variance; the block-centred partials do not."""
+    M, C_ = 4000, 16
+    y = (rnd(M, C_) * 0.01 + 100.0).to(BF).float()         # bf16 grid near 100 has spacing 0.5: values are 99.5/100/100.5
+    y = y + 0.0
+    st = torch.zeros(2, (M + 31) // 32, C_, device=DEV)
+    ops.colstats(bf(y), M, C_, 32, st)
+    outs = [torch.empty(C_, device=DEV) for _ in range(4)]
+    ops.bn_finalize(st, 32, M, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs)
+    check(outs[2], y.double().mean(0), 1e-6, "mean")
+    check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), 1e-4, "invstd")
+
+
 def test_colsum():
     x = rnd(1000, 72).to(BF).float()
     out = torch.zeros(72, device=DEV)
@@ -229,10 +248,10 @@ def _bn_setup(B, H, W, C_, seed=0):
 def _bn_coeffs(y2d, gamma, beta, rm=None, rv=None):
     C_ = y2d.shape[1]
     M = y2d.shape[0]
-    s = y2d.sum(0).to(DEV)
-    q = (y2d * y2d).sum(0).to(DEV)
+    st = torch.zeros(2, (M + 31) // 32, C_, device=DEV)
+    ops.colstats(bf(y2d), M, C_, 32, st)
     outs = [torch.empty(C_, device=DEV) for _ in range(4)]
-    ops.bn_finalize(s, q, M, gamma.to(DEV), beta.to(DEV), rm, rv, 0.1, 1e-5, C_, *outs)
+    ops.bn_finalize(st, 32, M, M, gamma.to(DEV), beta.to(DEV), rm, rv, 0.1, 1e-5, C_, *outs)
     return outs
 
 
@@ -294,16 +313,8 @@ def test_bn_apply_and_backward(variant):
         kw.update(mul=mul.to(DEV))
     OHo, OWo = (H // 2, W // 2) if variant == "pool" else (H, W)
     z = torch.empty(B * OHo * OWo, C_, dtype=BF, device=DEV)
-    osum = torch.zeros(C_, device=DEV)
-    osq = torch.zeros(C_, device=DEV)
-    if variant == "mul":
-        kw.update(osum=osum, osq=osq)
     ops.bn_apply(bf(y), scale, shift, z, B, H, W, C_, relu=True, **kw)
     check(z, ref.reshape(-1, C_), 6e-3, "bn_apply " + variant)
-    if variant == "mul":
-        zz = z.float().cpu()
-        check(osum, zz.sum(0), 1e-4, "osum")
-        check(osq, (zz * zz).sum(0), 1e-4, "osq")
 
     # backward
     dz = rnd(B, OHo, OWo, C_, seed=30).to(BF).float()
