@@ -1,0 +1,145 @@
+#!/usr/bin/env python
+"""CRIS-R50 train-step throughput on MI355X (BASELINE.json metric: train-step samples/sec, CRIS-R50 416x416).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One step = the whole hot path on one synthetic RefCOCO-shaped batch already resident in HBM: weight repack, forward,
+BCE loss, backward, (N > 1: SyncBN exchanges + overlapped gradient all-reduce over RCCL), fused Adam, train metric.
+Per-GPU batch is fixed at 8 (global 8*N): weak scaling, the reference's own recipe (global 64 on 8 GPUs).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FLOP_PER_SAMPLE = 395.0e9          # fwd+bwd, contractions only, R50/416/L17 (SURVEY.md 8d / BASELINE.md 2)
+ALG_BYTES_PER_SAMPLE = 0.98e9      # bf16 contraction operands+outputs under perfect fusion
+ADAM_BYTES_PER_STEP = 4.11e9
+MFMA_PEAK = 2500.0                 # TFLOP/s dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK = 8000.0                  # GB/s spec
+
+
+def cpu_baseline(spec, batch, size, word_len, threads):
+    """The oracle (fp32 CPU restatement of the reference forward/loss + autograd backward) timed on the host cores:
+    one train forward+backward at the bench batch.  A reported baseline, not the optimisation target."""
+    from cris.pytorch_amd import arch, synth
+    from oracle import cris_oracle as O
+    clip, head = arch.specs_by_name(spec)
+    sd = arch.synthetic_state_dict(clip, head, 0)
+    img, word, mask = synth.make_batch(batch, size, word_len, 0, 0)
+    torch.set_num_threads(threads)
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    t0 = time.time()
+    _, _, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=1)
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": batch / dt, "unit": "samples/s", "cores": threads, "kind": "port",
+            "sample": "1 train step (fwd+loss+bwd, fp32, no optimizer) of the CPU oracle at batch %d, %dx%d, L=%d: %.1f s"
+                      % (batch, size, size, word_len, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--spec", default="r50")
+    ap.add_argument("--size", type=int, default=416)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    comm = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        from cris.pytorch_amd.dist import TorchDistComm
+        comm = TorchDistComm(dev)
+
+    import __graft_entry__ as g
+    g.build()
+    from cris.pytorch_amd import arch, synth, ops
+    from cris.pytorch_amd.trainer import NativeTrainer
+
+    clip, head = arch.specs_by_name(args.spec)
+    sd = arch.synthetic_state_dict(clip, head, 0)
+    tr = NativeTrainer(clip, head, sd, dev, comm=comm, sync_bn=world > 1)
+    del sd
+    nb = 4
+    batches = [tuple(t.to(dev) for t in synth.make_batch(args.batch, args.size, head.word_len, rank, s)) for s in range(nb)]
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tr.train_step(*batches[i % nb])
+    sync()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = ops.KernelTimer()
+        ops.KERNEL_TIMER = timer
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss, _ = tr.train_step(*batches[i % nb])
+    sync()
+    dt = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    loss_v = float(loss)
+
+    if rank == 0:
+        sps = world * args.batch * args.steps / dt
+        steps_s = args.steps / dt
+        out = {
+            "metric": "train-step samples/sec, CRIS-R50 416x416 bs=64; loss parity vs ref",
+            "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "CRIS-%s bf16 training step (fwd+BCE+bwd+Adam), %dx%d, per-GPU bs=%d, 17-token text, "
+                                   "synthetic RefCOCO-shape batch resident in HBM (BASELINE.json configs[1]%s)"
+                                   % (args.spec.upper(), args.size, args.size, args.batch,
+                                      "" if world == 1 else "; x%d GPUs = configs[2] recipe: SyncBN + gradient all-reduce over RCCL" % world),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": loss_v},
+            "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12),
+                              "hbm_frac_alg": (sps / world * ALG_BYTES_PER_SAMPLE + steps_s * ADAM_BYTES_PER_STEP) / (HBM_PEAK * 1e9)},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            dom = max(summ, key=lambda k: summ[k]["ms"])
+            d = summ[dom]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": ach, "peak": MFMA_PEAK, "unit": "TFLOP/s",
+                               "frac": ach / MFMA_PEAK, "traffic": None,
+                               "launches_per_step": d["launches"] / args.steps, "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
+                               "share_of_step": d["ms"] / (1000.0 * dt)}
+            out["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
+                                  "launches_per_step": v["launches"] / args.steps} for k, v in summ.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.spec, args.batch, args.size, head.word_len, min(os.cpu_count() or 1, 64))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""Data parallelism for the native engine: one process per GPU, torch.distributed ("nccl" == RCCL on ROCm,
+over xGMI), mirroring the reference's DDP + SyncBatchNorm semantics (train.py:80-102):
+
+  * SyncBN: per BatchNorm layer the (sum, M2) statistics are all-reduced in forward and (sum g, sum g*xhat) in
+    backward (engine.Engine uses `allreduce_sum` for both) - N-GPU training equals 1-GPU training on the
+    concatenated batch;
+  * gradients: the flat fp32 gradient arena is laid out in forward-compute order, so backward completes it from
+    its end; each finished stage (proj, decoder, neck, text, visual) is all-reduced as ONE large message on a side
+    HIP stream while the earlier stages' backward still runs (xGMI is point-to-point and per-link bound: few big
+    messages, not DDP's 25 MB buckets); Adam applies the 1/world averaging through its grad_scale.
+The path shards by sample only; there is no other data-path collective.
+"""
+import torch
+import torch.distributed as dist
+
+
+class TorchDistComm:
+    def __init__(self, device=None):
+        assert dist.is_initialized()
+        self.world = dist.get_world_size()
+        self.rank = dist.get_rank()
+        self.device = device
+        self.side = torch.cuda.Stream(device=device) if (device is not None and torch.device(device).type == "cuda") else None
+        self._pending = []
+
+    # SyncBN exchanges run inline on the compute stream (they sit on the critical path by construction)
+    def allreduce_sum(self, t):
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    # gradient exchange: overlapped
+    def allreduce_async(self, t):
+        if self.side is None:
+            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait_all(self):
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if self.side is not None:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+
+def merge_batchnorm_partials(sum_l, m2_l, n_l, comm):
+    """Reference arithmetic of the SyncBN forward exchange on plain tensors (used by the CPU/gloo tests):
+    local (sum, M2 about the local mean, count) -> global (mean, biased var)."""
+    gsum = sum_l.clone()
+    comm.allreduce_sum(gsum)
+    n_g = n_l * comm.world
+    mean_g = gsum / n_g
+    m2 = m2_l + n_l * (sum_l / n_l - mean_g) ** 2
+    comm.allreduce_sum(m2)
+    return mean_g, m2 / n_g

@@ -101,22 +101,37 @@ class Engine:
         tree = build_param_tree(self.clip, self.head)
         bn_prefixes = [n for n, m in tree.named_modules() if isinstance(m, nn.modules.batchnorm._BatchNorm)]
         self.bn_prefixes = bn_prefixes
-        order, seen = [], set()
         pairs = {}
         for n, m in tree.named_modules():
             if m.__class__.__name__ == "BottleneckP" and m.downsample is not None:
                 pairs[n + ".bn3"] = n + ".downsample.1"
         paired_second = set(pairs.values())
-        for pfx in bn_prefixes:
-            if pfx in paired_second:
+        bn_set = set(bn_prefixes)
+        # forward-compute order (visual, text, neck, decoder, proj) so that backward completes the arena from its
+        # end towards its start and contiguous suffixes can be all-reduced while earlier layers still run
+        def stage(name):
+            if name.startswith("backbone.visual."):
+                return 0
+            if name.startswith("backbone."):
+                return 1
+            return {"neck": 2, "decoder": 3, "proj": 4}[name.split(".")[0]]
+        names = sorted(self.P.keys(), key=lambda k: stage(k))          # stable: keeps module order inside a stage
+        order, seen = [], set()
+        for name in names:
+            if name in seen:
                 continue
-            group = [pfx] + ([pairs[pfx]] if pfx in pairs else [])
-            for g in group:
-                order += [g + ".bias", g + ".weight"]
-                seen.update((g + ".bias", g + ".weight"))
-        for name in self.P:
-            if name not in seen:
+            pfx = name.rsplit(".", 1)[0]
+            if pfx in bn_set:
+                if pfx in paired_second:
+                    continue                                           # emitted together with its bn3 partner
+                for g in [pfx] + ([pairs[pfx]] if pfx in pairs else []):
+                    order += [g + ".bias", g + ".weight"]
+                    seen.update((g + ".bias", g + ".weight"))
+            else:
                 order.append(name)
+                seen.add(name)
+        assert set(order) == set(self.P.keys())
+        self.stage_of = stage
         total, offs = 0, {}
         for name in order:
             n = self.P[name].numel()
@@ -125,7 +140,15 @@ class Engine:
         self.grad_arena = torch.zeros(total, dtype=F32, device=self.dev)
         self.G = {name: self.grad_arena[o:o + self.P[name].numel()].view(self.P[name].shape) for name, o in offs.items()}
         self.grad_order = order
+        self.grad_offsets = offs
         self.bn_pairs = pairs
+        # arena [start, end) of each stage (0 visual, 1 text, 2 neck, 3 decoder, 4 proj)
+        self.stage_ranges = {}
+        for name in order:
+            st = stage(name)
+            lo, hi = offs[name], offs[name] + (self.P[name].numel() + 3) // 4 * 4
+            a, b = self.stage_ranges.get(st, (lo, hi))
+            self.stage_ranges[st] = (min(a, lo), max(b, hi))
 
     def _add_pack(self, name, N, Cin, taps, Cpad=None, want_D=True, transposed=False):
         src = self.P[name]
@@ -178,7 +201,7 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def gemm(self, x: Act, wname: str, N: int, *, k=1, pad=0, rows=None, bias: Optional[str] = None, out: Optional[Act] = None,
              out_f32=False, resid: Optional[Act] = None, drop: Drop = NO_DROP, stats=False, outT=None, geom: Optional[Geom] = None,
-             C_real=None, no_dgrad=False, stream_grad: Optional[Act] = None):
+             C_real=None, no_dgrad=False, stream_grad: Optional[Act] = None, w_transposed=False):
         """y = conv_k(x) with weight `wname` (rows n0:n1 of it when `rows`), optional bias / residual / dropout /
         BN statistics / transposed head-split copy.  `stream_grad`: fp32 residual-stream Act whose gradient is the
         gradient of this layer's output (post dropout) - used for `x + dropout(linear(..))` branches."""
@@ -217,7 +240,12 @@ class Engine:
                 gy_ld, gy_coff = pad8(N), 0
             else:
                 gy, gy_ld, gy_coff = out.g, out.ld, out.coff
-            ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff, C_real=creal)
+            if w_transposed:
+                # parameter stored [in, out] (used as x @ P): dP = x^T dY - same kernel with the operand roles swapped
+                ops.conv_wgrad(x.t, gy, Geom.linear(out.M, pad8(N)), x.C, Gw, ldy=x.ld, y_coff=x.coff, N_ld=x.C, ldx=gy_ld,
+                               x_coff=gy_coff, C_real=N)
+            else:
+                ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff, C_real=creal)
             if bias is not None:
                 ops.colsum(gy, out.M, N, self.G[bias][n0:n0 + N], ldx=gy_ld, coff=gy_coff)
             if no_dgrad:
@@ -530,7 +558,7 @@ class Engine:
                     gx.zero_()
                 ops.eot_scatter_add(eot, rows.g, B, L, D, gx)
             self.tape.append(bwd_eot)
-        state = self.gemm(rows, "backbone.text_projection", self.clip.embed_dim)
+        state = self.gemm(rows, "backbone.text_projection", self.clip.embed_dim, w_transposed=True)
         if self.training:
             def bwd_embed():
                 ops.embed_bwd(word, x0.g, self.G["backbone.token_embedding.weight"], self.G["backbone.positional_embedding"])
@@ -715,17 +743,26 @@ class Engine:
         self.training, self.seed = training, int(seed) & 0xFFFFFFFF
         self.tape = []
         self._dgrad_outT = None
+        self._stage_marks = {}
         if training:
             self.grad_arena.zero_()
         self.repack_weights()
         word = word.contiguous()
+        starts = {0: 0}
         v3, v4, v5, feats = self._encode_image(img.contiguous().float())
-        self._text_tape_start = len(self.tape)
+        self._text_tape_start = starts[1] = len(self.tape)
         txt, state = self._encode_text(word)
+        starts[2] = len(self.tape)
         fq = self._fpn(v3, v4, v5, state)
-        self._dec_tape_start = len(self.tape)
+        self._dec_tape_start = starts[3] = len(self.tape)
         fqd = self._decoder(fq, Act(txt.t, txt.Bn, txt.H, 1, txt.C, root=txt.root), word)
+        starts[4] = len(self.tape)
         pred, x, wb = self._projector(fqd, state)
+        # a stage's parameter gradients are complete once the closure at its start index has run, EXCEPT that the text
+        # encoder's output feeds the decoder/neck/projector (its closures all sit in [starts[1], starts[2]) anyway)
+        self._stage_marks = {}
+        for st, idx in starts.items():
+            self._stage_marks.setdefault(idx, []).append(st)
         if taps is not None:
             taps.update(self._neck_taps)
             taps.update(layer1=feats[0], layer2=feats[1], layer3=feats[2], layer4=feats[3], attnpool=v5, word=txt, state=state,
@@ -751,10 +788,16 @@ class Engine:
         self.tape.append(bwd_loss)
         return pred, msk, loss.view(())
 
-    def backward(self, gscale: Optional[torch.Tensor] = None):
-        """Run the tape in reverse.  `gscale`: optional 1-element fp32 device tensor multiplying dloss (GradScaler)."""
+    def backward(self, gscale: Optional[torch.Tensor] = None, on_stage_done: Optional[Callable[[int], None]] = None):
+        """Run the tape in reverse.  `gscale`: optional 1-element fp32 device tensor multiplying dloss (GradScaler).
+        `on_stage_done(stage)` fires when every gradient of arena stage 4 (proj) .. 0 (visual) has been issued on the
+        stream - the hook the data-parallel gradient exchange overlaps with the rest of backward."""
         self._gscale = gscale
-        for fn in reversed(self.tape):
-            fn()
+        marks = dict(self._stage_marks)                 # tape index at which a stage's closures START
+        for i in range(len(self.tape) - 1, -1, -1):
+            self.tape[i]()
+            if on_stage_done is not None and i in marks:
+                for st in marks[i]:
+                    on_stage_done(st)
         self.tape = []
         return self.G

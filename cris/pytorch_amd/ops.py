@@ -105,7 +105,39 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     if colsum is not None:
         p.colsum, p.colsq = ptr(colsum), ptr(colsq)
     p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
+    if KERNEL_TIMER is not None:
+        KERNEL_TIMER.launch("conv_gemm_n128" if N > 64 else "conv_gemm_n64", 2.0 * g.M * N * g.K,
+                            2.0 * (g.M * g.C * (1 if g.KH == 1 else 1) + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p))
+        return
     hip.call("cris_conv_gemm", C.byref(p), _stream())
+
+
+class KernelTimer:
+    """HIP-event timing of individual launches on the launch stream (bench.py roofline leg)."""
+
+    def __init__(self):
+        self.records = []        # (name, flops, bytes, start_event, end_event)
+
+    def launch(self, name, flops, nbytes, fn, *args):
+        s = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(s)
+        hip.call(fn, *args, s.cuda_stream)
+        e1.record(s)
+        self.records.append((name, flops, nbytes, e0, e1))
+
+    def summary(self):
+        out = {}
+        for name, fl, nb, e0, e1 in self.records:
+            d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
+
+
+KERNEL_TIMER = None
 
 
 def wgrad_splits(M: int, N: int, K: int) -> int:
@@ -128,6 +160,9 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
     p.M, p.N, p.K = g.M, N, g.K
     p.C_real = C_real if C_real is not None else g.C
     p.splits = splits if splits is not None else wgrad_splits(g.M, N, g.K)
+    if KERNEL_TIMER is not None:
+        KERNEL_TIMER.launch("conv_wgrad", 2.0 * g.M * N * g.K, 2.0 * (g.M * N + g.M * g.C) + 4.0 * N * g.K, "cris_conv_wgrad", C.byref(p))
+        return
     hip.call("cris_conv_wgrad", C.byref(p), _stream())
 
 

@@ -1,0 +1,76 @@
+"""TEST INFRASTRUCTURE ONLY - run the fp32 oracle with bf16 *storage* rounding at the points where the HIP path
+stores bf16 (conv / linear inputs, weights and outputs, ReLU / BN-apply outputs, LayerNorm outputs, attention
+probabilities and outputs, resampling outputs), fp32 everywhere else (accumulation, statistics, residual streams).
+
+Purpose: separate implementation errors from the inherent bf16 noise of this network.  With the synthetic
+random weights a 50-layer ResNet amplifies one bf16 rounding per layer to ~13 % relative error at layer4 and
+~30 % after the neck *for any bf16 implementation*; the HIP path must match this emulation closely (same
+rounding points => mostly identical rounded values) and the fp32 oracle only to that noise floor.
+"""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+from . import cris_oracle as O
+
+BF = torch.bfloat16
+
+
+def r(x):
+    return x.to(BF).to(x.dtype)
+
+
+@contextlib.contextmanager
+def bf16_storage():
+    saved = dict(conv2d=O.F.conv2d, linear=O.F.linear, relu=O.F.relu, interpolate=O.F.interpolate, avg_pool2d=O.F.avg_pool2d,
+                 layer_norm=O.layer_norm, mha_core=O.mha_core)
+
+    def conv2d(x, w, b=None, **kw):
+        b = kw.pop("bias", b)
+        return r(saved["conv2d"](r(x), r(w), b, **kw))
+
+    def linear(x, w, b=None):
+        return r(saved["linear"](r(x), r(w), b))
+
+    def relu(x, *a, **k):
+        return r(saved["relu"](x))
+
+    def interpolate(x, *a, **k):
+        return r(saved["interpolate"](x, *a, **k))
+
+    def avg_pool2d(x, *a, **k):
+        return r(saved["avg_pool2d"](x, *a, **k))
+
+    def layer_norm(x, sd, prefix):
+        return r(saved["layer_norm"](x, sd, prefix))
+
+    def mha_core(q, k, v, nheads, add_mask=None, key_pad=None, drop=None, stream=0):
+        B, Lq, E = q.shape
+        Lk = k.shape[1]
+        d = E // nheads
+        qh = q.view(B, Lq, nheads, d).transpose(1, 2)
+        kh = k.view(B, Lk, nheads, d).transpose(1, 2)
+        vh = v.view(B, Lk, nheads, d).transpose(1, 2)
+        s = (qh @ kh.transpose(-1, -2)) * (d ** -0.5)
+        if add_mask is not None:
+            s = s + add_mask
+        if key_pad is not None:
+            s = s.masked_fill(key_pad[:, None, None, :], float("-inf"))
+        m = s.max(-1, keepdim=True).values
+        e = torch.exp(s - m)
+        l = e.sum(-1, keepdim=True)
+        p = e
+        if drop is not None and drop.active:
+            p = drop.apply(p.contiguous(), stream)
+        o = (r(p) @ vh) / l                       # probabilities enter the PV product in bf16, normalised after
+        return r(o.transpose(1, 2).reshape(B, Lq, E))
+
+    O.F.conv2d, O.F.linear, O.F.relu, O.F.interpolate, O.F.avg_pool2d = conv2d, linear, relu, interpolate, avg_pool2d
+    O.layer_norm, O.mha_core = layer_norm, mha_core
+    try:
+        yield
+    finally:
+        O.F.conv2d, O.F.linear, O.F.relu = saved["conv2d"], saved["linear"], saved["relu"]
+        O.F.interpolate, O.F.avg_pool2d = saved["interpolate"], saved["avg_pool2d"]
+        O.layer_norm, O.mha_core = saved["layer_norm"], saved["mha_core"]

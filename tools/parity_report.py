@@ -53,9 +53,19 @@ def run(spec="tiny", B=2, S=64, dropout=0.0, seed=11, out=None):
                                       bn_updates=bnu, taps=otaps)
     oloss.backward()
     t_cpu = time.time() - t0
+    # bf16-storage emulation of the oracle (forward only): the noise floor any bf16 implementation shares
+    from oracle.bf16_emulation import bf16_storage
+    etaps = {}
+    with torch.no_grad(), bf16_storage():
+        epred, _, eloss = O.cris_forward(sd, clip, head, img, word, mask, training=True, drop_seed=seed if dropout > 0 else None, taps=etaps)
     rep = {"spec": spec, "B": B, "S": S, "dropout": dropout, "loss_hip": float(loss), "loss_oracle": float(oloss),
            "t_hip_s": t_hip, "t_oracle_s": t_cpu, "taps": {}, "grads": {}, "bn": {}}
     rep["mask_equal"] = bool(torch.equal(msk.cpu(), om))
+    rep["loss_emul"] = float(eloss)
+    rep["emul_vs_fp32"] = {k: rel(etaps[k], otaps[k]) for k in ("layer1", "layer2", "layer3", "layer4", "attnpool", "f5", "fq_neck", "fq_dec")}
+    rep["hip_vs_emul"] = {k: rel(nhwc_to_nchw(taps[k]), etaps[k]) for k in ("layer1", "layer2", "layer3", "layer4", "attnpool", "f5", "fq_neck", "fq_dec")}
+    rep["hip_vs_emul"]["pred"] = rel(pred, epred)
+    rep["emul_vs_fp32"]["pred"] = rel(epred, opred)
     rep["taps"]["pred"] = rel(pred, opred)
     for k in ("layer1", "layer2", "layer3", "layer4", "attnpool", "f5", "f4", "f3", "aggr", "fq_neck", "fq_dec"):
         rep["taps"][k] = rel(nhwc_to_nchw(taps[k]), otaps[k])
@@ -92,6 +102,9 @@ if __name__ == "__main__":
     rep = run(spec, B, S, dp, out=os.path.join(ROOT, "gpurun_out", "parity_%s_b%d_s%d_d%g.json" % (spec, B, S, dp)))
     print("loss hip %.6f oracle %.6f | mask_equal %s | t_hip %.2fs" % (rep["loss_hip"], rep["loss_oracle"], rep["mask_equal"], rep["t_hip_s"]))
     print("taps:", {k: "%.2e" % v for k, v in rep["taps"].items()})
+    print("loss bf16-emulated oracle %.6f" % rep["loss_emul"])
+    print("emul_vs_fp32:", {k: "%.2e" % v for k, v in rep["emul_vs_fp32"].items()})
+    print("hip_vs_emul :", {k: "%.2e" % v for k, v in rep["hip_vs_emul"].items()})
     print("bn running stats worst rel err: %.2e" % rep["bn_worst"])
     print("worst bn:", rep["bn_sorted"])
     print("worst grads (cos, rel, name):")
