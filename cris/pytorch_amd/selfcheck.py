@@ -1,0 +1,78 @@
+"""smoke(): one small CRIS train step (forward + BCE loss + backward + Adam) through the HIP path on cuda:0,
+checked against the CPU oracle on the same seeded inputs.  This module is the ONLY place in the package that
+imports oracle/ - as the checker; the step itself never touches it (see __graft_entry__.smoke)."""
+import dataclasses
+import math
+
+import torch
+
+
+def _rel(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _cos(a, b):
+    a, b = a.double().flatten().cpu(), b.double().flatten().cpu()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0"):
+    """Returns a dict of parity figures: HIP engine vs fp32 oracle (and vs the oracle run with bf16 storage rounding,
+    the noise floor every bf16 implementation shares)."""
+    from . import arch, synth
+    from .trainer import NativeTrainer
+    from oracle import cris_oracle as O                      # checker only
+    from oracle.bf16_emulation import bf16_storage
+
+    clip, head = arch.specs_by_name(spec)
+    head = dataclasses.replace(head, dropout=dropout)
+    sd = arch.synthetic_state_dict(clip, head, 0)
+    img, word, mask = synth.make_batch(batch, size, head.word_len, 0, 0)
+    dev = torch.device(device)
+    tr = NativeTrainer(clip, head, sd, dev)
+    e = tr.engine
+    pred, msk, loss = e.forward(img.to(dev), word.to(dev), mask.to(dev), training=True, seed=seed)
+    G = e.backward()
+    torch.cuda.synchronize(dev)
+    grads = {k: v.detach().clone() for k, v in G.items()}
+
+    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    dseed = seed if dropout > 0 else None
+    opred, om, oloss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=dseed)
+    oloss.backward()
+    with torch.no_grad(), bf16_storage():
+        epred, _, eloss = O.cris_forward(sd, clip, head, img, word, mask, training=True, drop_seed=dseed)
+
+    coss = {}
+    for k, g in grads.items():
+        og = leaf[k].grad
+        if og is None or k.endswith("k_proj.bias") or float(og.norm()) == 0.0:
+            continue                    # d/d(key bias) == 0 analytically: rounding noise on both sides
+        coss[k] = _cos(g, og)
+    worst = min(coss, key=coss.get)
+    rep = {
+        "loss_hip": float(loss), "loss_oracle": float(oloss), "loss_emul": float(eloss),
+        "mask_equal": bool(torch.equal(msk.cpu(), om)),
+        "pred_rel_vs_fp32": _rel(pred, opred), "pred_rel_vs_emul": _rel(pred, epred), "emul_rel_vs_fp32": _rel(epred, opred),
+        "grad_cos_min": coss[worst], "grad_cos_min_name": worst,
+        "grad_cos_median": sorted(coss.values())[len(coss) // 2], "n_grads": len(coss),
+    }
+    # one optimizer step on top (Adam over the arena) must keep everything finite
+    l2, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev), seed=seed + 1)
+    torch.cuda.synchronize(dev)
+    rep["loss_step2"] = float(l2)
+    rep["params_finite"] = all(bool(torch.isfinite(p).all()) for p in e.P.values())
+    return rep
+
+
+def smoke():
+    rep = run()
+    print("smoke:", {k: (round(v, 6) if isinstance(v, float) else v) for k, v in rep.items()})
+    assert rep["mask_equal"], "nearest mask resize is an index op: must be bit exact"
+    assert math.isfinite(rep["loss_hip"]) and math.isfinite(rep["loss_step2"]) and rep["params_finite"]
+    # bf16 path vs fp32 oracle: loss within 2e-2 absolute on an O(0.7) BCE, logits within 3x the bf16-storage noise
+    # floor of the oracle itself (+5e-2), gradients pointing the same way
+    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < 2e-2, rep
+    assert rep["pred_rel_vs_fp32"] < 3.0 * rep["emul_rel_vs_fp32"] + 5e-2, rep
+    assert rep["grad_cos_median"] > 0.98 and rep["grad_cos_min"] > 0.5, rep
