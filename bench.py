@@ -88,8 +88,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    first_loss = None
     for i in range(args.warmup):
-        tr.train_step(*batches[i % nb])
+        l0, _ = tr.train_step(*batches[i % nb])
+        if first_loss is None:
+            first_loss = float(l0)
     sync()
     timer = None
     if not args.no_kernel_timer:
@@ -119,7 +122,7 @@ def main():
                                    "synthetic RefCOCO-shape batch resident in HBM (BASELINE.json configs[1]%s)"
                                    % (args.spec.upper(), args.size, args.size, args.batch,
                                       "" if world == 1 else "; x%d GPUs = configs[2] recipe: SyncBN + gradient all-reduce over RCCL" % world),
-                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "final_loss": loss_v},
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first_loss, "final_loss": loss_v},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12),
                               "hbm_frac_alg": (sps / world * ALG_BYTES_PER_SAMPLE + steps_s * ADAM_BYTES_PER_STEP) / (HBM_PEAK * 1e9)},
         }

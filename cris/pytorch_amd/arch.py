@@ -346,12 +346,19 @@ def synthetic_state_dict(clip: ClipSpec, head: HeadSpec, seed: int = 0) -> "Orde
             t = _round_fp16(torch.randn(shape, generator=g) * shape[0] ** -0.5)
         elif len(shape) == 1 and leaf in ("weight", "bias") and _is_norm(tree, parent):
             if leaf == "weight":
-                lo, hi = (0.2, 0.6) if parent.endswith(".bn3") else (0.7, 1.3)
-                t = torch.rand(shape, generator=g) * (hi - lo) + lo
+                t = _norm_gamma(parent, shape, seed)
             else:
                 t = torch.randn(shape, generator=g) * 0.05
+                if _is_batchnorm(tree, parent):
+                    # beta = +gamma: ~84 % of the ReLU units behind each BatchNorm are active, like a trained network and
+                    # unlike a random ReLU-BN stack, whose forward map is chaotic (a single bf16 rounding per layer grows
+                    # to 10-50 % at the logits: measured with oracle/bf16_emulation.py).  Any state_dict is a legitimate
+                    # test input; this one keeps bf16-vs-fp32 parity figures meaningful.
+                    t = t + _norm_gamma(parent, shape, seed)
         elif leaf in ("bias", "in_proj_bias"):
             t = torch.randn(shape, generator=g) * 0.02
+            if name.startswith("proj.txt."):
+                t = t * 0.05        # 2304 of these enter every logit (see the weight rule below)
             if in_clip:
                 t = _round_fp16(t)
         elif leaf in ("weight", "in_proj_weight"):
@@ -361,13 +368,22 @@ def synthetic_state_dict(clip: ClipSpec, head: HeadSpec, seed: int = 0) -> "Orde
             gain = 2.0 if len(shape) == 4 else 1.0
             t = torch.randn(shape, generator=g) * math.sqrt(gain / fan_in)
             if name.startswith("proj.txt."):
-                t = t * 0.05        # keeps the 2304-term pixel-text similarity (the logits) O(1)
+                t = t * 0.01        # keeps the 2304-term pixel-text similarity (the logits) O(1)
             if in_clip:
                 t = _round_fp16(t)
         else:  # pragma: no cover
             raise KeyError("no init rule for %s %s" % (name, shape))
         out[name] = t.contiguous()
     return out
+
+
+def _norm_gamma(parent: str, shape, seed: int) -> torch.Tensor:
+    lo, hi = (0.2, 0.6) if parent.endswith(".bn3") else (0.7, 1.3)
+    return torch.rand(shape, generator=_gen_for(parent + ".weight", seed)) * (hi - lo) + lo
+
+
+def _is_batchnorm(tree: nn.Module, parent: str) -> bool:
+    return isinstance(tree.get_submodule(parent), nn.modules.batchnorm._BatchNorm)
 
 
 def _is_norm(tree: nn.Module, parent: str) -> bool:

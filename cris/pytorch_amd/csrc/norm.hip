@@ -7,6 +7,46 @@
 // ------------------------------------------------------------------------------------------------
 // BN coefficients
 // ------------------------------------------------------------------------------------------------
+#define BN_MERGE_SLICES 64      // first-level merge width for long partial lists (see cris_bn_partials_rows)
+
+// Chan et al. pairwise update of (n, mean, M2) with a block (nb rows, sum sb, M2 mb)
+__device__ __forceinline__ void chan_add(float& n, float& mean, float& m2, float nb, float sb, float mb) {
+    if (nb <= 0.f) return;
+    const float mean_b = sb / nb;
+    const float nt = n + nb;
+    const float d = mean_b - mean;
+    mean += d * (nb / nt);
+    m2 += mb + d * d * (n * nb / nt);
+    n = nt;
+}
+
+// level 1: slice s merges parts [s*pps, (s+1)*pps) into one (sum, M2 about the slice mean) row.  Block = 64 channels x 4
+// part lanes, coalesced 256-B rows; deterministic (fixed merge tree).
+__global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__ psum, const float* __restrict__ pm2, int nparts,
+                                                       int rows_per_part, int M, int C, int pps, float* __restrict__ osum,
+                                                       float* __restrict__ om2) {
+    __shared__ float sh[3][4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int s = blockIdx.y;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C) {
+        const int i1 = min(nparts, (s + 1) * pps);
+        for (int i = s * pps + pl; i < i1; i += 4) {
+            const int rows = min(rows_per_part, M - i * rows_per_part);
+            if (rows > 0) chan_add(n, mean, m2, (float)rows, psum[(size_t)i * C + c], pm2[(size_t)i * C + c]);
+        }
+    }
+    sh[0][pl][cl] = n; sh[1][pl][cl] = mean; sh[2][pl][cl] = m2;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) chan_add(n, mean, m2, sh[0][j][cl], sh[1][j][cl] * sh[0][j][cl], sh[2][j][cl]);
+        osum[(size_t)s * C + c] = mean * n;
+        om2[(size_t)s * C + c] = m2;
+    }
+}
+
 __global__ void bn_finalize_kernel(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
                                    float count, const float* gamma, const float* beta, float* rmean, float* rvar,
                                    float momentum, float eps, int C, float* scale, float* shift, float* mean_o,
@@ -19,20 +59,18 @@ __global__ void bn_finalize_kernel(const float* psum, const float* pm2, int npar
         mean = global_stats[c] / count;
         m2 = global_stats[C + c];
     } else {
-        // merge per-block partials (Chan et al.): M2 = sum M2_i + n_i (mean_i - mean)^2
-        float tot = 0.f;
-        for (int i = 0; i < nparts; ++i) tot += psum[(size_t)i * C + c];
-        mean = tot / count_local;
+        // merge per-block partials (Chan et al.) in one pass
+        float n = 0.f;
+        mean = 0.f;
         m2 = 0.f;
         const int M = (int)count_local;
         for (int i = 0; i < nparts; ++i) {
-            const int n = min(rows_per_part, M - i * rows_per_part);
-            if (n <= 0) break;
-            const float d = psum[(size_t)i * C + c] / (float)n - mean;
-            m2 += pm2[(size_t)i * C + c] + (float)n * d * d;
+            const int rows = min(rows_per_part, M - i * rows_per_part);
+            if (rows <= 0) break;
+            chan_add(n, mean, m2, (float)rows, psum[(size_t)i * C + c], pm2[(size_t)i * C + c]);
         }
         if (merged) {                       // hand the local (sum, M2) to the SyncBN exchange; finalize runs again after it
-            merged[c] = tot;
+            merged[c] = mean * n;
             merged[C + c] = m2;
             mean_o[c] = mean;               // local mean, needed to re-centre M2 about the global mean
             return;
@@ -52,12 +90,29 @@ __global__ void bn_finalize_kernel(const float* psum, const float* pm2, int npar
     }
 }
 
+// rows the caller must allocate for a partials buffer of `nparts` parts (room for the level-1 merge output)
+extern "C" int cris_bn_partials_rows(int nparts) { return nparts > 2 * BN_MERGE_SLICES ? nparts + BN_MERGE_SLICES : nparts; }
+
 extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
                                 float count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 float momentum, float eps, int C, float* scale, float* shift, float* mean, float* invstd,
                                 float* merged, const float* global_stats, void* stream) {
     CRIS_CHECK_ARG((global_stats || (psum && pm2 && nparts > 0 && rows_per_part > 0)) && gamma && beta && mean && C > 0 && count > 0.f, "bad args");
     CRIS_CHECK_ARG(merged || (scale && shift && invstd), "bad args");
+    if (!global_stats && nparts > 2 * BN_MERGE_SLICES) {
+        // two-level merge: BN_MERGE_SLICES slices written behind the partials (rows nparts .. nparts+slices)
+        const int pps = cris_cdiv(nparts, BN_MERGE_SLICES);
+        const int slices = cris_cdiv(nparts, pps);
+        float* osum = const_cast<float*>(psum) + (size_t)nparts * C;
+        float* om2 = const_cast<float*>(pm2) + (size_t)nparts * C;
+        hipLaunchKernelGGL(bn_merge_kernel, dim3(cris_cdiv(C, 64), slices), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts,
+                           rows_per_part, (int)count_local, C, pps, osum, om2);
+        CRIS_LAUNCH_CHECK();
+        psum = osum;
+        pm2 = om2;
+        nparts = slices;
+        rows_per_part *= pps;
+    }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
                        count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
                        merged, global_stats);

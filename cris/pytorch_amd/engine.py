@@ -60,16 +60,6 @@ class Act:
         return r._g, True
 
 
-class Stats:
-    """BatchNorm statistics partials [2][nparts][C] + rows per partial."""
-    def __init__(self, t, rows):
-        self.t, self.aux_rows = t, rows
-        self.shape = t.shape
-
-    def __getitem__(self, i):
-        return self.t[i]
-
-
 class Comm:
     """Cross-rank hooks used by SyncBN / gradient averaging (dist.py provides the RCCL implementation)."""
     world = 1
@@ -221,7 +211,7 @@ class Engine:
             out = self.new_act(g.Bn, g.OH, g.OW, N, ld=pad8(N), dtype=F32 if out_f32 else BF16, zero=(pad8(N) != N))
         st = None
         if stats:
-            st = Stats(ops.new_stats(g.M, N, self.dev), ops.stat_rows(N))
+            st = ops.new_stats(g.M, N, self.dev)
         kw = {}
         if outT is not None:
             kw = dict(outT=outT["buf"], T_L=outT["L"], T_Lpad=outT["Lpad"], T_E=outT["E"], T_sec_stride=outT["sec_stride"])
@@ -275,19 +265,18 @@ class Engine:
         if not self.training:
             ops.bn_eval_coeffs(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
             return scale, shift, mean, invstd, count
-        rpp = st.aux_rows
         if self.sync_bn:
             # SyncBatchNorm (train.py:97-98): exchange (sum, M2) instead of torch's (mean, invstd, count) all_gather
             gcount = count * self.comm.world
             merged = self.zeros(2 * C)
-            ops.bn_finalize(st, rpp, count, count, gamma, beta, None, None, BN_MOM, BN_EPS, C, None, None, mean, None, merged=merged)
+            ops.bn_finalize(st, count, count, gamma, beta, None, None, BN_MOM, BN_EPS, C, None, None, mean, None, merged=merged)
             self.comm.allreduce_sum(merged[:C])
             ops.bn_recentre(merged[C:], mean, merged[:C], count, gcount, C)
             self.comm.allreduce_sum(merged[C:])
-            ops.bn_finalize(None, 0, count, gcount, gamma, beta, rm, rv, BN_MOM, BN_EPS, C, scale, shift, mean, invstd,
+            ops.bn_finalize(None, count, gcount, gamma, beta, rm, rv, BN_MOM, BN_EPS, C, scale, shift, mean, invstd,
                             global_stats=merged)
             return scale, shift, mean, invstd, gcount
-        ops.bn_finalize(st, rpp, count, count, gamma, beta, rm, rv, BN_MOM, BN_EPS, C, scale, shift, mean, invstd)
+        ops.bn_finalize(st, count, count, gamma, beta, rm, rv, BN_MOM, BN_EPS, C, scale, shift, mean, invstd)
         return scale, shift, mean, invstd, count
 
     def bn(self, y: Act, st, pfx: str, *, relu=True, pool=False, ident: Optional[Act] = None, y2: Optional[Act] = None, st2=None,
@@ -308,9 +297,7 @@ class Engine:
                      ldi=None if ident is None else ident.ld, i_coff=0 if ident is None else ident.coff, mul=mul)
         if want_stats:
             # statistics of this output for a BatchNorm that follows without a conv in between (FPN norm_layer)
-            ost = Stats(torch.zeros(2, (out.M + 31) // 32, C, dtype=F32, device=self.dev), 32)
-            ops.colstats(out.t, out.M, C, 32, ost, ldx=out.ld, coff=out.coff)
-            out.aux["stats"] = ost
+            out.aux["stats"] = ops.colstats(out.t, out.M, C, 32, self.dev, ldx=out.ld, coff=out.coff)
         if not self.training:
             return out
         dmul = self.zeros(y.Bn, C) if mul is not None else None

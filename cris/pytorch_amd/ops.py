@@ -232,15 +232,33 @@ def stat_parts(M: int, N: int) -> int:
     return ((M + 127) // 128) * (128 // stat_rows(N))
 
 
-def new_stats(M: int, N: int, device):
-    """partials buffer [2][nparts][N] (sum, M2) for conv_gemm(colsum=st[0], colsq=st[1])"""
-    return torch.zeros(2, stat_parts(M, N), N, dtype=torch.float32, device=device)
+def partials_rows(nparts: int) -> int:
+    """rows a partials buffer needs (room for bn_finalize's first-level merge; cris_bn_partials_rows)"""
+    return nparts + 64 if nparts > 128 else nparts
 
 
-def bn_finalize(st, rows_per_part, count_local, count, gamma, beta, rmean, rvar, momentum, eps, C_, scale, shift, mean, invstd,
+class Stats:
+    """BatchNorm statistics partials: t [2][rows >= nparts][C] (sum, M2 about the part mean), `rows_per_part` rows each."""
+    __slots__ = ("t", "nparts", "rows_per_part")
+
+    def __init__(self, nparts, C_, rows_per_part, device):
+        self.t = torch.empty(2, partials_rows(nparts), C_, dtype=torch.float32, device=device)
+        self.nparts, self.rows_per_part = nparts, rows_per_part
+
+    def __getitem__(self, i):
+        return self.t[i]
+
+
+def new_stats(M: int, N: int, device) -> Stats:
+    """partials for conv_gemm(colsum=st[0], colsq=st[1]): every part row is written by the epilogue (no zero fill needed)"""
+    return Stats(stat_parts(M, N), N, stat_rows(N), device)
+
+
+def bn_finalize(st: Optional[Stats], count_local, count, gamma, beta, rmean, rvar, momentum, eps, C_, scale, shift, mean, invstd,
                 merged=None, global_stats=None):
     hip.call("cris_bn_finalize", ptr(st[0]) if st is not None else None, ptr(st[1]) if st is not None else None,
-             st.shape[1] if st is not None else 0, rows_per_part, float(count_local), float(count), ptr(gamma), ptr(beta),
+             st.nparts if st is not None else 0, st.rows_per_part if st is not None else 0, float(count_local), float(count),
+             ptr(gamma), ptr(beta),
              ptr(rmean), ptr(rvar), float(momentum), float(eps), C_, ptr(scale), ptr(shift), ptr(mean), ptr(invstd), ptr(merged),
              ptr(global_stats), _stream())
 
@@ -249,9 +267,11 @@ def bn_recentre(m2, mean_local, gsum, n_local, count_global, C_):
     hip.call("cris_bn_recentre", ptr(m2), ptr(mean_local), ptr(gsum), float(n_local), float(count_global), C_, _stream())
 
 
-def colstats(x, M, C_, rows_per_part, st, ldx=None, coff=0):
+def colstats(x, M, C_, rows_per_part, device, ldx=None, coff=0) -> Stats:
+    st = Stats((M + rows_per_part - 1) // rows_per_part, C_, rows_per_part, device)
     hip.call("cris_colstats_bf16", ptr(x), ldx if ldx is not None else x.shape[-1], coff, M, C_, rows_per_part, ptr(st[0]),
              ptr(st[1]), _stream())
+    return st
 
 
 def bn_eval_coeffs(gamma, beta, rmean, rvar, eps, C_, scale, shift):

@@ -41,22 +41,32 @@ def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0"):
     dseed = seed if dropout > 0 else None
     opred, om, oloss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=dseed)
     oloss.backward()
-    with torch.no_grad(), bf16_storage():
-        epred, _, eloss = O.cris_forward(sd, clip, head, img, word, mask, training=True, drop_seed=dseed)
+    # the oracle again with bf16 storage rounding at the points where the HIP path stores bf16 (forward AND the
+    # gradients flowing back through the same casts): the noise floor any bf16 implementation of this network shares
+    leaf_e = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    with bf16_storage():
+        epred, _, eloss = O.cris_forward(leaf_e, clip, head, img, word, mask, training=True, drop_seed=dseed)
+        eloss.backward()
+    epred, eloss = epred.detach(), eloss.detach()
 
-    coss = {}
+    coss, ecoss, hecoss = {}, {}, {}
     for k, g in grads.items():
         og = leaf[k].grad
         if og is None or k.endswith("k_proj.bias") or float(og.norm()) == 0.0:
             continue                    # d/d(key bias) == 0 analytically: rounding noise on both sides
         coss[k] = _cos(g, og)
+        ecoss[k] = _cos(leaf_e[k].grad, og)
+        hecoss[k] = _cos(g, leaf_e[k].grad)
     worst = min(coss, key=coss.get)
+    med = lambda d: sorted(d.values())[len(d) // 2]
     rep = {
-        "loss_hip": float(loss), "loss_oracle": float(oloss), "loss_emul": float(eloss),
+        "loss_hip": float(loss), "loss_oracle": float(oloss.detach()), "loss_emul": float(eloss),
         "mask_equal": bool(torch.equal(msk.cpu(), om)),
         "pred_rel_vs_fp32": _rel(pred, opred), "pred_rel_vs_emul": _rel(pred, epred), "emul_rel_vs_fp32": _rel(epred, opred),
         "grad_cos_min": coss[worst], "grad_cos_min_name": worst,
-        "grad_cos_median": sorted(coss.values())[len(coss) // 2], "n_grads": len(coss),
+        "grad_cos_median": med(coss), "n_grads": len(coss),
+        "emul_grad_cos_median": med(ecoss), "emul_grad_cos_min": min(ecoss.values()),
+        "hip_vs_emul_grad_cos_median": med(hecoss),
     }
     # one optimizer step on top (Adam over the arena) must keep everything finite
     l2, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev), seed=seed + 1)

@@ -107,7 +107,10 @@ int cris_colsum_bf16(const cris_bf16* x, int ldx, int coff, int M, int N, float*
  * epilogue or cris_colstats_bf16 and are merged with Chan's parallel-variance formula.
  * SyncBN: call once with `merged` (local sum / M2 / mean out), all-reduce the sums, cris_bn_recentre the M2,
  * all-reduce the M2, then call again with `global_stats`.
+ * Long partial lists are merged in two levels: psum / pm2 must have room for cris_bn_partials_rows(nparts) rows of C
+ * floats each (the first-level result is written behind the nparts partial rows).
  * ---------------------------------------------------------------------------------------------- */
+int cris_bn_partials_rows(int nparts);
 int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local, float count,
                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                      float eps, int C, float* scale, float* shift, float* mean, float* invstd, float* merged,

@@ -113,7 +113,7 @@ def test_conv_gemm_epilogues():
         check(st[0][part], blk.sum(0), 3e-3, "part sum")
         check(st[1][part], ((blk - blk.mean(0)) ** 2).sum(0), 5e-3, "part M2")
     outs = [torch.empty(N, device=DEV) for _ in range(4)]
-    ops.bn_finalize(st, rows, M, M, torch.ones(N, device=DEV), torch.zeros(N, device=DEV), None, None, 0.1, 1e-5, N, *outs)
+    ops.bn_finalize(st, M, M, torch.ones(N, device=DEV), torch.zeros(N, device=DEV), None, None, 0.1, 1e-5, N, *outs)
     check(outs[2], y.mean(0), 3e-3, "mean from partials")
     check(outs[3], torch.rsqrt(y.var(0, unbiased=False) + 1e-5), 3e-3, "invstd from partials")
     # dropout (mask is an index op: exact), then residual
@@ -220,12 +220,23 @@ def test_bn_stats_robust_to_large_mean():
     M, C_ = 4000, 16
     y = (rnd(M, C_) * 0.01 + 100.0).to(BF).float()         # bf16 grid near 100 has spacing 0.5: values are 99.5/100/100.5
     y = y + 0.0
-    st = torch.zeros(2, (M + 31) // 32, C_, device=DEV)
-    ops.colstats(bf(y), M, C_, 32, st)
+    st = ops.colstats(bf(y), M, C_, 32, DEV)
     outs = [torch.empty(C_, device=DEV) for _ in range(4)]
-    ops.bn_finalize(st, 32, M, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs)
+    ops.bn_finalize(st, M, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs)
     check(outs[2], y.double().mean(0), 1e-6, "mean")
     check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), 1e-4, "invstd")
+
+
+def test_bn_finalize_two_level_merge():
+    """> 128 partials take the two-level (slice) merge path; result must equal the direct statistics."""
+    M, C_ = 40000, 72                                        # 1250 parts of 32 rows, ragged last slice
+    y = (rnd(M, C_) * 2.0 + 3.0).to(BF).float()
+    st = ops.colstats(bf(y), M, C_, 32, DEV)
+    assert st.nparts > 128 and st.t.shape[1] == st.nparts + 64
+    outs = [torch.empty(C_, device=DEV) for _ in range(4)]
+    ops.bn_finalize(st, M, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs)
+    check(outs[2], y.double().mean(0), 1e-6, "mean")
+    check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), 1e-5, "invstd")
 
 
 def test_colsum():
@@ -248,10 +259,9 @@ def _bn_setup(B, H, W, C_, seed=0):
 def _bn_coeffs(y2d, gamma, beta, rm=None, rv=None):
     C_ = y2d.shape[1]
     M = y2d.shape[0]
-    st = torch.zeros(2, (M + 31) // 32, C_, device=DEV)
-    ops.colstats(bf(y2d), M, C_, 32, st)
+    st = ops.colstats(bf(y2d), M, C_, 32, DEV)
     outs = [torch.empty(C_, device=DEV) for _ in range(4)]
-    ops.bn_finalize(st, 32, M, M, gamma.to(DEV), beta.to(DEV), rm, rv, 0.1, 1e-5, C_, *outs)
+    ops.bn_finalize(st, M, M, gamma.to(DEV), beta.to(DEV), rm, rv, 0.1, 1e-5, C_, *outs)
     return outs
 
 

@@ -7,11 +7,14 @@ O=gpurun_out
 mkdir -p $O
 what="${1:-all}"
 if [[ "$what" == all || "$what" == *tests* ]]; then
-  timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+  timeout 900 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
   tail -15 $O/pytest_gpu.log
 fi
 if [[ "$what" == all || "$what" == *parity* ]]; then
   timeout 300 python tools/parity_report.py tiny 4 64 0.1 > $O/parity_tiny.log 2>&1; tail -30 $O/parity_tiny.log
+fi
+if [[ "$what" == all || "$what" == *stage* ]]; then
+  timeout 300 python tools/stage_bwd_check.py tiny 4 64 > $O/stage_bwd_tiny.log 2>&1; grep -v Warning $O/stage_bwd_tiny.log | tail -40
 fi
 if [[ "$what" == all || "$what" == *bench* ]]; then
   timeout 600 python bench.py --steps 10 --warmup 3 > $O/bench.log 2>&1; echo "bench rc=$?"; tail -3 $O/bench.log
