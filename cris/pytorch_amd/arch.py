@@ -300,6 +300,13 @@ def build_param_tree(clip: ClipSpec, head: HeadSpec) -> nn.Module:
 # ----------------------------------------------------------------------------------------------
 # deterministic synthetic weights
 # ----------------------------------------------------------------------------------------------
+# The pixel-text similarity (the logits) sums 2304 products x*w with w = Linear(state): at plain fan-in scales its std is
+# ~50.  The shrink needed for O(1) logits (initial BCE ~0.8) is spread over the three tensors on that product path
+# (text_projection, proj.txt.weight, proj.vis.4.weight) so that none of them becomes tiny relative to Adam's fixed
+# 1e-4 first steps (a 100x smaller weight is 100x more sensitive: the loss then jumps 0.8 -> 11 after ONE step).
+LOGIT_SHRINK = 0.25
+
+
 def _gen_for(name: str, seed: int) -> torch.Generator:
     h = hashlib.sha256(("%d:%s" % (seed, name)).encode()).digest()
     g = torch.Generator(device="cpu")
@@ -343,7 +350,7 @@ def synthetic_state_dict(clip: ClipSpec, head: HeadSpec, seed: int = 0) -> "Orde
         elif name.endswith("attnpool.positional_embedding"):
             t = torch.randn(shape, generator=g) / shape[1] ** 0.5
         elif name == "backbone.text_projection":
-            t = _round_fp16(torch.randn(shape, generator=g) * shape[0] ** -0.5)
+            t = _round_fp16(torch.randn(shape, generator=g) * shape[0] ** -0.5 * LOGIT_SHRINK)
         elif len(shape) == 1 and leaf in ("weight", "bias") and _is_norm(tree, parent):
             if leaf == "weight":
                 t = _norm_gamma(parent, shape, seed)
@@ -358,7 +365,7 @@ def synthetic_state_dict(clip: ClipSpec, head: HeadSpec, seed: int = 0) -> "Orde
         elif leaf in ("bias", "in_proj_bias"):
             t = torch.randn(shape, generator=g) * 0.02
             if name.startswith("proj.txt."):
-                t = t * 0.05        # 2304 of these enter every logit (see the weight rule below)
+                t = t * 0.5         # 2304 of these enter every logit (see the weight rule below)
             if in_clip:
                 t = _round_fp16(t)
         elif leaf in ("weight", "in_proj_weight"):
@@ -367,8 +374,8 @@ def synthetic_state_dict(clip: ClipSpec, head: HeadSpec, seed: int = 0) -> "Orde
                 fan_in *= s
             gain = 2.0 if len(shape) == 4 else 1.0
             t = torch.randn(shape, generator=g) * math.sqrt(gain / fan_in)
-            if name.startswith("proj.txt."):
-                t = t * 0.01        # keeps the 2304-term pixel-text similarity (the logits) O(1)
+            if name in ("proj.txt.weight", "proj.vis.4.weight"):
+                t = t * LOGIT_SHRINK
             if in_clip:
                 t = _round_fp16(t)
         else:  # pragma: no cover

@@ -1,0 +1,66 @@
+"""Generate loss-trajectory fixtures with the CPU oracle + torch.optim.Adam (this container; hours of CPU for R50).
+
+    python tests/golden/make_trajectory.py r50 8 416 100 0.1 2e-6     -> tests/golden/traj_r50_b8_s416_d0.1_lr2e-06.json
+
+Protocol = the reference train loop on synthetic data (engine/engine.py:37-57, train.py:105-107): fresh seeded batch per
+step (synth.make_batch(rank 0, step t)), forward + BCE loss, backward, Adam(lr, betas .9/.999, eps 1e-8, wd 0) over
+every parameter that receives a gradient, BatchNorm running statistics updated.  lr: the reference's 1e-4 for the tiny
+model; for R50 with random (untrained) weights Adam's first +-1e-4 steps through the 2304-term pixel-text product move
+the logits by ~20 per step (the oracle's own loss goes 0.76 -> 11.0 after ONE step) - a transient no two
+implementations with different rounding can track - so the R50 fixture uses lr 2e-6, where the loss falls smoothly.  Dropout masks come from the shared
+counter hash (oracle/dropout_hash.py) with the trainer's seed rule (step*7919+17), so the HIP path can be compared step by
+step at the full BASELINE.json configs[1] shape WITHOUT running the CPU oracle on the GPU box.  The file is rewritten
+after every step (partial runs are usable)."""
+import dataclasses
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from cris.pytorch_amd import arch, synth  # noqa: E402
+from oracle import cris_oracle as O  # noqa: E402
+
+
+def main(spec="tiny", B=4, S=64, steps=100, dropout=0.1, lr=1e-4, threads=6):
+    torch.set_num_threads(threads)
+    clip, head = arch.specs_by_name(spec)
+    head = dataclasses.replace(head, dropout=dropout)
+    sd = arch.synthetic_state_dict(clip, head, 0)
+    leaf = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.endswith(("running_mean", "running_var")))
+                else v.clone()) for k, v in sd.items()}
+    params = [v for v in leaf.values() if v.requires_grad]
+    opt = torch.optim.Adam(params, lr=lr)
+    out = os.path.join(HERE, "traj_%s_b%d_s%d_d%g_lr%g.json" % (spec, B, S, dropout, lr))
+    rec = {"spec": spec, "batch": B, "size": S, "dropout": dropout, "lr": lr, "seed_rule": "step*7919+17",
+           "loss": [], "iou": [], "pr50": [], "sec_per_step": []}
+    for t in range(steps):
+        t0 = time.time()
+        img, word, mask = synth.make_batch(B, S, head.word_len, 0, t)
+        bnu = {}
+        pred, m, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True,
+                                       drop_seed=(t * 7919 + 17) if dropout > 0 else None, bn_updates=bnu)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        with torch.no_grad():
+            for pfx, (rm, rv) in bnu.items():
+                leaf[pfx + ".running_mean"].copy_(rm)
+                leaf[pfx + ".running_var"].copy_(rv)
+            iou, pr = O.train_metric(pred.detach(), m)
+        rec["loss"].append(float(loss.detach()))
+        rec["iou"].append(float(iou))
+        rec["pr50"].append(float(pr))
+        rec["sec_per_step"].append(round(time.time() - t0, 2))
+        with open(out, "w") as f:
+            json.dump(rec, f)
+        print(t, rec["loss"][-1], rec["sec_per_step"][-1], flush=True)
+
+
+if __name__ == "__main__":
+    a = sys.argv[1:]
+    main(a[0] if a else "tiny", int(a[1]) if len(a) > 1 else 4, int(a[2]) if len(a) > 2 else 64,
+         int(a[3]) if len(a) > 3 else 100, float(a[4]) if len(a) > 4 else 0.1, float(a[5]) if len(a) > 5 else 1e-4)

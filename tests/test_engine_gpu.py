@@ -12,10 +12,16 @@ Tolerances (bf16 activations / MFMA operands, fp32 accumulation, statistics and 
   * loss trajectory over optimizer steps vs the oracle driven by torch.optim.Adam: max |diff| reported, bound 3e-2.
 """
 import dataclasses
+import json
 import math
+import os
+import sys
 
+import numpy as np
 import pytest
 import torch
+
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -24,30 +30,58 @@ from cris.pytorch_amd.trainer import NativeTrainer  # noqa: E402
 from oracle import cris_oracle as O  # noqa: E402
 
 
-def _assert_parity(rep):
+def _assert_parity(rep, k=3.0):
+    """HIP-vs-fp32 errors are bounded by k x the errors the ORACLE ITSELF shows when it is run with bf16 storage rounding at
+    the same points (oracle/bf16_emulation.py): the noise floor of any bf16 implementation of this network."""
     assert rep["mask_equal"]
     assert math.isfinite(rep["loss_hip"]) and rep["params_finite"]
-    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < 2e-2, rep
-    assert rep["pred_rel_vs_fp32"] < 3.0 * rep["emul_rel_vs_fp32"] + 5e-2, rep
-    assert rep["grad_cos_median"] > 0.98 and rep["grad_cos_min"] > 0.5, rep
+    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < k * abs(rep["loss_emul"] - rep["loss_oracle"]) + 1e-2, rep
+    assert rep["pred_rel_vs_fp32"] < k * rep["emul_rel_vs_fp32"] + 1e-2, rep
+    assert 1.0 - rep["grad_cos_median"] < k * (1.0 - rep["emul_grad_cos_median"]) + 5e-3, rep
+    assert 1.0 - rep["grad_cos_min"] < k * (1.0 - rep["emul_grad_cos_min"]) + 5e-2, rep
 
 
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_tiny_step_matches_oracle(dropout):
-    _assert_parity(selfcheck.run("tiny", batch=4, size=64, dropout=dropout, seed=11))
+    rep = selfcheck.run("tiny", batch=8, size=64, dropout=dropout, seed=11)
+    print(rep)
+    _assert_parity(rep)
 
 
 def test_tiny_ragged_shapes():
-    """odd batch, non-square-friendly size (96 -> 24/12/6/3 maps), all-but-one padded text."""
-    _assert_parity(selfcheck.run("tiny", batch=3, size=96, dropout=0.0, seed=5))
+    """odd batch, 96 px (24/12/6/3 feature maps: every tile tail path), random text lengths."""
+    rep = selfcheck.run("tiny", batch=3, size=96, dropout=0.0, seed=5)
+    print(rep)
+    _assert_parity(rep)
 
 
 def test_r50_small_step_matches_oracle():
     """Full CRIS-R50 parameter tree (146.8 M parameters) at 160x160, batch 2 - the golden-fixture case."""
     rep = selfcheck.run("r50", batch=2, size=160, dropout=0.0, seed=3)
-    assert rep["mask_equal"] and rep["params_finite"]
-    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < 3e-2, rep
-    assert rep["grad_cos_median"] > 0.95, rep
+    print(rep)
+    _assert_parity(rep)
+    g = np.load(os.path.join(GOLDEN, "r50_b2_s160.npz"))          # the reference's own loss on the same inputs
+    assert abs(rep["loss_oracle"] - float(g["loss"])) < 2e-4
+
+
+def test_stage_isolated_parity():
+    """Every stage (bottlenecks, attnpool, text encoder, FPN, decoder with/without dropout, projector + loss) fed with the
+    oracle's bf16-rounded inputs and a random upstream gradient: errors cannot compound across stages here, so the bounds
+    are tight - outputs rel L2 <= 2e-2, input gradients cos >= 0.99, parameter gradients cos >= 0.98."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import stage_bwd_check
+    rows = stage_bwd_check.main("tiny", 8, 64)
+    bad = []
+    for stage, what, r, c in rows:
+        if what in ("out", "pred", "word", "state", "loss"):
+            ok = r <= 2e-2 and c >= 0.999
+        elif what.startswith("param:"):
+            ok = c >= 0.98
+        else:
+            ok = c >= 0.99
+        if not ok:
+            bad.append((stage, what, r, c))
+    assert not bad, bad
 
 
 def test_eval_forward_matches_oracle():
@@ -63,29 +97,38 @@ def test_eval_forward_matches_oracle():
     assert err < 0.1, err
 
 
-def test_loss_trajectory_vs_oracle_adam():
-    """10 optimizer steps: HIP trainer (fused Adam over the gradient arena) vs oracle + torch.optim.Adam, dropout 0."""
-    clip, head = arch.specs_by_name("tiny")
-    head = dataclasses.replace(head, dropout=0.0)
+def _trajectory(name, max_steps=None):
+    fx = json.load(open(os.path.join(GOLDEN, name)))
+    clip, head = arch.specs_by_name(fx["spec"])
+    head = dataclasses.replace(head, dropout=fx["dropout"])
     sd = arch.synthetic_state_dict(clip, head, 0)
     dev = torch.device("cuda:0")
-    tr = NativeTrainer(clip, head, sd, dev, base_lr=1e-4)
-    leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
-    plist = [v for k, v in leaf.items() if v.is_floating_point() and v.requires_grad and not k.endswith(("running_mean", "running_var"))]
-    opt = torch.optim.Adam(plist, lr=1e-4)
-    diffs = []
-    for step in range(10):
-        img, word, mask = synth.make_batch(4, 64, head.word_len, 0, step)
+    tr = NativeTrainer(clip, head, sd, dev, base_lr=fx["lr"])
+    n = len(fx["loss"]) if max_steps is None else min(max_steps, len(fx["loss"]))
+    losses = []
+    for t in range(n):
+        img, word, mask = synth.make_batch(fx["batch"], fx["size"], head.word_len, 0, t)
         loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
-        bnu = {}
-        _, _, oloss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, bn_updates=bnu)
-        opt.zero_grad()
-        oloss.backward()
-        opt.step()
-        with torch.no_grad():
-            for pfx, (rm, rv) in bnu.items():
-                leaf[pfx + ".running_mean"].copy_(rm)
-                leaf[pfx + ".running_var"].copy_(rv)
-        diffs.append(abs(float(loss) - float(oloss)))
-    print("loss trajectory |diff| per step:", ["%.2e" % d for d in diffs])
+        losses.append(float(loss))
+    diffs = [abs(a - b) for a, b in zip(losses, fx["loss"][:n])]
+    return losses, fx["loss"][:n], diffs
+
+
+def test_loss_trajectory_tiny_100_steps():
+    """100 optimizer steps with dropout 0.1 (shared counter-hash masks) and the reference's Adam(lr 1e-4) vs the fixture made
+    by the CPU oracle + torch.optim.Adam (tests/golden/make_trajectory.py).  bf16 bound: max |dloss| <= 3e-2 (see DESIGN.md
+    parity table for the measured figure)."""
+    losses, ref, diffs = _trajectory("traj_tiny_b4_s64_d0.1_lr0.0001.json")
+    print("tiny trajectory: max |d| %.3e mean |d| %.3e, final hip %.4f oracle %.4f" % (max(diffs), sum(diffs) / len(diffs), losses[-1], ref[-1]))
+    assert max(diffs) < 3e-2, diffs
+    assert losses[-1] < 0.5 * losses[0]            # and it actually trains
+
+
+def test_loss_trajectory_r50_full_size():
+    """BASELINE.json configs[1] shape (R50, 416x416, batch 8, L=17, dropout 0.1), first 20 steps of the oracle fixture."""
+    name = "traj_r50_b8_s416_d0.1_lr2e-06.json"
+    if not os.path.exists(os.path.join(GOLDEN, name)):
+        pytest.skip("fixture not generated")
+    losses, ref, diffs = _trajectory(name, max_steps=20)
+    print("r50 trajectory:", ["%.4f/%.4f" % (a, b) for a, b in zip(losses, ref)])
     assert max(diffs) < 3e-2, diffs

@@ -7,7 +7,7 @@ O=gpurun_out
 mkdir -p $O
 what="${1:-all}"
 if [[ "$what" == all || "$what" == *tests* ]]; then
-  timeout 900 python -m pytest tests -m gpu -q --timeout 600 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
+  timeout 900 python -m pytest tests -m gpu -q -s --timeout 600 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $O/pytest_gpu.log
   tail -15 $O/pytest_gpu.log
 fi
 if [[ "$what" == all || "$what" == *parity* ]]; then

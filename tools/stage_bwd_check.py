@@ -40,6 +40,15 @@ def rand_like(x, seed):
     return r16(torch.randn(x.shape, generator=torch.Generator().manual_seed(seed)))
 
 
+RESULTS = []          # (stage, what, rel, cos) rows collected by record()
+
+
+def record(stage, what, a, b):
+    r, c = rel(a, b), cos(a, b)
+    RESULTS.append((stage, what, r, c))
+    return r, c
+
+
 class Ctx:
     def __init__(self, spec, B, S, dropout=0.0):
         self.clip, head = arch.specs_by_name(spec)
@@ -68,12 +77,13 @@ class Ctx:
         torch.cuda.synchronize()
         out = []
         for what, a, b in pairs:
-            out.append("%s: rel %.2e cos %.5f" % (what, rel(a, b), cos(a, b)))
+            out.append("%s: rel %.2e cos %.5f" % ((what,) + record(name, what, a, b)))
         worst = (2.0, 0.0, "")
         n = 0
         for k, v in self.leaf.items():
             if k.startswith(prefix) and v.is_floating_point() and v.grad is not None and not k.endswith("k_proj.bias"):
                 c = cos(e.G[k], v.grad)
+                RESULTS.append((name, "param:" + k, rel(e.G[k], v.grad), c))
                 n += 1
                 if c < worst[0]:
                     worst = (c, rel(e.G[k], v.grad), k)
@@ -85,6 +95,7 @@ class Ctx:
 
 
 def main(spec="tiny", B=4, S=64):
+    del RESULTS[:]
     c = Ctx(spec, B, S)
     e, t = c.eng, c.taps
     v = "backbone.visual"
@@ -105,7 +116,7 @@ def main(spec="tiny", B=4, S=64):
         z = e._bottleneck(xa, "%s.%s" % (v, blk), planes, stride, has_ds)
         set_grad(z, gout)
         c.finish("bottleneck " + blk, [("out", nhwc_to_nchw(z), ref), ("dx", None, None)][:1] , "%s.%s" % (v, blk))
-        print("      dx: rel %.2e cos %.5f" % (rel(grad_nchw(xa), xl.grad), cos(grad_nchw(xa), xl.grad)))
+        print("      dx: rel %.2e cos %.5f" % record("bottleneck " + blk, "dx", grad_nchw(xa), xl.grad))
     # ---- attnpool
     c.begin()
     xl = r16(t["layer4"]).requires_grad_(True)
@@ -116,7 +127,7 @@ def main(spec="tiny", B=4, S=64):
     z = e._attnpool(xa, v + ".attnpool")
     set_grad(z, gout)
     c.finish("attnpool", [("out", nhwc_to_nchw(z), ref)], v + ".attnpool")
-    print("      dx: rel %.2e cos %.5f" % (rel(grad_nchw(xa), xl.grad), cos(grad_nchw(xa), xl.grad)))
+    print("      dx: rel %.2e cos %.5f" % record("attnpool", "dx", grad_nchw(xa), xl.grad))
     # ---- text encoder
     c.begin()
     wref, sref = O.encode_text(c.word, c.leaf, e.clip)
@@ -144,8 +155,8 @@ def main(spec="tiny", B=4, S=64):
     set_grad(z, gout)
     c.finish("fpn", [("out", nhwc_to_nchw(z), ref)], "neck")
     for nm, a, l in zip(("dv3", "dv4", "dv5"), acts, ins):
-        print("      %s: rel %.2e cos %.5f" % (nm, rel(grad_nchw(a), l.grad), cos(grad_nchw(a), l.grad)))
-    print("      dstate: rel %.2e cos %.5f" % (rel(st.g.float(), ins[3].grad), cos(st.g.float(), ins[3].grad)))
+        print("      %s: rel %.2e cos %.5f" % ((nm,) + record("fpn", nm, grad_nchw(a), l.grad)))
+    print("      dstate: rel %.2e cos %.5f" % record("fpn", "dstate", st.g.float(), ins[3].grad))
     # ---- decoder (with dropout masks from the shared hash)
     for dp in (0.0, 0.1):
         c2 = Ctx(spec, B, S, dropout=dp) if dp > 0 else c
@@ -163,8 +174,8 @@ def main(spec="tiny", B=4, S=64):
         z = e2._decoder(fa, ta, c2.word.to(DEV))
         set_grad(z, gout)
         c2.finish("decoder p=%g" % dp, [("out", nhwc_to_nchw(z), ref)], "decoder")
-        print("      dfq: rel %.2e cos %.5f ; dtxt: rel %.2e cos %.5f" % (rel(grad_nchw(fa), fql.grad), cos(grad_nchw(fa), fql.grad),
-                                                                      rel(ta.g.float().view(wl.shape), wl.grad), cos(ta.g.float().view(wl.shape), wl.grad)))
+        print("      dfq: rel %.2e cos %.5f ; dtxt: rel %.2e cos %.5f" % (record("decoder p=%g" % dp, "dfq", grad_nchw(fa), fql.grad)
+                                                                      + record("decoder p=%g" % dp, "dtxt", ta.g.float().view(wl.shape), wl.grad)))
     # ---- projector + loss
     c.begin()
     fql = r16(t["fq_dec"]).requires_grad_(True)
@@ -192,8 +203,9 @@ def main(spec="tiny", B=4, S=64):
         ops.dynconv_bwd(x.t, dpred, B, OH, OW, cc, wb.t, gx, e._dwb)
     e.tape.append(bwd_loss)
     c.finish("projector+loss", [("pred", pred, pref), ("loss", loss, lref.detach().view(1))], "proj")
-    print("      dfq: rel %.2e cos %.5f ; dstate: rel %.2e cos %.5f" % (rel(grad_nchw(fa), fql.grad), cos(grad_nchw(fa), fql.grad),
-                                                                        rel(st.g.float(), sl.grad), cos(st.g.float(), sl.grad)))
+    print("      dfq: rel %.2e cos %.5f ; dstate: rel %.2e cos %.5f" % (record("projector+loss", "dfq", grad_nchw(fa), fql.grad)
+                                                                        + record("projector+loss", "dstate", st.g.float(), sl.grad)))
+    return RESULTS
 
 
 if __name__ == "__main__":
