@@ -56,6 +56,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--shape-table", default=None, help="write the per-shape GEMM timing table (tsv) here")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,6 +138,14 @@ def main():
                                "share_of_step": d["ms"] / (1000.0 * dt)}
             out["kernels"] = {k: {"ms_per_step": v["ms"] / args.steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                   "launches_per_step": v["launches"] / args.steps} for k, v in summ.items()}
+        if timer is not None and args.shape_table:
+            rows = sorted(timer.by_shape().items(), key=lambda kv: -kv[1]["ms"])
+            with open(args.shape_table, "w") as f:
+                f.write("kernel\tshape\tlaunches/step\tms/step\tus/launch\tTFLOP/s\talgGB/s\n")
+                for (kn, tag), v in rows:
+                    f.write("%s\t%s\t%.1f\t%.3f\t%.1f\t%.1f\t%.0f\n" % (
+                        kn, tag, v["launches"] / args.steps, v["ms"] / args.steps, 1e3 * v["ms"] / v["launches"],
+                        v["flops"] / (v["ms"] * 1e-3) / 1e12, v["bytes"] / (v["ms"] * 1e-3) / 1e9))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.spec, args.batch, args.size, head.word_len, min(os.cpu_count() or 1, 64))
         print(json.dumps(out))

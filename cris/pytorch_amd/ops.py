@@ -107,7 +107,8 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.launch("conv_gemm_n128" if N > 64 else "conv_gemm_n64", 2.0 * g.M * N * g.K,
-                            2.0 * (g.M * g.C * (1 if g.KH == 1 else 1) + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p))
+                            2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p),
+                            tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
         return
     hip.call("cris_conv_gemm", C.byref(p), _stream())
 
@@ -118,17 +119,28 @@ class KernelTimer:
     def __init__(self):
         self.records = []        # (name, flops, bytes, start_event, end_event)
 
-    def launch(self, name, flops, nbytes, fn, *args):
+    def launch(self, name, flops, nbytes, fn, *args, tag=""):
         s = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
         hip.call(fn, *args, s.cuda_stream)
         e1.record(s)
-        self.records.append((name, flops, nbytes, e0, e1))
+        self.records.append((name, flops, nbytes, e0, e1, tag))
+
+    def by_shape(self):
+        """{(kernel, shape tag): {launches, ms, flops, bytes}} - which problem shapes the time goes to"""
+        out = {}
+        for name, fl, nb, e0, e1, tag in self.records:
+            d = out.setdefault((name, tag), dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += nb
+        return out
 
     def summary(self):
         out = {}
-        for name, fl, nb, e0, e1 in self.records:
+        for name, fl, nb, e0, e1, _ in self.records:
             d = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += e0.elapsed_time(e1)
@@ -161,7 +173,8 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
     p.C_real = C_real if C_real is not None else g.C
     p.splits = splits if splits is not None else wgrad_splits(g.M, N, g.K)
     if KERNEL_TIMER is not None:
-        KERNEL_TIMER.launch("conv_wgrad", 2.0 * g.M * N * g.K, 2.0 * (g.M * N + g.M * g.C) + 4.0 * N * g.K, "cris_conv_wgrad", C.byref(p))
+        KERNEL_TIMER.launch("conv_wgrad", 2.0 * g.M * N * g.K, 2.0 * (g.M * N + g.M * g.C) + 4.0 * N * g.K, "cris_conv_wgrad", C.byref(p),
+                            tag="M%d N%d K%d k%d s%d" % (g.M, N, g.K, g.KH, p.splits))
         return
     hip.call("cris_conv_wgrad", C.byref(p), _stream())
 
