@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const cris_attn_params p)
     const int64_t* toks = p.key_tokens ? p.key_tokens + (size_t)b * p.Lk : nullptr;
 
     const bool has_drop = p.drop_thresh > 0u;
-    const uint32_t dkey = cris_drop_key(p.drop_seed, p.drop_stream);
+    const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const float inv_keep = has_drop ? 1.f / (1.f - p.drop_p) : 1.f;
     const uint32_t didx0 = ((uint32_t)bh * (uint32_t)p.Lq + (uint32_t)q) * (uint32_t)p.Lk;
 
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const cris_attn_params
     const bf16_t* Kt = p.Kt + (size_t)bh * 64 * p.Lk_pad;
     const int64_t* toks = p.key_tokens ? p.key_tokens + (size_t)b * p.Lk : nullptr;
     const bool has_drop = p.drop_thresh > 0u;
-    const uint32_t dkey = cris_drop_key(p.drop_seed, p.drop_stream);
+    const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const float inv_keep = has_drop ? 1.f / (1.f - p.drop_p) : 1.f;
     const uint32_t didx0 = ((uint32_t)bh * (uint32_t)p.Lq + (uint32_t)q) * (uint32_t)p.Lk;
 
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const cris_attn_param
     const float* lsep = p.lse + (size_t)bh * p.Lq;
     const float* delp = p.delta + (size_t)bh * p.Lq;
     const bool has_drop = p.drop_thresh > 0u;
-    const uint32_t dkey = cris_drop_key(p.drop_seed, p.drop_stream);
+    const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const float inv_keep = has_drop ? 1.f / (1.f - p.drop_p) : 1.f;
 
     f32x4 dk[4], dv[4];

@@ -360,7 +360,9 @@ extern "C" int cris_quickgelu_bwd(const cris_bf16* x, const cris_bf16* dy, cris_
     return 0;
 }
 // y(bf16) = dropout_mask(idx) ? x * 1/(1-p) : 0  (gradient of an output dropout applied to an fp32 stream)
-__global__ void cast_drop_kernel(const float* x, bf16_t* y, long n, float scale, uint32_t thresh, uint32_t key) {
+__global__ void cast_drop_kernel(const float* x, bf16_t* y, long n, float scale, uint32_t thresh, uint32_t seed, uint32_t stream_id,
+                                 const uint32_t* seed_dev) {
+    const uint32_t key = cris_drop_key(seed + (seed_dev ? seed_dev[0] : 0u), stream_id);
     GRID_STRIDE(i, n) {
         float v = x[i];
         if (thresh) v = cris_keep(key, (uint32_t)i, thresh) ? v * scale : 0.f;
@@ -368,11 +370,22 @@ __global__ void cast_drop_kernel(const float* x, bf16_t* y, long n, float scale,
     }
 }
 extern "C" int cris_cast_f32_bf16_drop(const float* x, cris_bf16* y, long n, float drop_p, uint32_t drop_thresh, uint32_t seed,
-                                       uint32_t stream_id, void* stream) {
+                                       uint32_t stream_id, const uint32_t* seed_dev, void* stream) {
     CRIS_CHECK_ARG(x && y && n > 0 && n < (1L << 32), "bad args");
     const float scale = drop_thresh ? 1.f / (1.f - drop_p) : 1.f;
     hipLaunchKernelGGL(cast_drop_kernel, dim3(cris_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, x, y, n, scale, drop_thresh,
-                       seed ^ (stream_id * 0x9E3779B9u));
+                       seed, stream_id, seed_dev);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+__global__ void step_advance_kernel(int* step, uint32_t* seed) {
+    const int s = step[0] + 1;
+    step[0] = s;
+    seed[0] = (uint32_t)s * 7919u + 17u;
+}
+extern "C" int cris_step_advance(int32_t* step, uint32_t* seed, void* stream) {
+    CRIS_CHECK_ARG(step && seed, "bad args");
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, seed);
     CRIS_LAUNCH_CHECK();
     return 0;
 }
@@ -744,7 +757,12 @@ extern "C" int cris_train_metric(const float* logits, const float* target, int B
 // ------------------------------------------------------------------------------------------------
 #define ADAM_ELEMS 8192
 __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restrict__ tab, int n_desc, float beta1, float beta2, float eps,
-                                                   float wd, float bc1, float bc2, float gscale) {
+                                                   float wd, float bc1, float bc2, float gscale, const int* __restrict__ step_dev) {
+    if (step_dev) {                       // step count lives on the device (HIP-graph replay): bias corrections from it
+        const float t = (float)step_dev[0];
+        bc1 = 1.f - __powf(beta1, t);
+        bc2 = 1.f - __powf(beta2, t);
+    }
     int lo = 0, hi = n_desc - 1;
     const int bid = blockIdx.x;
     while (lo < hi) {
@@ -758,7 +776,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restr
     for (int e = threadIdx.x; e < ADAM_ELEMS; e += 256) {
         const long i = base + e;
         if (i >= d.n) break;
-        float g = d.g[i] * gscale;
+        long gi = i;
+        if (d.taps > 0) {                 // gradient kept in the GEMM layout [n][tap][cpad] (cris_conv_wgrad)
+            const long per_n = (long)d.cin * d.taps;
+            const long n = i / per_n;
+            const int r = (int)(i - n * per_n);
+            const int c = r / d.taps, tap = r - c * d.taps;
+            gi = (n * d.taps + tap) * d.cpad + c;
+        }
+        float g = d.g[gi] * gscale;
         float p = d.p[i];
         if (wd != 0.f) g += wd * p;
         const float m = beta1 * d.m[i] + (1.f - beta1) * g;
@@ -770,10 +796,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restr
 }
 extern "C" int cris_adam_block_elems(void) { return ADAM_ELEMS; }
 extern "C" int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
-                              float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream) {
+                              float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
+                              void* stream) {
     CRIS_CHECK_ARG(dev_table && n_desc > 0 && total_blocks > 0, "empty table");
     hipLaunchKernelGGL(adam_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dev_table, n_desc, beta1, beta2, eps,
-                       weight_decay, bias_corr1, bias_corr2, grad_scale);
+                       weight_decay, bias_corr1, bias_corr2, grad_scale, step_dev);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

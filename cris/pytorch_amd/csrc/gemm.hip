@@ -1,20 +1,29 @@
 // Implicit-GEMM convolution / linear (forward and input-gradient) and weight-gradient kernels for gfx950.
 //
 // Forward: out[M,N] = A_im2col[M,K] * Wt[N,K]^T, bf16 operands, v_mfma_f32_16x16x32_bf16, fp32 accumulate.
-//   tile 128 x BN x 64 (BN = 128: 2x2 waves of 64x64; BN = 64: 4x1 waves of 32x64), 256 threads,
-//   register-staged global->LDS double buffer (the im2col gather + zero fill needs per-lane addresses,
-//   so LDS-DMA is not used), LDS rows of 128 B with the 16-byte chunk index XOR-swizzled by (row>>1)&7 so
-//   that ds_read_b128 fragment reads of 16 consecutive rows hit 16 distinct 16-B slots (conflict free,
-//   see MI355X_MICROARCH.md section LDS), XCD-aware tile order (consecutive tiles of one XCD share the A panel).
+//   tiles 128x128 / 64x128 / 128x64 (x 64 in K), 256 threads; operands go HBM/L2 -> LDS by LDS-DMA
+//   (global_load_lds_dwordx4; the im2col gather and the zero fill are per-lane SOURCE addresses, the LDS image stays
+//   lane-linear) through a 3-4 deep ring with counted vmcnt + one raw barrier per K-step; LDS rows of 128 B with the
+//   16-byte chunk index XOR-swizzled by (row>>1)&7 so that ds_read_b128 fragment reads of 16 consecutive rows hit 16
+//   distinct 16-B slots (conflict free, see MI355X_MICROARCH.md section LDS); XCD-aware tile order (consecutive tiles
+//   of one XCD share the A panel).  M <= 144 linear problems (text encoder, per-sample vectors) take a latency-oriented
+//   kernel: no staging, K split over the waves.
 // Wgrad: dW[N,K] = dY[M,N]^T * X_im2col[M,K]; the reduction dim (pixels) is the strided one for both
 //   operands, so each thread loads 8 rows x 16 B, transposes the 8x8 bf16 block in registers and writes
-//   m-contiguous 16-B chunks to LDS ([n][128 m] / [k][128 m], chunk XOR (row&15)); split over m with fp32
-//   atomics straight into the parameter-layout gradient.
+//   m-contiguous 16-B chunks to LDS ([n][128 m] / [k][128 m], chunk XOR (row&15)); the gradient is kept in the GEMM
+//   layout [n][tap*C + c] (coalesced 64-B runs; the optimizer / cris_unpack_grads map it back to [n][c][tap]);
+//   split over m only as far as needed to fill the chip, fp32 atomics when split, plain stores otherwise.
 #include "common.h"
 #include "../../../include/cris_hip.h"
 
-#define BM 128
 #define BK 64
+#define SKINNY_MAX_M 144      // M <= this and a 1x1 geometry -> skinny kernel (no LDS staging, K split over the waves)
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+#define CRIS_BUF_FLAGS 0x00020000          // V# dword 3 for raw (stride 0) buffers on gfx9 / CDNA
+#define CRIS_OOB 0x80000000u               // byte offset beyond every descriptor used here (extents are < 2 GiB): reads as 0
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+#define CRIS_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | ((((N) >> 4) & 3) << 14) | (0x7 << 4) | (0xF << 8))
 
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
@@ -23,161 +32,28 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; 
     return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_params p) {
-    constexpr int WTM = BM / WAVES_M;          // wave tile rows
-    constexpr int WTN = BN / WAVES_N;
-    constexpr int FM = WTM / 16;
-    constexpr int FN = WTN / 16;
-    constexpr int NA = BM * 8 / 256;           // 16-B vectors per thread per K step (A)
-    constexpr int NB = BN * 8 / 256;
-    constexpr int A_BYTES = BM * 128;
-    constexpr int B_BYTES = BN * 128;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (A_BYTES + B_BYTES)];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63;
-    const int wave = t >> 6;
-    const int wm = wave / WAVES_N;
-    const int wn = wave % WAVES_N;
-
-    // XCD-aware tile order: blocks b, b+8, b+16.. run on the same XCD (observed round-robin); give each
-    // XCD a contiguous run of tiles, n fastest, so its L2 keeps one A panel and sweeps the weights.
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int tile_m = bid / tiles_n;
-    const int tile_n = bid - tile_m * tiles_n;
-    const int m0 = tile_m * BM;
-    const int n0 = tile_n * BN;
-
-    // ---- per-thread A row decomposition (constant over the K loop) ----
-    const int kc = t & 7;                      // 16-B chunk (8 channels) inside the 64-wide K step
-    const int lrow = t >> 3;                   // 0..31
-    const int OHW = p.OH * p.OW;
-    int a_pix[NA], a_ih[NA], a_iw[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int m = m0 + lrow + 32 * i;
-        if (m < p.M) {
-            const int b = m / OHW;
-            const int r = m - b * OHW;
-            const int oh = r / p.OW;
-            const int ow = r - oh * p.OW;
-            a_pix[i] = b * p.H * p.W;
-            a_ih[i] = oh * p.stride - p.pad;
-            a_iw[i] = ow * p.stride - p.pad;
-        } else {
-            a_pix[i] = 0; a_ih[i] = -(1 << 28); a_iw[i] = 0;       // never in range -> zeros
-        }
-    }
-    // running (tap, c) of this thread's chunk
-    int kcur = kc * 8;
-    int c_cur = kcur % p.C;
-    int tap = kcur / p.C;
-    int kh = tap / p.KW;
-    int kw = tap - kh * p.KW;
-
-    uint4 ra[NA], rb[NB];
-    auto load_tile = [&]() {
-        const bool kvalid = kcur < p.K;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int ih = a_ih[i] + kh, iw = a_iw[i] + kw;
-            if (kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W) {
-                const size_t off = (size_t)(a_pix[i] + ih * p.W + iw) * p.lda + p.a_coff + c_cur;
-                v = *reinterpret_cast<const uint4*>(p.A + off);
-            }
-            ra[i] = v;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            const int n = n0 + lrow + 32 * i;
-            if (kvalid && n < p.N) v = *reinterpret_cast<const uint4*>(p.Wt + (size_t)n * p.ldb + kcur);
-            rb[i] = v;
-        }
-        // advance to the next K step
-        kcur += BK;
-        c_cur += BK;
-        while (c_cur >= p.C) {
-            c_cur -= p.C;
-            if (++kw == p.KW) { kw = 0; ++kh; }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
-        unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) *reinterpret_cast<uint4*>(sa + lds_off(lrow + 32 * i, kc)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<uint4*>(sb + lds_off(lrow + 32 * i, kc)) = rb[i];
-    };
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile();
-    store_tile(0);
-    __syncthreads();
+// Epilogue of one wave tile (FM x FN fragments of 16x16, C/D layout col = lane&15, row = (lane>>4)*4 + r) whose first
+// row / column are row0 / col0: bias, activation, dropout, residual, bf16|fp32 store, head-split transposed copy and the
+// BatchNorm statistics partial `part` (sum, M2 about the part mean over the FM*16 rows of this wave tile).
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, f32x4 (&acc)[FM][FN], int row0, int col0, int part,
+                                              int lane) {
     const int fr = lane & 15, fg = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile();
-        const unsigned char* sa = smem + buf * (A_BYTES + B_BYTES);
-        const unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[FM], bfr[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int row = wm * WTM + i * 16 + fr;
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(row, ks * 4 + fg));
-            }
-#pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int row = wn * WTN + j * 16 + fr;
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(row, ks * 4 + fg));
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + r ----
     const bool has_drop = p.drop_thresh > 0u;
-    const uint32_t dkey = cris_drop_key(p.drop_seed, p.drop_stream);
+    const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const uint32_t dthr = p.drop_thresh;
     const float dscale = has_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const int Hh = p.outT ? p.T_E / 64 : 1;
-    const int part = tile_m * WAVES_M + wm;                  // statistics partial index (one per wave row-block)
-    const int part_row0 = m0 + wm * WTM;
-    const int part_cnt = max(0, min(WTM, p.M - part_row0));
+    const int part_cnt = max(0, min(FM * 16, p.M - row0));
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int col = n0 + wn * WTN + j * 16 + fr;
+        const int col = col0 + j * 16 + fr;
         const bool cvalid = col < p.N;
         const float bias = (p.bias && cvalid) ? p.bias[col] : 0.f;
         float vals[FM][4];
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int rowb = m0 + wm * WTM + i * 16 + fg * 4;
+            const int rowb = row0 + i * 16 + fg * 4;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -240,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * WTM + i * 16 + fg * 4 + r;
+                    const int m = row0 + i * 16 + fg * 4 + r;
                     const float d = vals[i][r] - mu;
                     q += (m < p.M) ? d * d : 0.f;
                 }
@@ -254,7 +130,248 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     }
 }
 
-extern "C" int cris_conv_gemm_stat_rows(int N) { return N <= 64 ? BM / 4 : BM / 2; }
+// Main kernel: BM x BN x 64 tiles, 4 waves, operands staged by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave
+// instruction = 8 tile rows of 128 B) into a ring of STAGES LDS buffers with STAGES-1 K-steps in flight: one counted
+// s_waitcnt vmcnt + one raw s_barrier per K-step, never a full drain inside the loop.  The LDS image is lane-linear
+// (DMA rule), so the XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is applied on the SOURCE side:
+// the lane that lands on 16-B slot `cpos` of row r fetches logical K-chunk cpos ^ ((r>>1)&7) - a permutation inside one
+// 128-B row, so global coalescing is unchanged.  The DMAs are buffer loads (buffer_load_dwordx4 ... lds) through raw
+// descriptors over the activation / weight extents: zero fill (spatial padding, M / N / K tails) = an out-of-range byte
+// offset, which the hardware returns as 0 - a branch-free per-lane select, so every wave issues exactly NA + NB DMAs per
+// K-step and the counted vmcnt below is exact.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_params p) {
+    constexpr int WTM = BM / WAVES_M;          // wave tile rows
+    constexpr int WTN = BN / WAVES_N;
+    constexpr int FM = WTM / 16;
+    constexpr int FN = WTN / 16;
+    constexpr int NA = BM / 32;                // DMA instructions per wave per K-step (A): 8 rows each, 4 waves
+    constexpr int NB = BN / 32;
+    constexpr int A_BYTES = BM * 128;
+    constexpr int STAGE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WAVES_N;
+    const int wn = wave % WAVES_N;
+
+    // XCD-aware tile order: blocks b, b+8, b+16.. run on the same XCD (round-robin dispatch); give each XCD a
+    // contiguous run of tiles, n fastest, so its L2 keeps one A panel and sweeps the weights.
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n;
+    const int tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- this lane's DMA role: rows (wave + 4j)*8 + (lane>>3), LDS slot lane&7, logical K-chunk kc ----
+    const int rsub = lane >> 3;
+    const int kc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);       // == (lane&7) ^ ((row>>1)&7) for every j
+    const int OHW = p.OH * p.OW;
+    int a_pix[NA], a_ih[NA], a_iw[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + (wave + 4 * i) * 8 + rsub;
+        if (m < p.M) {
+            const int b = m / OHW;
+            const int r = m - b * OHW;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            a_pix[i] = b * p.H * p.W;
+            a_ih[i] = oh * p.stride - p.pad;
+            a_iw[i] = ow * p.stride - p.pad;
+        } else {
+            a_pix[i] = 0; a_ih[i] = -(1 << 28); a_iw[i] = 0;       // never in range -> zeros
+        }
+    }
+    unsigned b_off[NB];                        // byte offset of this lane's weight rows (rows >= N are out of range -> 0)
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_off[i] = (unsigned)(n0 + (wave + 4 * i) * 8 + rsub) * (unsigned)p.ldb * 2u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.A), 0, (int)((size_t)p.Bn * p.H * p.W * p.lda * 2), CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.Wt), 0, (int)((size_t)p.N * p.ldb * 2), CRIS_BUF_FLAGS);
+    // running (tap, c) of this lane's chunk
+    int kcur = kc * 8;
+    int c_cur = kcur % p.C;
+    int tap = kcur / p.C;
+    int kh = tap / p.KW;
+    int kw = tap - kh * p.KW;
+
+    auto issue_stage = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE_BYTES + wave * 1024;          // wave-uniform LDS base of DMA j: + j*4096
+        unsigned char* sb = sa + A_BYTES;
+        const bool kvalid = kcur < p.K;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int ih = a_ih[i] + kh, iw = a_iw[i] + kw;
+            const bool ok = kvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned off = ((unsigned)(a_pix[i] + ih * p.W + iw) * (unsigned)p.lda + (unsigned)(p.a_coff + c_cur)) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sa + i * 4096), 16, ok ? off : CRIS_OOB, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const unsigned off = b_off[i] + (unsigned)kcur * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + i * 4096), 16, kvalid ? off : CRIS_OOB, 0, 0, 0);
+        }
+        // advance to the next K step
+        kcur += BK;
+        c_cur += BK;
+        while (c_cur >= p.C) {
+            c_cur -= p.C;
+            if (++kw == p.KW) { kw = 0; ++kh; }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (p.K + BK - 1) / BK;
+    // prologue: STAGES-1 K-steps in flight (steps beyond nk read zeros: keeps the vmcnt arithmetic uniform)
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue_stage(s);
+    const int fr = lane & 15, fg = lane >> 4;
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        CRIS_VMCNT((STAGES - 2) * (NA + NB));       // this wave's share of K-step kt has landed ...
+        __builtin_amdgcn_s_barrier();               // ... and everyone's; everyone is also done reading step kt-1
+        {
+            int nb = buf + STAGES - 1;
+            if (nb >= STAGES) nb -= STAGES;
+            issue_stage(nb);                        // refill the buffer of step kt-1 with step kt+STAGES-1
+        }
+        const unsigned char* sa = smem + buf * STAGE_BYTES;
+        const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[FM], bfr[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int row = wm * WTM + i * 16 + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(row, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wn * WTN + j * 16 + fr;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(row, ks * 4 + fg));
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // keep this step's LDS reads / MFMAs ahead of the next barrier
+        if (++buf == STAGES) buf = 0;
+    }
+    CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
+
+    gemm_epilogue<FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
+}
+
+// Skinny kernel (M <= FM*16 rows, 1x1 geometry: text encoder / per-sample vectors).  Such GEMMs are pure latency: one
+// block owns all rows x 32 columns and its 4 waves split K (interleaved 32-wide chunks, so the block reads contiguous
+// 256-B runs), fragments loaded straight from L2 into registers (no LDS staging, no barrier in the loop), partial
+// accumulators reduced through LDS, full epilogue by wave 0.
+template <int FM>
+__global__ __launch_bounds__(256) void skinny_gemm_kernel(const cris_conv_gemm_params p) {
+    constexpr int FN = 2;
+    __shared__ float red[3][FM * FN * 4][64];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n0 = blockIdx.x * (FN * 16);
+    const bf16_t* arow[FM];
+    const bf16_t* brow[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = i * 16 + fr;
+        arow[i] = m < p.M ? p.A + (size_t)m * p.lda + p.a_coff : nullptr;
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + j * 16 + fr;
+        brow[j] = n < p.N ? p.Wt + (size_t)n * p.ldb : nullptr;
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const uint4 z = make_uint4(0, 0, 0, 0);
+    for (int kb = wave * 32; kb < p.K; kb += 128) {                 // wave-uniform trip count (MFMA ignores EXEC)
+        const int k = kb + fg * 8;
+        const bool kv = k < p.K;                                     // K % 8 == 0: a chunk is either whole or absent
+        uint4 av[FM], bv[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) av[i] = (kv && arow[i]) ? *reinterpret_cast<const uint4*>(arow[i] + k) : z;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bv[j] = (kv && brow[j]) ? *reinterpret_cast<const uint4*>(brow[j] + k) : z;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]),
+                                                                    acc[i][j], 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) red[wave - 1][(i * FN + j) * 4 + r][lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[i][j][r] += red[0][(i * FN + j) * 4 + r][lane] + red[1][(i * FN + j) * 4 + r][lane] +
+                                    red[2][(i * FN + j) * 4 + r][lane];
+        gemm_epilogue<FM, FN>(p, acc, 0, n0, 0, lane);
+    }
+}
+
+// tile selection (host).  Returns the rows per BatchNorm-statistics partial of the chosen variant.
+enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x128, V_128x128 };
+static int pick_variant(const cris_conv_gemm_params& p) {
+    const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
+    if (lin && p.M <= 16) return V_SKINNY1;
+    if (lin && p.M <= SKINNY_MAX_M) return V_SKINNY9;
+    if (p.N <= 64) return V_128x64;
+    // fewer than ~1.75 tiles per CU at 128x128: halve the tile (2 blocks of 72 KB LDS fit a CU)
+    if ((long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128) < 448) return V_64x128;
+    return V_128x128;
+}
+static int variant_stat_rows(int v) {
+    switch (v) {
+        case V_SKINNY1: return 16;
+        case V_SKINNY9: return SKINNY_MAX_M;
+        case V_128x128: return 64;
+        default: return 32;
+    }
+}
+extern "C" int cris_conv_gemm_stat_rows(const cris_conv_gemm_params* p) { return variant_stat_rows(pick_variant(*p)); }
+
+static int set_lds(const void* kern, int bytes) {
+    return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     const cris_conv_gemm_params& p = *pp;
@@ -269,14 +386,37 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
                    "bad transposed-store geometry");
     CRIS_CHECK_ARG((uintptr_t)p.A % 16 == 0 && (uintptr_t)p.Wt % 16 == 0, "operands must be 16-byte aligned");
     CRIS_CHECK_ARG((long)p.M * p.N < (1L << 32) || p.drop_thresh == 0u, "dropout index overflow");
-    const int tiles_m = cris_cdiv(p.M, BM);
+    CRIS_CHECK_ARG((size_t)p.Bn * p.H * p.W * p.lda * 2 < (1UL << 31) && ((size_t)p.N + 256) * p.ldb * 2 < (1UL << 31),
+                   "operand extent must stay below 2 GiB (32-bit buffer offsets)");
     hipStream_t s = (hipStream_t)stream;
-    if (p.N <= 64) {
-        const int tiles_n = cris_cdiv(p.N, 64);
-        hipLaunchKernelGGL((conv_gemm_kernel<64, 4, 1>), dim3(tiles_m * tiles_n), dim3(256), 0, s, p);
-    } else {
-        const int tiles_n = cris_cdiv(p.N, 128);
-        hipLaunchKernelGGL((conv_gemm_kernel<128, 2, 2>), dim3(tiles_m * tiles_n), dim3(256), 0, s, p);
+    constexpr int LDS_128x64 = 4 * (128 + 64) * 128, LDS_64x128 = 3 * (64 + 128) * 128, LDS_128x128 = 4 * (128 + 128) * 128;
+    void (*const k_128x64)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 64, 4, 1, 4>;
+    void (*const k_64x128)(const cris_conv_gemm_params) = conv_gemm_kernel<64, 128, 2, 2, 3>;
+    void (*const k_128x128)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 128, 2, 2, 4>;
+    static const int lds_ready = set_lds((const void*)k_128x64, LDS_128x64) | set_lds((const void*)k_64x128, LDS_64x128) |
+                                 set_lds((const void*)k_128x128, LDS_128x128);
+    if (lds_ready != 0) {
+        cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, lds_ready);
+        return lds_ready;
+    }
+    switch (pick_variant(p)) {
+        case V_SKINNY1:
+            hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(256), 0, s, p);
+            break;
+        case V_SKINNY9:
+            hipLaunchKernelGGL(skinny_gemm_kernel<9>, dim3(cris_cdiv(p.N, 32)), dim3(256), 0, s, p);
+            break;
+        case V_128x64:
+            hipLaunchKernelGGL(k_128x64, dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256),
+                               LDS_128x64, s, p);
+            break;
+        case V_64x128:
+            hipLaunchKernelGGL(k_64x128, dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256),
+                               LDS_64x128, s, p);
+            break;
+        default:
+            hipLaunchKernelGGL(k_128x128, dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128)), dim3(256),
+                               LDS_128x128, s, p);
     }
     CRIS_LAUNCH_CHECK();
     return 0;
@@ -394,20 +534,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
         __syncthreads();
     }
 
-    const int taps = p.KH * p.KW;
+    // epilogue: GEMM-layout gradient dW[n][k] (k contiguous: the 16 lanes of a fragment row hit 64 contiguous bytes);
+    // plain stores when this block owns the whole reduction, fp32 atomics otherwise
+    const bool single = p.splits == 1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int k = k0 + wc * 64 + j * 16 + fr;
-        if (k >= p.K) continue;
-        const int tp = k / p.C;
-        const int c = k - tp * p.C;
-        if (c >= p.C_real) continue;
+    for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int r = 0; r < 4; ++r) {
+            const int n = n0 + wr * 64 + i * 16 + fg * 4 + r;
+            if (n >= p.N) continue;
+            float* row = p.dW + (size_t)n * p.ldw;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wr * 64 + i * 16 + fg * 4 + r;
-                if (n < p.N) atomicAdd(p.dW + ((size_t)n * p.C_real + c) * taps + tp, acc[i][j][r]);
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + wc * 64 + j * 16 + fr;
+                if (k >= p.K) continue;
+                if (single) row[k] = acc[i][j][r];
+                else atomicAdd(row + k, acc[i][j][r]);
             }
         }
     }
@@ -420,7 +562,7 @@ extern "C" int cris_conv_wgrad(const cris_wgrad_params* pp, void* stream) {
     CRIS_CHECK_ARG((p.C & 7) == 0 && (p.ldx & 7) == 0 && (p.x_coff & 7) == 0, "X channels/ld/offset must be multiples of 8");
     CRIS_CHECK_ARG((p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && (p.N_ld & 7) == 0 && p.N_ld >= p.N, "dY ld/offset/N_ld");
     CRIS_CHECK_ARG(p.K == p.KH * p.KW * p.C && p.M == p.Bn * p.OH * p.OW, "geometry");
-    CRIS_CHECK_ARG(p.C_real > 0 && p.C_real <= p.C, "C_real");
+    CRIS_CHECK_ARG(p.ldw >= p.K, "ldw < K");
     dim3 grid(cris_cdiv(p.K, WG_T), cris_cdiv(p.N, WG_T), p.splits);
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();

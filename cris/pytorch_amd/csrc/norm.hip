@@ -500,8 +500,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const cris_ln_fwd_params p)
     const int lane = threadIdx.x & 63;
     const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
-    const uint32_t in_key = cris_drop_key(p.in_seed, p.in_stream);
-    const uint32_t out_key = cris_drop_key(p.out_seed, p.out_stream);
+    const uint32_t sdev = p.seed_dev ? p.seed_dev[0] : 0u;
+    const uint32_t in_key = cris_drop_key(p.in_seed + sdev, p.in_stream);
+    const uint32_t out_key = cris_drop_key(p.out_seed + sdev, p.out_stream);
     const float in_scale = p.in_thresh ? 1.f / (1.f - p.in_drop_p) : 1.f;
     const float out_scale = p.out_thresh ? 1.f / (1.f - p.out_drop_p) : 1.f;
     const float invC = 1.f / (float)p.C;
@@ -589,8 +590,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p)
     const int nwaves = gridDim.x * 4;
     for (int i = threadIdx.x; i < 2 * 64 * 8 * LN_MAXV; i += 256) (&sg[0][0])[i] = 0.f;
     __syncthreads();
-    const uint32_t in_key = cris_drop_key(p.in_seed, p.in_stream);
-    const uint32_t out_key = cris_drop_key(p.out_seed, p.out_stream);
+    const uint32_t sdev = p.seed_dev ? p.seed_dev[0] : 0u;
+    const uint32_t in_key = cris_drop_key(p.in_seed + sdev, p.in_stream);
+    const uint32_t out_key = cris_drop_key(p.out_seed + sdev, p.out_stream);
     const float in_scale = p.in_thresh ? 1.f / (1.f - p.in_drop_p) : 1.f;
     const float out_scale = p.out_thresh ? 1.f / (1.f - p.out_drop_p) : 1.f;
     const float invC = 1.f / (float)p.C;

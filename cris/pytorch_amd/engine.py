@@ -78,6 +78,7 @@ class Engine:
         self.tape: List[Callable[[], None]] = []
         self.training = True
         self.seed = 0
+        self.seed_dev = None            # optional device word added to every dropout seed (graph replay: trainer.py)
         self._tables = {}
         self._build_grad_arena()
         self._build_packs()
@@ -85,6 +86,28 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # parameter-side setup
     # ------------------------------------------------------------------------------------------
+    def gemm_layout(self, name):
+        """(N, Cin, taps, Cpad) of a weight that runs through the GEMM kernels, or None.  Its gradient is kept in the
+        GEMM layout [N][taps*Cpad] (k = tap*Cpad + c), which for taps == 1 and Cpad == Cin IS the parameter layout."""
+        p = self.P[name]
+        if name == "backbone.visual.conv1.weight":
+            return p.shape[0], 27, 1, 32                     # stem: im2col'd, k = ci*9 + kh*3 + kw (parameter order)
+        if p.dim() == 4:
+            return p.shape[0], p.shape[1], p.shape[2] * p.shape[3], pad8(p.shape[1])
+        return None
+
+    def grad_param_layout(self, name):
+        """Gradient of `name` as a tensor shaped like the parameter (a relayout copy for 3x3 / padded convolutions; used by
+        tests, tools and checkpoint-style export - the optimizer reads the GEMM layout directly)."""
+        g, lay = self.G[name], self.gemm_layout(name)
+        if lay is None or (lay[2] == 1 and lay[3] == lay[1]):
+            return g.view(self.P[name].shape)
+        N, Cin, taps, Cpad = lay
+        return g.view(N, taps, Cpad)[:, :, :Cin].permute(0, 2, 1).reshape(self.P[name].shape)
+
+    def grads_param_layout(self):
+        return {k: self.grad_param_layout(k) for k in self.G}
+
     def _build_grad_arena(self):
         """One flat fp32 gradient arena; BatchNorm blocks are laid out [dbeta | dgamma] (and
         [bn3 | downsample.1] pairs contiguous) so bn_bwd_reduce accumulates straight into them."""
@@ -122,13 +145,17 @@ class Engine:
                 seen.add(name)
         assert set(order) == set(self.P.keys())
         self.stage_of = stage
-        total, offs = 0, {}
+        total, offs, shapes = 0, {}, {}
         for name in order:
-            n = self.P[name].numel()
-            offs[name] = total
+            lay = self.gemm_layout(name)
+            shapes[name] = tuple(self.P[name].shape) if lay is None else (lay[0], lay[2] * lay[3])
+            n = 1
+            for d in shapes[name]:
+                n *= d
+            offs[name] = (total, n)
             total += (n + 3) // 4 * 4            # keep every view 16-byte aligned
         self.grad_arena = torch.zeros(total, dtype=F32, device=self.dev)
-        self.G = {name: self.grad_arena[o:o + self.P[name].numel()].view(self.P[name].shape) for name, o in offs.items()}
+        self.G = {name: self.grad_arena[o:o + n].view(shapes[name]) for name, (o, n) in offs.items()}
         self.grad_order = order
         self.grad_offsets = offs
         self.bn_pairs = pairs
@@ -136,7 +163,7 @@ class Engine:
         self.stage_ranges = {}
         for name in order:
             st = stage(name)
-            lo, hi = offs[name], offs[name] + (self.P[name].numel() + 3) // 4 * 4
+            lo, hi = offs[name][0], offs[name][0] + (offs[name][1] + 3) // 4 * 4
             a, b = self.stage_ranges.get(st, (lo, hi))
             self.stage_ranges[st] = (min(a, lo), max(b, hi))
 
@@ -149,10 +176,9 @@ class Engine:
         self.packs = ops.PackTable()
         self.WF, self.WD = {}, {}
         for name, p in self.P.items():
-            if name == "backbone.visual.conv1.weight":
-                self._add_pack(name, p.shape[0], 27, 1, Cpad=32, want_D=False)       # stem: im2col'd, k = ci*9+kh*3+kw
-            elif p.dim() == 4:
-                self._add_pack(name, p.shape[0], p.shape[1], p.shape[2] * p.shape[3])
+            if p.dim() == 4:
+                N, Cin, taps, Cpad = self.gemm_layout(name)
+                self._add_pack(name, N, Cin, taps, Cpad=Cpad, want_D=name != "backbone.visual.conv1.weight")
             elif name == "backbone.text_projection":
                 self._add_pack(name, p.shape[1], p.shape[0], 1, transposed=True)      # used as x @ P
             elif p.dim() == 2 and name.endswith(("weight", "in_proj_weight")) and "embedding" not in name:
@@ -184,14 +210,14 @@ class Engine:
 
     def drop(self, layer, site):
         p = self.head.dropout if self.training else 0.0
-        return Drop(p, self.seed, layer * 8 + site) if p > 0 else NO_DROP
+        return Drop(p, self.seed, layer * 8 + site, self.seed_dev) if p > 0 else NO_DROP
 
     # ------------------------------------------------------------------------------------------
     # GEMM layer (conv / linear) forward + tape
     # ------------------------------------------------------------------------------------------
     def gemm(self, x: Act, wname: str, N: int, *, k=1, pad=0, rows=None, bias: Optional[str] = None, out: Optional[Act] = None,
              out_f32=False, resid: Optional[Act] = None, drop: Drop = NO_DROP, stats=False, outT=None, geom: Optional[Geom] = None,
-             C_real=None, no_dgrad=False, stream_grad: Optional[Act] = None, w_transposed=False):
+             no_dgrad=False, stream_grad: Optional[Act] = None, w_transposed=False):
         """y = conv_k(x) with weight `wname` (rows n0:n1 of it when `rows`), optional bias / residual / dropout /
         BN statistics / transposed head-split copy.  `stream_grad`: fp32 residual-stream Act whose gradient is the
         gradient of this layer's output (post dropout) - used for `x + dropout(linear(..))` branches."""
@@ -209,19 +235,15 @@ class Engine:
             bias_t = self.P[bias][n0:n0 + N]
         if out is None:
             out = self.new_act(g.Bn, g.OH, g.OW, N, ld=pad8(N), dtype=F32 if out_f32 else BF16, zero=(pad8(N) != N))
-        st = None
-        if stats:
-            st = ops.new_stats(g.M, N, self.dev)
         kw = {}
         if outT is not None:
             kw = dict(outT=outT["buf"], T_L=outT["L"], T_Lpad=outT["Lpad"], T_E=outT["E"], T_sec_stride=outT["sec_stride"])
-        ops.conv_gemm(x.t, Wf, g, N, lda=x.ld, a_coff=x.coff, ldb=ldbF, bias=bias_t,
-                      resid=None if resid is None else resid.t, ldr=None if resid is None else resid.ld,
-                      r_coff=0 if resid is None else resid.coff, out=out.t, ldc=out.ld, c_coff=out.coff,
-                      colsum=None if st is None else st[0], colsq=None if st is None else st[1], drop=drop, **kw)
+        st = ops.conv_gemm(x.t, Wf, g, N, lda=x.ld, a_coff=x.coff, ldb=ldbF, bias=bias_t,
+                           resid=None if resid is None else resid.t, ldr=None if resid is None else resid.ld,
+                           r_coff=0 if resid is None else resid.coff, out=out.t, ldc=out.ld, c_coff=out.coff,
+                           stats=stats, drop=drop, **kw)
         if not self.training:
             return (out, st) if stats else out
-        creal = C_real if C_real is not None else x.C
 
         def bwd():
             if stream_grad is not None:
@@ -233,9 +255,9 @@ class Engine:
             if w_transposed:
                 # parameter stored [in, out] (used as x @ P): dP = x^T dY - same kernel with the operand roles swapped
                 ops.conv_wgrad(x.t, gy, Geom.linear(out.M, pad8(N)), x.C, Gw, ldy=x.ld, y_coff=x.coff, N_ld=x.C, ldx=gy_ld,
-                               x_coff=gy_coff, C_real=N)
+                               x_coff=gy_coff)
             else:
-                ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff, C_real=creal)
+                ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff)
             if bias is not None:
                 ops.colsum(gy, out.M, N, self.G[bias][n0:n0 + N], ldx=gy_ld, coff=gy_coff)
             if no_dgrad:
@@ -443,7 +465,7 @@ class Engine:
         ops.stem_im2col(img, col)
         xcol = Act(col, B, H // 2, W // 2, 32)
         y = self.new_act(B, H // 2, W // 2, w // 2)
-        _, st = self.gemm(xcol, v + ".conv1.weight", w // 2, geom=Geom.linear(xcol.M, 32), stats=True, C_real=27, no_dgrad=True, out=y)
+        _, st = self.gemm(xcol, v + ".conv1.weight", w // 2, geom=Geom.linear(xcol.M, 32), stats=True, no_dgrad=True, out=y)
         x = self.bn(y, st, v + ".bn1")
         x = self.conv_bn(x, v + ".conv2", v + ".bn2", w // 2, k=3, pad=1)
         x = self.conv_bn(x, v + ".conv3", v + ".bn3", w, k=3, pad=1, pool=True)
@@ -604,7 +626,7 @@ class Engine:
         self.conv_bn(cat4, n + ".aggr.0", n + ".aggr.1", fo[1], out=cc.slice(0, fo[1]))
         ops.fill_coords(cc.t, cc.ld, fo[1], cc.ld - fo[1], cc.Bn, cc.H, cc.W)
         self._neck_taps = dict(f5=f5, f4=f4, f3=f3, aggr=cc.slice(0, fo[1]), s=s)
-        fq = self.conv_bn(cc, n + ".coordconv.0.conv1.0", n + ".coordconv.0.conv1.1", fo[1], k=3, pad=1, C_real=fo[1] + 2)
+        fq = self.conv_bn(cc, n + ".coordconv.0.conv1.0", n + ".coordconv.0.conv1.1", fo[1], k=3, pad=1)
         fq = self.conv_bn(fq, n + ".coordconv.1.0", n + ".coordconv.1.1", fo[1], k=3, pad=1)
         return fq
 

@@ -27,7 +27,8 @@ class ConvGemmParams(C.Structure):
                 ("ldr", I), ("r_coff", I), ("resid_f32", I),
                 ("ldc", I), ("c_coff", I), ("out_f32", I),
                 ("T_L", I), ("T_Lpad", I), ("T_E", I),
-                ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U)]
+                ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U),
+                ("drop_seed_dev", P)]
 
 
 class WgradParams(C.Structure):
@@ -37,7 +38,7 @@ class WgradParams(C.Structure):
                 ("Bn", I), ("H", I), ("W", I), ("C", I),
                 ("OH", I), ("OW", I), ("KH", I), ("KW", I), ("stride", I), ("pad", I),
                 ("M", I), ("N", I), ("K", I),
-                ("C_real", I), ("splits", I)]
+                ("ldw", I), ("splits", I)]
 
 
 class PackDesc(C.Structure):
@@ -88,7 +89,8 @@ class LnFwdParams(C.Structure):
                 ("in_relu", I),
                 ("in_drop_p", F), ("in_thresh", U), ("in_seed", U), ("in_stream", U),
                 ("out_drop_p", F), ("out_thresh", U), ("out_seed", U), ("out_stream", U),
-                ("eps", F)]
+                ("eps", F),
+                ("seed_dev", P)]
 
 
 class LnBwdParams(C.Structure):
@@ -101,7 +103,8 @@ class LnBwdParams(C.Structure):
                 ("rows", I), ("C", I),
                 ("in_relu", I),
                 ("in_drop_p", F), ("in_thresh", U), ("in_seed", U), ("in_stream", U),
-                ("out_drop_p", F), ("out_thresh", U), ("out_seed", U), ("out_stream", U)]
+                ("out_drop_p", F), ("out_thresh", U), ("out_seed", U), ("out_stream", U),
+                ("seed_dev", P)]
 
 
 class AttnParams(C.Structure):
@@ -120,14 +123,16 @@ class AttnParams(C.Structure):
                 ("B", I), ("Hn", I), ("Lq", I), ("Lk", I),
                 ("causal", I),
                 ("scale", F),
-                ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U)]
+                ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U),
+                ("drop_seed_dev", P)]
 
 
 class AdamDesc(C.Structure):
     _fields_ = [("p", P), ("g", P), ("m", P), ("v", P),
                 ("n", L),
                 ("lr", F), ("pad_", F),
-                ("block_start", I), ("pad2_", I)]
+                ("block_start", I), ("taps", I),
+                ("cin", I), ("cpad", I)]
 
 
 STRUCTS = {
@@ -148,7 +153,7 @@ _SIGS = {
     "cris_pack_blocks": (I, [P]),
     "cris_pack_block_elems": (I, []),
     "cris_colsum_bf16": (I, [P, I, I, I, I, P, P]),
-    "cris_conv_gemm_stat_rows": (I, [I]),
+    "cris_conv_gemm_stat_rows": (I, [P]),
     "cris_bn_partials_rows": (I, [I]),
     "cris_bn_finalize": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P, P]),
     "cris_bn_recentre": (I, [P, P, P, F, F, I, P]),
@@ -172,7 +177,8 @@ _SIGS = {
     "cris_add_rowtable": (I, [P, I, P, I, P, I, I, I, P]),
     "cris_cast_f32_bf16": (I, [P, P, L, P]),
     "cris_cast_bf16_f32": (I, [P, P, L, I, P]),
-    "cris_cast_f32_bf16_drop": (I, [P, P, L, F, U, U, U, P]),
+    "cris_cast_f32_bf16_drop": (I, [P, P, L, F, U, U, U, P, P]),
+    "cris_step_advance": (I, [P, P, P]),
     "cris_axpy_f32": (I, [P, P, F, L, P]),
     "cris_quickgelu_fwd": (I, [P, P, L, P]),
     "cris_quickgelu_bwd": (I, [P, P, P, L, P]),
@@ -190,7 +196,7 @@ _SIGS = {
     "cris_bce_bwd": (I, [P, P, L, P, P, P]),
     "cris_train_metric": (I, [P, P, I, I, F, F, P, P]),
     "cris_memset_f32": (I, [P, F, L, P]),
-    "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P]),
+    "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, P]),
     "cris_adam_block_elems": (I, []),
 }
 EXPORTS = sorted(_SIGS)

@@ -67,6 +67,7 @@ class Drop:
     p: float
     seed: int
     stream: int
+    dev: Optional[torch.Tensor] = None       # optional uint32/int32 device word added to `seed` (HIP-graph replay)
 
     @property
     def thresh(self):
@@ -77,9 +78,10 @@ NO_DROP = Drop(0.0, 0, 0)
 
 
 def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None, act=0, resid=None, ldr=None, r_coff=0,
-              out=None, ldc=None, c_coff=0, outT=None, T_L=0, T_Lpad=0, T_E=0, T_sec_stride=0, colsum=None, colsq=None,
+              out=None, ldc=None, c_coff=0, outT=None, T_L=0, T_Lpad=0, T_E=0, T_sec_stride=0, stats=False,
               drop: Drop = NO_DROP):
-    """out[M,N] = epi(A_im2col @ Wt^T).  A bf16 NHWC buffer (row stride lda), Wt bf16 [N][ldb]."""
+    """out[M,N] = epi(A_im2col @ Wt^T).  A bf16 NHWC buffer (row stride lda), Wt bf16 [N][ldb].
+    stats=True: also returns the BatchNorm statistics partials (Stats) of the output columns."""
     p = hip.ConvGemmParams()
     p.A, p.Wt, p.bias = ptr(A), ptr(Wt), ptr(bias)
     p.lda = lda if lda is not None else A.shape[-1]
@@ -102,15 +104,20 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     if outT is not None:
         p.outT = ptr(outT)
         p.T_L, p.T_Lpad, p.T_E, p.T_sec_stride = T_L, T_Lpad, T_E, T_sec_stride
-    if colsum is not None:
-        p.colsum, p.colsq = ptr(colsum), ptr(colsq)
     p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
+    p.drop_seed_dev = ptr(drop.dev)
+    st = None
+    if stats:
+        rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))          # depends on the tile variant the library picks
+        st = Stats((g.M + rows - 1) // rows, N, rows, A.device)
+        p.colsum, p.colsq = ptr(st[0]), ptr(st[1])
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.launch("conv_gemm_n128" if N > 64 else "conv_gemm_n64", 2.0 * g.M * N * g.K,
                             2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p),
                             tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
-        return
+        return st
     hip.call("cris_conv_gemm", C.byref(p), _stream())
+    return st
 
 
 class KernelTimer:
@@ -153,13 +160,15 @@ KERNEL_TIMER = None
 
 
 def wgrad_splits(M: int, N: int, K: int) -> int:
+    """split the pixel reduction only as far as needed to put ~2 blocks on each of the 256 CUs; every split costs a
+    128x128 tile of fp32 atomics, so long reductions per block win"""
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     steps = (M + 127) // 128
-    want = max(1, (1024 + tiles - 1) // tiles)
+    want = max(1, (512 + tiles // 2) // tiles)
     return max(1, min(want, (steps + 3) // 4, 512))
 
 
-def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, C_real=None, splits=None):
+def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, ldw=None, splits=None):
     p = hip.WgradParams()
     p.dY, p.X, p.dW = ptr(dY), ptr(X), ptr(dW)
     p.ldy = ldy if ldy is not None else dY.shape[-1]
@@ -170,7 +179,7 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
     p.Bn, p.H, p.W, p.C = g.Bn, g.H, g.W, g.C
     p.OH, p.OW, p.KH, p.KW, p.stride, p.pad = g.OH, g.OW, g.KH, g.KW, g.stride, g.pad
     p.M, p.N, p.K = g.M, N, g.K
-    p.C_real = C_real if C_real is not None else g.C
+    p.ldw = ldw if ldw is not None else dW.shape[-1]
     p.splits = splits if splits is not None else wgrad_splits(g.M, N, g.K)
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.launch("conv_wgrad", 2.0 * g.M * N * g.K, 2.0 * (g.M * N + g.M * g.C) + 4.0 * N * g.K, "cris_conv_wgrad", C.byref(p),
@@ -236,15 +245,6 @@ def colsum(x, M, N, out, ldx=None, coff=0):
 
 
 # ---- BatchNorm ---------------------------------------------------------------------------------
-def stat_rows(N: int) -> int:
-    """rows per statistics partial written by conv_gemm for an N-column output"""
-    return 32 if N <= 64 else 64
-
-
-def stat_parts(M: int, N: int) -> int:
-    return ((M + 127) // 128) * (128 // stat_rows(N))
-
-
 def partials_rows(nparts: int) -> int:
     """rows a partials buffer needs (room for bn_finalize's first-level merge; cris_bn_partials_rows)"""
     return nparts + 64 if nparts > 128 else nparts
@@ -262,9 +262,6 @@ class Stats:
         return self.t[i]
 
 
-def new_stats(M: int, N: int, device) -> Stats:
-    """partials for conv_gemm(colsum=st[0], colsq=st[1]): every part row is written by the epilogue (no zero fill needed)"""
-    return Stats(stat_parts(M, N), N, stat_rows(N), device)
 
 
 def bn_finalize(st: Optional[Stats], count_local, count, gamma, beta, rmean, rvar, momentum, eps, C_, scale, shift, mean, invstd,
@@ -352,6 +349,7 @@ def ln_fwd(x, gamma, beta, rows, C_, mean, rstd, *, ldx=None, y=None, ypos=None,
     p.rows, p.C, p.in_relu = rows, C_, int(in_relu)
     p.in_drop_p, p.in_thresh, p.in_seed, p.in_stream = in_drop.p, in_drop.thresh, in_drop.seed & 0xFFFFFFFF, in_drop.stream
     p.out_drop_p, p.out_thresh, p.out_seed, p.out_stream = out_drop.p, out_drop.thresh, out_drop.seed & 0xFFFFFFFF, out_drop.stream
+    p.seed_dev = ptr(in_drop.dev if in_drop.dev is not None else out_drop.dev)
     p.eps = eps
     hip.call("cris_ln_fwd", C.byref(p), _stream())
 
@@ -367,6 +365,7 @@ def ln_bwd(x, gamma, mean, rstd, rows, C_, dx, *, ldx=None, dy=None, dypos=None,
     p.rows, p.C, p.in_relu = rows, C_, int(in_relu)
     p.in_drop_p, p.in_thresh, p.in_seed, p.in_stream = in_drop.p, in_drop.thresh, in_drop.seed & 0xFFFFFFFF, in_drop.stream
     p.out_drop_p, p.out_thresh, p.out_seed, p.out_stream = out_drop.p, out_drop.thresh, out_drop.seed & 0xFFFFFFFF, out_drop.stream
+    p.seed_dev = ptr(in_drop.dev if in_drop.dev is not None else out_drop.dev)
     hip.call("cris_ln_bwd", C.byref(p), _stream())
 
 
@@ -381,6 +380,7 @@ def attn_params(Q, K, V, Vt, B, Hn, Lq, Lk, Lk_pad, scale, *, ldq=None, ldk=None
     p.key_tokens = ptr(key_tokens)
     p.B, p.Hn, p.Lq, p.Lk, p.causal, p.scale = B, Hn, Lq, Lk, int(causal), float(scale)
     p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
+    p.drop_seed_dev = ptr(drop.dev)
     return p
 
 
@@ -451,7 +451,11 @@ def cast_bf16_f32(x, y, accum=False):
 
 def cast_f32_bf16_drop(x, y, drop: Drop):
     hip.call("cris_cast_f32_bf16_drop", ptr(x), ptr(y), x.numel(), drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream,
-             _stream())
+             ptr(drop.dev), _stream())
+
+
+def step_advance(step, seed):
+    hip.call("cris_step_advance", ptr(step), ptr(seed), _stream())
 
 
 def axpy_f32(dst, src, alpha=1.0):
@@ -529,7 +533,8 @@ def memset_f32(t, v=0.0):
 class AdamTable:
     """Device table of {p, g, m, v, n, lr}: one launch = torch.optim.Adam.step() over every tensor."""
 
-    def __init__(self, params, grads, lrs):
+    def __init__(self, params, grads, lrs, layouts=None):
+        """layouts[i]: None (gradient in the parameter layout) or (N, Cin, taps, Cpad) (GEMM layout, see cris_conv_wgrad)"""
         lib = hip.load()
         be = lib.cris_adam_block_elems()
         self.m = [torch.zeros_like(p) for p in params]
@@ -541,6 +546,9 @@ class AdamTable:
         for i, (p, g) in enumerate(zip(self.params, self.grads)):
             d = self.arr[i]
             d.p, d.g, d.m, d.v, d.n, d.lr = ptr(p), ptr(g), ptr(self.m[i]), ptr(self.v[i]), p.numel(), self.lrs[i]
+            lay = layouts[i] if layouts is not None else None
+            if lay is not None and not (lay[2] == 1 and lay[3] == lay[1]):
+                d.taps, d.cin, d.cpad = lay[2], lay[1], lay[3]
             d.block_start = start
             start += (p.numel() + be - 1) // be
         self.total_blocks = start
@@ -558,9 +566,10 @@ class AdamTable:
             self.arr[i].lr = lr
         self._upload(self.params[0].device)
 
-    def step(self, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    def step(self, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, step_dev=None):
+        """step_dev: optional int32 device tensor holding the 1-based step count (graph replay); else a host counter"""
         self.step_count += 1
         bc1 = 1.0 - beta1 ** self.step_count
         bc2 = 1.0 - beta2 ** self.step_count
         hip.call("cris_adam_step", ptr(self.dev), self.n, self.total_blocks, beta1, beta2, eps, weight_decay, bc1, bc2,
-                 grad_scale, _stream())
+                 grad_scale, ptr(step_dev), _stream())

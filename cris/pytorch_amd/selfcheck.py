@@ -33,9 +33,9 @@ def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0"):
     tr = NativeTrainer(clip, head, sd, dev)
     e = tr.engine
     pred, msk, loss = e.forward(img.to(dev), word.to(dev), mask.to(dev), training=True, seed=seed)
-    G = e.backward()
+    e.backward()
     torch.cuda.synchronize(dev)
-    grads = {k: v.detach().clone() for k, v in G.items()}
+    grads = {k: v.detach().clone() for k, v in e.grads_param_layout().items()}
 
     leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     dseed = seed if dropout > 0 else None

@@ -35,7 +35,8 @@ class NativeTrainer:
         self.names = names
         self.group = {n: (0 if (n.startswith("backbone") and "positional_embedding" not in n) else 1) for n in names}
         self.base_lr, self.lr_multi, self.weight_decay = base_lr, lr_multi, weight_decay
-        self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [base_lr] * len(names))
+        self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [base_lr] * len(names),
+                                  layouts=[e.gemm_layout(n) for n in names])
         self.step_idx = 0
         self.metric = torch.zeros(2, device=device)
 

@@ -61,22 +61,26 @@ typedef struct {
     float drop_p;            /* dropout on (acc+bias, act) before the residual add; survivors scaled 1/(1-p) */
     uint32_t drop_thresh;    /* keep iff hash >= drop_thresh; host computes min(int(p*2^32), 2^32-1); 0 = off */
     uint32_t drop_seed, drop_stream;
+    const uint32_t* drop_seed_dev; /* optional device word added to drop_seed (per-step seed of a replayed HIP graph) */
 } cris_conv_gemm_params;
 int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
-int cris_conv_gemm_stat_rows(int N);
+/* rows per BatchNorm-statistics partial written for this problem (depends on the tile variant chosen; host only) */
+int cris_conv_gemm_stat_rows(const cris_conv_gemm_params* p);
 
-/* Weight gradient: dW[n, c, tap] += sum_m dY[m, n] * X_im2col[m, tap*C + c]   (fp32 atomics, split over m).
- * Replaces convolution_backward(weight) / addmm backward for every Conv2d / Linear above. */
+/* Weight gradient in the GEMM layout: dW[n][tap*C + c] (+)= sum_m dY[m, n] * X_im2col[m, tap*C + c]
+ * (splits == 1: plain store of the whole reduction; splits > 1: fp32 atomics into a zeroed buffer).
+ * Replaces convolution_backward(weight) / addmm backward for every Conv2d / Linear above.  cris_adam_step reads this
+ * layout directly; cris_unpack_grads converts it to the parameter layout [n][c][tap]. */
 typedef struct {
     const cris_bf16* dY;     /* [M][ldy] (+y_coff) */
     const cris_bf16* X;      /* NHWC input of the forward conv */
-    float* dW;               /* parameter-layout fp32: dW[(n*C_real + c)*taps + tap] */
+    float* dW;               /* fp32 [N][ldw], k = tap*C + c contiguous */
     int ldy, y_coff, N_ld;   /* N_ld: columns of dY that may be read (multiple of 8, >= N) */
     int ldx, x_coff;
     int Bn, H, W, C;
     int OH, OW, KH, KW, stride, pad;
     int M, N, K;
-    int C_real;              /* channels that exist in the parameter (C may be zero padded above it) */
+    int ldw;                 /* row stride of dW (>= K) */
     int splits;              /* grid.z; each split covers ceil(M/splits) rows rounded up to 128 */
 } cris_wgrad_params;
 int cris_conv_wgrad(const cris_wgrad_params* p, void* stream);
@@ -176,6 +180,7 @@ typedef struct {
     float in_drop_p; uint32_t in_thresh, in_seed, in_stream;     /* dropout on the input (FFN: LN(dropout(relu(h)))) */
     float out_drop_p; uint32_t out_thresh, out_seed, out_stream; /* dropout on LN(x) before the residual add */
     float eps;
+    const uint32_t* seed_dev;                        /* optional device word added to in_seed / out_seed */
 } cris_ln_fwd_params;
 int cris_ln_fwd(const cris_ln_fwd_params* p, void* stream);
 
@@ -192,6 +197,7 @@ typedef struct {
     int in_relu;
     float in_drop_p; uint32_t in_thresh, in_seed, in_stream;
     float out_drop_p; uint32_t out_thresh, out_seed, out_stream;
+    const uint32_t* seed_dev;
 } cris_ln_bwd_params;
 int cris_ln_bwd(const cris_ln_bwd_params* p, void* stream);
 
@@ -222,6 +228,7 @@ typedef struct {
     int causal;
     float scale;
     float drop_p; uint32_t drop_thresh, drop_seed, drop_stream;
+    const uint32_t* drop_seed_dev;                   /* optional device word added to drop_seed */
 } cris_attn_params;
 int cris_attn_fwd(const cris_attn_params* p, void* stream);
 int cris_attn_bwd_dq(const cris_attn_params* p, void* stream);
@@ -254,7 +261,9 @@ int cris_cast_f32_bf16(const float* x, cris_bf16* y, long n, void* stream);
 int cris_cast_bf16_f32(const cris_bf16* x, float* y, long n, int accum, void* stream);
 /* y = bf16(dropout(x)) over a flat fp32 tensor (gradient of nn.Dropout on the residual branches, model/layers.py:217-219) */
 int cris_cast_f32_bf16_drop(const float* x, cris_bf16* y, long n, float drop_p, uint32_t drop_thresh, uint32_t seed,
-                            uint32_t stream_id, void* stream);
+                            uint32_t stream_id, const uint32_t* seed_dev, void* stream);
+/* device-side per-step state of a replayed HIP graph: step[0] += 1 ; seed[0] = step[0] * 7919 + 17 */
+int cris_step_advance(int32_t* step, uint32_t* seed, void* stream);
 int cris_axpy_f32(float* dst, const float* src, float alpha, long n, void* stream);
 /* QuickGELU x*sigmoid(1.702x) on a stored bf16 pre-activation (model/clip.py:234-236) */
 int cris_quickgelu_fwd(const cris_bf16* x, cris_bf16* y, long n, void* stream);
@@ -291,15 +300,21 @@ int cris_train_metric(const float* logits, const float* target, int Bn, int HW, 
 /* elementwise multiply by per-(batch,channel) scalar handled inside cris_bn_apply (mul) */
 int cris_memset_f32(float* p, float v, long n, void* stream);
 
-/* fused multi-tensor Adam (torch.optim.Adam semantics, train.py:105-107): table of {p,g,m,v,n} */
+/* fused multi-tensor Adam (torch.optim.Adam semantics, train.py:105-107): table of {p,g,m,v,n}.
+ * p/m/v are in the parameter layout; g is in the parameter layout when taps == 0, else in the GEMM layout
+ * [n][tap][cpad] written by cris_conv_wgrad (element (n, c, tap) of the parameter reads g[(n*taps + tap)*cpad + c]).
+ * step_dev (optional, device int32): 1-based step count read on the device - the bias corrections are then
+ * 1 - beta^step and bias_corr1/2 are ignored (lets a captured HIP graph be replayed step after step). */
 typedef struct {
     float* p; const float* g; float* m; float* v;
     long n;
     float lr; float pad_;
-    int block_start; int pad2_;
+    int block_start; int taps;
+    int cin; int cpad;
 } cris_adam_desc;
 int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
-                   float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, void* stream);
+                   float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
+                   void* stream);
 int cris_adam_block_elems(void);
 
 #ifdef __cplusplus

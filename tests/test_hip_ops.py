@@ -103,11 +103,10 @@ def test_conv_gemm_epilogues():
     check(wide[:, 64:], torch.relu(base) + resbf, 6e-3, "relu+resid bf16 slice")
     assert float(wide[:, :64].float().abs().max()) == 0.0
     # BatchNorm statistics partials: per 64-row block (sum, M2 about the block mean), merged by bn_finalize
-    st = ops.new_stats(M, N, DEV)
     out2 = torch.empty(M, N, dtype=BF, device=DEV)
-    ops.conv_gemm(bf(x), bf(w + 0.05), g, N, out=out2, colsum=st[0], colsq=st[1])
+    st = ops.conv_gemm(bf(x), bf(w + 0.05), g, N, out=out2, stats=True)
     y = x @ (w + 0.05).to(BF).float().t()
-    rows = ops.stat_rows(N)
+    rows = st.rows_per_part
     for part in range((M + rows - 1) // rows):
         blk = y[part * rows:(part + 1) * rows]
         check(st[0][part], blk.sum(0), 3e-3, "part sum")
@@ -167,12 +166,17 @@ def test_conv_wgrad(case):
     dy = torch.zeros(g.M, Nld)
     dy[:, :N] = rnd(g.M, N, seed=5)
     dy = dy.to(BF).float()
-    dW = torch.zeros(N, C_real, k, k, device=DEV)
-    ops.conv_wgrad(bf(dy), bf(x), g, N, dW, C_real=C_real)
-    # reference: autograd of conv2d wrt weight
-    wt = torch.zeros(N, C_real, k, k, requires_grad=True)
-    y = F.conv2d(x[..., :C_real].permute(0, 3, 1, 2), wt, padding=pad)
-    y.backward(dy[:, :N].reshape(B, g.OH, g.OW, N).permute(0, 3, 1, 2))
+    for splits in (None, 1):                                  # atomics path (split reduction) and plain-store path
+        dWg = torch.zeros(N, k * k * C_, device=DEV)           # GEMM layout [n][tap][c]
+        ops.conv_wgrad(bf(dy), bf(x), g, N, dWg, splits=splits)
+        dW = dWg.view(N, k * k, C_)[:, :, :C_real].permute(0, 2, 1).reshape(N, C_real, k, k)
+        # reference: autograd of conv2d wrt weight
+        wt = torch.zeros(N, C_real, k, k, requires_grad=True)
+        y = F.conv2d(x[..., :C_real].permute(0, 3, 1, 2), wt, padding=pad)
+        y.backward(dy[:, :N].reshape(B, g.OH, g.OW, N).permute(0, 3, 1, 2))
+        check(dW, wt.grad, 3e-3, "wgrad %s splits=%s" % (case, splits))
+        assert float(dWg.view(N, k * k, C_)[:, :, C_real:].abs().max() if C_real < C_ else 0.0) == 0.0
+    return
     check(dW, wt.grad, 3e-3, "wgrad %s" % case)
 
 
@@ -693,3 +697,25 @@ def test_adam_matches_torch():
         tab.step()
     for dp, rp in zip(dev_p, ref_p):
         check(dp, rp.data, 1e-6, "adam")
+
+
+def test_adam_gemm_layout_gradient_and_device_step():
+    """conv-weight gradient in the GEMM layout [n][tap][cpad] (what cris_conv_wgrad writes) + step count on the device"""
+    N, Cin, k, Cpad = 24, 20, 3, 24
+    w = rnd(N, Cin, k, k)
+    g = rnd(N, Cin, k, k, seed=3)
+    g_gemm = torch.zeros(N, k * k, Cpad)
+    g_gemm[:, :, :Cin] = g.permute(0, 2, 3, 1).reshape(N, k * k, Cin)
+    g_gemm[:, :, Cin:] = 7.0                                  # padding must never be read
+    dev_p, dev_g = w.clone().to(DEV), g_gemm.reshape(N, k * k * Cpad).to(DEV)
+    tab = ops.AdamTable([dev_p], [dev_g], [1e-3], layouts=[(N, Cin, k * k, Cpad)])
+    rp = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([rp], lr=1e-3)
+    step_dev = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for step in range(3):
+        rp.grad = g.clone()
+        opt.step()
+        step_dev += 1
+        tab.step_count = 100                                  # host counter deliberately wrong: the device count must win
+        tab.step(step_dev=step_dev)
+    check(dev_p, rp.data, 1e-6, "adam gemm-layout")

@@ -42,7 +42,8 @@ def run(spec="tiny", B=2, S=64, dropout=0.0, seed=11, out=None):
     taps = {}
     t0 = time.time()
     pred, msk, loss = eng.forward(img.to(dev), word.to(dev), mask.to(dev), training=True, seed=seed, taps=taps)
-    G = eng.backward()
+    eng.backward()
+    G = eng.grads_param_layout()
     torch.cuda.synchronize()
     t_hip = time.time() - t0
     # oracle

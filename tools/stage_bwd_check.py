@@ -82,16 +82,16 @@ class Ctx:
         n = 0
         for k, v in self.leaf.items():
             if k.startswith(prefix) and v.is_floating_point() and v.grad is not None and not k.endswith("k_proj.bias"):
-                c = cos(e.G[k], v.grad)
-                RESULTS.append((name, "param:" + k, rel(e.G[k], v.grad), c))
+                c = cos(e.grad_param_layout(k), v.grad)
+                RESULTS.append((name, "param:" + k, rel(e.grad_param_layout(k), v.grad), c))
                 n += 1
                 if c < worst[0]:
-                    worst = (c, rel(e.G[k], v.grad), k)
+                    worst = (c, rel(e.grad_param_layout(k), v.grad), k)
         print("[%s] %s | params %d worst cos %.5f (rel %.2e) %s" % (name, " ; ".join(out), n, worst[0], worst[1], worst[2]))
         if os.environ.get("VERBOSE_STAGE") == name:
             for k, v in self.leaf.items():
                 if k.startswith(prefix) and v.is_floating_point() and v.grad is not None:
-                    print("        %.5f %.2e %s" % (cos(e.G[k], v.grad), rel(e.G[k], v.grad), k))
+                    print("        %.5f %.2e %s" % (cos(e.grad_param_layout(k), v.grad), rel(e.grad_param_layout(k), v.grad), k))
 
 
 def main(spec="tiny", B=4, S=64):
@@ -140,7 +140,7 @@ def main(spec="tiny", B=4, S=64):
     state.root._g = gs.to(DEV).to(BF).contiguous()
     c.finish("text", [("word", xf.t.float().view(wref.shape), wref), ("state", state.t.float(), sref)], "backbone.t")
     print("      token_embedding cos %.5f pos cos %.5f text_projection cos %.5f ln_final.w cos %.5f" % tuple(
-        cos(e.G[k], c.leaf[k].grad) for k in ("backbone.token_embedding.weight", "backbone.positional_embedding",
+        cos(e.grad_param_layout(k), c.leaf[k].grad) for k in ("backbone.token_embedding.weight", "backbone.positional_embedding",
                                               "backbone.text_projection", "backbone.ln_final.weight")))
     # ---- FPN
     c.begin()
