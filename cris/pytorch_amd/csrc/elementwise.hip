@@ -379,9 +379,9 @@ extern "C" int cris_cast_f32_bf16_drop(const float* x, cris_bf16* y, long n, flo
     return 0;
 }
 __global__ void step_advance_kernel(int* step, uint32_t* seed) {
-    const int s = step[0] + 1;
-    step[0] = s;
-    seed[0] = (uint32_t)s * 7919u + 17u;
+    const int s = step[0];                       // steps completed so far
+    seed[0] = (uint32_t)s * 7919u + 17u;        // dropout seed of the step that starts now (0-based rule)
+    step[0] = s + 1;                             // 1-based count read by cris_adam_step
 }
 extern "C" int cris_step_advance(int32_t* step, uint32_t* seed, void* stream) {
     CRIS_CHECK_ARG(step && seed, "bad args");

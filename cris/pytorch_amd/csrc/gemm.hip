@@ -122,7 +122,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, f3
                 }
             q += __shfl_xor(q, 16, 64);
             q += __shfl_xor(q, 32, 64);
-            if (fg == 0 && cvalid) {
+            if (fg == 0 && cvalid && part_cnt > 0) {          // parts = ceil(M / rows-per-part): none beyond the last row
                 p.colsum[(size_t)part * p.N + col] = s1;
                 p.colsq[(size_t)part * p.N + col] = q;
             }
@@ -389,10 +389,11 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     CRIS_CHECK_ARG((size_t)p.Bn * p.H * p.W * p.lda * 2 < (1UL << 31) && ((size_t)p.N + 256) * p.ldb * 2 < (1UL << 31),
                    "operand extent must stay below 2 GiB (32-bit buffer offsets)");
     hipStream_t s = (hipStream_t)stream;
-    constexpr int LDS_128x64 = 4 * (128 + 64) * 128, LDS_64x128 = 3 * (64 + 128) * 128, LDS_128x128 = 4 * (128 + 128) * 128;
-    void (*const k_128x64)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 64, 4, 1, 4>;
+    // <= 72 KB per block: two blocks (8 waves) share a CU's 160 KB LDS and hide each other's barriers / epilogues
+    constexpr int LDS_128x64 = 3 * (128 + 64) * 128, LDS_64x128 = 3 * (64 + 128) * 128, LDS_128x128 = 2 * (128 + 128) * 128;
+    void (*const k_128x64)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 64, 4, 1, 3>;
     void (*const k_64x128)(const cris_conv_gemm_params) = conv_gemm_kernel<64, 128, 2, 2, 3>;
-    void (*const k_128x128)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 128, 2, 2, 4>;
+    void (*const k_128x128)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 128, 2, 2, 2>;
     static const int lds_ready = set_lds((const void*)k_128x64, LDS_128x64) | set_lds((const void*)k_64x128, LDS_64x128) |
                                  set_lds((const void*)k_128x128, LDS_128x128);
     if (lds_ready != 0) {

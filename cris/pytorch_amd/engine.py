@@ -79,6 +79,9 @@ class Engine:
         self.training = True
         self.seed = 0
         self.seed_dev = None            # optional device word added to every dropout seed (graph replay: trainer.py)
+        # the text encoder (12 layers of M = B*L ~ 136-row GEMMs: latency-bound, ~16 workgroups each) is independent of
+        # the visual encoder until the neck: it runs on a second HIP stream, forward and backward, underneath the convs
+        self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self._tables = {}
         self._build_grad_arena()
         self._build_packs()
@@ -757,11 +760,21 @@ class Engine:
             self.grad_arena.zero_()
         self.repack_weights()
         word = word.contiguous()
-        starts = {0: 0}
+        main = torch.cuda.current_stream()
+        starts = {1: 0}
+        self._text_tape_start = 0
+        if self.side is not None:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                txt, state = self._encode_text(word)
+        else:
+            txt, state = self._encode_text(word)
+        starts[0] = len(self.tape)
         v3, v4, v5, feats = self._encode_image(img.contiguous().float())
-        self._text_tape_start = starts[1] = len(self.tape)
-        txt, state = self._encode_text(word)
+        if self.side is not None:
+            main.wait_stream(self.side)
         starts[2] = len(self.tape)
+        self._ranges = dict(text=(starts[1], starts[0]), visual=(starts[0], starts[2]))
         fq = self._fpn(v3, v4, v5, state)
         self._dec_tape_start = starts[3] = len(self.tape)
         fqd = self._decoder(fq, Act(txt.t, txt.Bn, txt.H, 1, txt.C, root=txt.root), word)
@@ -803,10 +816,30 @@ class Engine:
         stream - the hook the data-parallel gradient exchange overlaps with the rest of backward."""
         self._gscale = gscale
         marks = dict(self._stage_marks)                 # tape index at which a stage's closures START
-        for i in range(len(self.tape) - 1, -1, -1):
+        (t0, t1), (v0, v1) = self._ranges["text"], self._ranges["visual"]
+        head_start = max(t1, v1)                        # neck / decoder / projector closures: main stream
+        for i in range(len(self.tape) - 1, head_start - 1, -1):
             self.tape[i]()
             if on_stage_done is not None and i in marks:
                 for st in marks[i]:
-                    on_stage_done(st)
+                    if st >= 2:
+                        on_stage_done(st)
+        # the two encoders' backward passes are independent: text on the side stream, visual on the launch stream
+        main = torch.cuda.current_stream()
+        if self.side is not None:
+            self.side.wait_stream(main)
+            with torch.cuda.stream(self.side):
+                for i in range(t1 - 1, t0 - 1, -1):
+                    self.tape[i]()
+        else:
+            for i in range(t1 - 1, t0 - 1, -1):
+                self.tape[i]()
+        for i in range(v1 - 1, v0 - 1, -1):
+            self.tape[i]()
+        if self.side is not None:
+            main.wait_stream(self.side)
+        if on_stage_done is not None:
+            on_stage_done(1)
+            on_stage_done(0)
         self.tape = []
         return self.G

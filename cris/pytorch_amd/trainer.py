@@ -4,7 +4,15 @@ Semantics follow the reference loop (engine/engine.py:37-73, train.py:105-111): 
 weight_decay from the yaml) over two parameter groups built by the `build_segmenter` name rule
 (model/__init__.py:36-48); bf16 needs no loss scaling so there is no GradScaler; the train metric
 (utils/misc.py:114-129) is computed on the device without a host sync.
+
+Launch model: the step is a static schedule of ~1400 kernel launches.  After one eager step (which fills the host-side
+caches and the allocator) the whole step - forward, backward, gradient exchange, Adam, metric - is captured ONCE into a
+HIP graph (torch.cuda.CUDAGraph over the launch stream; the independent text-encoder branch is captured on a second
+stream and so becomes a parallel branch of the graph) and replayed per step: one host call per step instead of one per
+kernel.  What changes from step to step lives in device memory: the input batch (static buffers the caller's tensors
+are copied into), the step counter (Adam bias corrections) and the dropout seed (`cris_step_advance`).
 """
+import os
 from typing import Optional
 
 import torch
@@ -23,7 +31,7 @@ def split_state_dict(sd, device):
 
 class NativeTrainer:
     def __init__(self, clip: ClipSpec, head: HeadSpec, state_dict, device, base_lr=1e-4, lr_multi=0.1, weight_decay=0.0,
-                 comm=None, sync_bn=False):
+                 comm=None, sync_bn=False, use_graph: Optional[bool] = None):
         self.device = device
         params, buffers = split_state_dict(state_dict, device)
         self.engine = Engine(clip, head, params, buffers, device, comm=comm, sync_bn=sync_bn)
@@ -37,15 +45,36 @@ class NativeTrainer:
         self.base_lr, self.lr_multi, self.weight_decay = base_lr, lr_multi, weight_decay
         self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [base_lr] * len(names),
                                   layouts=[e.gemm_layout(n) for n in names])
-        self.step_idx = 0
         self.metric = torch.zeros(2, device=device)
+        # per-step device state: steps done (int32) and the dropout seed of the running step
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        if use_graph is None:
+            use_graph = os.environ.get("CRIS_NO_GRAPH", "0") != "1"
+        self.use_graph = bool(use_graph) and torch.device(device).type == "cuda"
+        self._graph = None
+        self._static = None
+        self._eager_steps = 0
+        self.graph_error = None
+
+    @property
+    def step_idx(self):
+        return int(self.step_dev.item())
 
     def set_group_lrs(self, lr_backbone, lr_head):
         self.adam.set_lrs([lr_backbone if self.group[n] == 0 else lr_head for n in self.names])
+        self._graph = None                       # learning rates live in the device table: no re-capture needed, but
+        self._eager_steps = 0                    # the table buffer was re-uploaded (new address) -> capture again
 
-    def train_step(self, img, word, mask, seed: Optional[int] = None):
+    # ------------------------------------------------------------------------------------------------
+    def _step_body(self, img, word, mask, host_seed: Optional[int]):
         e = self.engine
-        seed = self.step_idx * 7919 + 17 if seed is None else seed
+        if host_seed is None:
+            ops.step_advance(self.step_dev, self.seed_dev)
+            e.seed_dev, seed = self.seed_dev, 0
+        else:                                    # explicit seed (tests): host value, the device counter still advances
+            ops.step_advance(self.step_dev, self.seed_dev)
+            e.seed_dev, seed = None, host_seed
         pred, msk, loss = e.forward(img, word, mask, training=True, seed=seed)
         if self.comm.world > 1:
             def on_stage(st):
@@ -55,11 +84,49 @@ class NativeTrainer:
             self.comm.wait_all()
         else:
             e.backward()
-        self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world)
+        self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
         self.metric.zero_()
         ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
-        self.step_idx += 1
-        return loss, self.metric
+        return loss, pred, msk
+
+    def train_step(self, img, word, mask, seed: Optional[int] = None):
+        """One optimizer step.  Returns (loss 0-dim device tensor, metric [IoU%, Pr@50%] device tensor); both are
+        overwritten by the next call."""
+        if not self.use_graph or seed is not None or ops.KERNEL_TIMER is not None:
+            loss, _, _ = self._step_body(img, word, mask, seed)
+            return loss, self.metric
+        key = (tuple(img.shape), tuple(word.shape), tuple(mask.shape))
+        if self._static is not None and self._static[0] != key:
+            self._graph, self._static, self._eager_steps = None, None, 0      # new shapes: new schedule
+        if self._graph is None:
+            if self._eager_steps < 1:
+                # first step with these shapes runs eagerly: constant tables get uploaded, the allocator warms up
+                self._eager_steps += 1
+                self._static = (key, img.clone(), word.clone(), mask.clone())
+                loss, _, _ = self._step_body(self._static[1], self._static[2], self._static[3], None)
+                return loss, self.metric
+            try:
+                self._capture()
+            except Exception as ex:              # noqa: BLE001 - e.g. a collective that cannot be captured
+                self.graph_error = repr(ex)
+                self.use_graph = False
+                torch.cuda.synchronize(self.device)
+                loss, _, _ = self._step_body(img, word, mask, None)
+                return loss, self.metric
+        _, s_img, s_word, s_mask = self._static
+        s_img.copy_(img, non_blocking=True)
+        s_word.copy_(word, non_blocking=True)
+        s_mask.copy_(mask, non_blocking=True)
+        self._graph.replay()
+        return self._loss, self.metric
+
+    def _capture(self):
+        _, s_img, s_word, s_mask = self._static
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, pred, msk = self._step_body(s_img, s_word, s_mask, None)
+        self._graph, self._loss, self._keep = g, loss, (pred, msk)
 
     @torch.no_grad()
     def eval_forward(self, img, word):

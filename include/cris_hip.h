@@ -46,8 +46,8 @@ typedef struct {
     void* out;               /* [M][ldc] (+c_coff) bf16 or fp32; or NULL */
     cris_bf16* outT;         /* optional head-split transposed copy, see T_* ; or NULL */
     float* colsum;           /* optional BatchNorm statistics partials [nparts][N]: per row-block column sums ...  */
-    float* colsq;            /* ... and sums of squared deviations from the block mean; nparts = ceil(M/128) * 128 /
-                                cris_conv_gemm_stat_rows(N) blocks of cris_conv_gemm_stat_rows(N) rows (deterministic, no atomics) */
+    float* colsq;            /* ... and sums of squared deviations from the block mean; nparts = ceil(M / R) blocks of
+                                R = cris_conv_gemm_stat_rows(p) rows (deterministic, no atomics) */
     long T_sec_stride;       /* elements between consecutive T_E-wide column sections in outT */
     int lda, a_coff;
     int Bn, H, W, C;
@@ -262,7 +262,7 @@ int cris_cast_bf16_f32(const cris_bf16* x, float* y, long n, int accum, void* st
 /* y = bf16(dropout(x)) over a flat fp32 tensor (gradient of nn.Dropout on the residual branches, model/layers.py:217-219) */
 int cris_cast_f32_bf16_drop(const float* x, cris_bf16* y, long n, float drop_p, uint32_t drop_thresh, uint32_t seed,
                             uint32_t stream_id, const uint32_t* seed_dev, void* stream);
-/* device-side per-step state of a replayed HIP graph: step[0] += 1 ; seed[0] = step[0] * 7919 + 17 */
+/* device-side per-step state of a replayed HIP graph: seed[0] = step[0] * 7919 + 17 ; step[0] += 1 */
 int cris_step_advance(int32_t* step, uint32_t* seed, void* stream);
 int cris_axpy_f32(float* dst, const float* src, float alpha, long n, void* stream);
 /* QuickGELU x*sigmoid(1.702x) on a stored bf16 pre-activation (model/clip.py:234-236) */

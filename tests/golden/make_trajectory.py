@@ -25,7 +25,7 @@ from cris.pytorch_amd import arch, synth  # noqa: E402
 from oracle import cris_oracle as O  # noqa: E402
 
 
-def main(spec="tiny", B=4, S=64, steps=100, dropout=0.1, lr=1e-4, threads=6):
+def main(spec="tiny", B=4, S=64, steps=100, dropout=0.1, lr=1e-4, emul=False, threads=6):
     torch.set_num_threads(threads)
     clip, head = arch.specs_by_name(spec)
     head = dataclasses.replace(head, dropout=dropout)
@@ -34,17 +34,21 @@ def main(spec="tiny", B=4, S=64, steps=100, dropout=0.1, lr=1e-4, threads=6):
                 else v.clone()) for k, v in sd.items()}
     params = [v for v in leaf.values() if v.requires_grad]
     opt = torch.optim.Adam(params, lr=lr)
-    out = os.path.join(HERE, "traj_%s_b%d_s%d_d%g_lr%g.json" % (spec, B, S, dropout, lr))
-    rec = {"spec": spec, "batch": B, "size": S, "dropout": dropout, "lr": lr, "seed_rule": "step*7919+17",
+    out = os.path.join(HERE, "traj_%s_b%d_s%d_d%g_lr%g%s.json" % (spec, B, S, dropout, lr, "_bf16emul" if emul else ""))
+    import contextlib
+    from oracle.bf16_emulation import bf16_storage
+    ctx = bf16_storage if emul else contextlib.nullcontext
+    rec = {"spec": spec, "batch": B, "size": S, "dropout": dropout, "lr": lr, "seed_rule": "step*7919+17", "bf16_storage_emulation": emul,
            "loss": [], "iou": [], "pr50": [], "sec_per_step": []}
     for t in range(steps):
         t0 = time.time()
         img, word, mask = synth.make_batch(B, S, head.word_len, 0, t)
         bnu = {}
-        pred, m, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True,
-                                       drop_seed=(t * 7919 + 17) if dropout > 0 else None, bn_updates=bnu)
-        opt.zero_grad()
-        loss.backward()
+        with ctx():
+            pred, m, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True,
+                                           drop_seed=(t * 7919 + 17) if dropout > 0 else None, bn_updates=bnu)
+            opt.zero_grad()
+            loss.backward()
         opt.step()
         with torch.no_grad():
             for pfx, (rm, rv) in bnu.items():
@@ -63,4 +67,5 @@ def main(spec="tiny", B=4, S=64, steps=100, dropout=0.1, lr=1e-4, threads=6):
 if __name__ == "__main__":
     a = sys.argv[1:]
     main(a[0] if a else "tiny", int(a[1]) if len(a) > 1 else 4, int(a[2]) if len(a) > 2 else 64,
-         int(a[3]) if len(a) > 3 else 100, float(a[4]) if len(a) > 4 else 0.1, float(a[5]) if len(a) > 5 else 1e-4)
+         int(a[3]) if len(a) > 3 else 100, float(a[4]) if len(a) > 4 else 0.1, float(a[5]) if len(a) > 5 else 1e-4,
+         emul=len(a) > 6 and a[6] == "emul")
