@@ -795,6 +795,38 @@ __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restr
     }
 }
 extern "C" int cris_adam_block_elems(void) { return ADAM_ELEMS; }
+
+// GEMM-layout gradient -> parameter-layout gradient for a table of tensors (same descriptor as Adam: p = destination in the
+// parameter layout, g = source [n][tap][cpad]); used when a torch optimizer / DDP wants ordinary .grad tensors
+__global__ __launch_bounds__(256) void unpack_grads_kernel(const cris_adam_desc* __restrict__ tab, int n_desc) {
+    int lo = 0, hi = n_desc - 1;
+    const int bid = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].block_start <= bid) lo = mid; else hi = mid - 1;
+    }
+    const cris_adam_desc d = tab[lo];
+    const long base = (long)(bid - d.block_start) * ADAM_ELEMS;
+    const long per_n = (long)d.cin * max(d.taps, 1);
+    for (int e = threadIdx.x; e < ADAM_ELEMS; e += 256) {
+        const long i = base + e;
+        if (i >= d.n) break;
+        long gi = i;
+        if (d.taps > 0) {
+            const long n = i / per_n;
+            const int r = (int)(i - n * per_n);
+            const int c = r / d.taps, tap = r - c * d.taps;
+            gi = (n * d.taps + tap) * d.cpad + c;
+        }
+        d.p[i] = d.g[gi];
+    }
+}
+extern "C" int cris_unpack_grads(const cris_adam_desc* dev_table, int n_desc, int total_blocks, void* stream) {
+    CRIS_CHECK_ARG(dev_table && n_desc > 0 && total_blocks > 0, "empty table");
+    hipLaunchKernelGGL(unpack_grads_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dev_table, n_desc);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
 extern "C" int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
                               float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
                               void* stream) {

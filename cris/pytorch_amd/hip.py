@@ -198,6 +198,7 @@ _SIGS = {
     "cris_memset_f32": (I, [P, F, L, P]),
     "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, P]),
     "cris_adam_block_elems": (I, []),
+    "cris_unpack_grads": (I, [P, I, I, P]),
 }
 EXPORTS = sorted(_SIGS)
 

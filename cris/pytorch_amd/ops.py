@@ -573,3 +573,26 @@ class AdamTable:
         bc2 = 1.0 - beta2 ** self.step_count
         hip.call("cris_adam_step", ptr(self.dev), self.n, self.total_blocks, beta1, beta2, eps, weight_decay, bc1, bc2,
                  grad_scale, ptr(step_dev), _stream())
+
+
+class UnpackTable:
+    """Device table for cris_unpack_grads: GEMM-layout gradients (srcs) -> parameter-layout tensors (dsts)."""
+
+    def __init__(self, srcs, dsts, layouts):
+        lib = hip.load()
+        be = lib.cris_adam_block_elems()
+        self.keep = (list(srcs), list(dsts))
+        n = len(dsts)
+        arr = (hip.AdamDesc * n)()
+        start = 0
+        for i, (s_, d_, lay) in enumerate(zip(srcs, dsts, layouts)):
+            d = arr[i]
+            d.p, d.g, d.n = ptr(d_), ptr(s_), d_.numel()
+            d.taps, d.cin, d.cpad = lay[2], lay[1], lay[3]
+            d.block_start = start
+            start += (d_.numel() + be - 1) // be
+        self.n, self.total_blocks = n, start
+        self.dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dsts[0].device)
+
+    def run(self):
+        hip.call("cris_unpack_grads", ptr(self.dev), self.n, self.total_blocks, _stream())

@@ -316,6 +316,8 @@ int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks
                    float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
                    void* stream);
 int cris_adam_block_elems(void);
+/* dst (param layout, desc.p) <- src (GEMM layout, desc.g) for a table of tensors; block_start as for cris_adam_step */
+int cris_unpack_grads(const cris_adam_desc* dev_table, int n_desc, int total_blocks, void* stream);
 
 #ifdef __cplusplus
 }

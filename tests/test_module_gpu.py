@@ -1,0 +1,63 @@
+"""GPU tests of the drop-in nn.Module (cris.pytorch_amd.model.CRIS) driven the way the reference's engine drives its model
+(engine/engine.py:37-57): ambient fp16 autocast, GradScaler, torch.optim.Adam over build_segmenter's groups."""
+from types import SimpleNamespace as NS
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from cris.pytorch_amd import arch, synth  # noqa: E402
+from cris.pytorch_amd.model import build_segmenter  # noqa: E402
+from cris.pytorch_amd.trainer import NativeTrainer  # noqa: E402
+from test_module_surface import TINY  # noqa: E402
+
+
+def _batch(step, dev):
+    return tuple(t.to(dev) for t in synth.make_batch(4, 64, 9, 0, step))
+
+
+def test_module_train_loop_matches_native_trainer():
+    dev = torch.device("cuda:0")
+    model, groups = build_segmenter(NS(**TINY))
+    model = model.to(dev).train()
+    opt = torch.optim.Adam(groups, lr=1e-4, weight_decay=0.0)       # as train.py:105-107: both groups start at base_lr
+    scaler = torch.amp.GradScaler("cuda")
+    clip, head = arch.specs_by_name("tiny")
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tr = NativeTrainer(clip, head, sd, dev, base_lr=1e-4, use_graph=False)
+    for step in range(4):
+        img, word, mask = _batch(step, dev)
+        with torch.autocast("cuda"):                                # engine/engine.py:48 (fp16 autocast is ambient)
+            pred, target, loss = model(img, word, mask)
+        opt.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.step(opt)
+        scaler.update()
+        ref_loss, _ = tr.train_step(img, word, mask)
+        assert pred.shape == (4, 1, 16, 16) and target.shape == pred.shape and loss.dim() == 0 and loss.requires_grad
+        assert not pred.requires_grad
+        # same kernels, same seeds, same Adam arithmetic (torch's vs the fused HIP one): agreement to fp32 rounding of the
+        # optimizer, amplified by a few steps of training
+        assert abs(float(loss) - float(ref_loss)) < 2e-3, (step, float(loss), float(ref_loss))
+    assert all(p.grad is not None for n, p in model.named_parameters() if n != "backbone.logit_scale")
+    assert model.backbone.logit_scale.grad is None                  # unused in the reference too
+    assert int(model.backbone.visual.bn1.num_batches_tracked) == 4
+
+
+def test_module_eval_and_checkpoint_reload():
+    dev = torch.device("cuda:0")
+    model, _ = build_segmenter(NS(**TINY))
+    model = model.to(dev)
+    img, word, mask = _batch(0, dev)
+    model.train()
+    model(img, word, mask)[2].backward()
+    model.eval()
+    p1 = model(img, word)
+    assert p1.shape == (4, 1, 16, 16) and not p1.requires_grad
+    # checkpoint interchange: a fresh module loaded from the state_dict gives the same eval output
+    other, _ = build_segmenter(NS(**TINY))
+    other.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    other = other.to(dev).eval()
+    p2 = other(img, word)
+    assert torch.equal(p1, p2)
