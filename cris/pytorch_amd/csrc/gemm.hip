@@ -35,30 +35,35 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; 
 // Epilogue of one wave tile (FM x FN fragments of 16x16, C/D layout col = lane&15, row = (lane>>4)*4 + r) whose first
 // row / column are row0 / col0: bias, activation, dropout, residual, bf16|fp32 store, head-split transposed copy and the
 // BatchNorm statistics partial `part` (sum, M2 about the part mean over the FM*16 rows of this wave tile).
-template <int FM, int FN>
-__device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, f32x4 (&acc)[FM][FN], int row0, int col0, int part,
+template <int MT, int FM, int FN, typename ACC>
+__device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, ACC (&acc)[FM][FN], int row0, int col0, int part,
                                               int lane) {
-    const int fr = lane & 15, fg = lane >> 4;
+    // MT = 16: v_mfma_f32_16x16x32 C/D layout  col = lane&15, row = (lane>>4)*4 + r            (r = 0..3)
+    // MT = 32: v_mfma_f32_32x32x16 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (reg = 0..15)
+    // both: per lane NG groups of 4 consecutive rows of one column
+    constexpr int NG = MT == 16 ? 1 : 4;
+    const int fr = lane & (MT - 1), fg = lane / MT;
     const bool has_drop = p.drop_thresh > 0u;
     const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const uint32_t dthr = p.drop_thresh;
     const float dscale = has_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const int Hh = p.outT ? p.T_E / 64 : 1;
-    const int part_cnt = max(0, min(FM * 16, p.M - row0));
+    const int part_cnt = max(0, min(FM * MT, p.M - row0));
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const int col = col0 + j * 16 + fr;
+        const int col = col0 + j * MT + fr;
         const bool cvalid = col < p.N;
         const float bias = (p.bias && cvalid) ? p.bias[col] : 0.f;
-        float vals[FM][4];
+        float vals[FM * NG][4];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int rowb = row0 + i * 16 + fg * 4;
+        for (int ig = 0; ig < FM * NG; ++ig) {
+            const int i = ig / NG, g = ig % NG;
+            const int rowb = row0 + i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4);
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = rowb + r;
-                float x = acc[i][j][r] + bias;
+                float x = acc[i][j][g * 4 + r] + bias;
                 if (p.act == 1) x = fmaxf(x, 0.f);
                 else if (p.act == 2) x = x / (1.0f + __expf(-1.702f * x));
                 if (has_drop) x = cris_keep(dkey, (uint32_t)m * (uint32_t)p.N + (uint32_t)col, dthr) ? x * dscale : 0.f;
@@ -70,7 +75,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, f3
                 }
                 if (!valid) x = 0.f;
                 v[r] = x;
-                vals[i][r] = x;
+                vals[ig][r] = x;
                 if (valid && p.out) {
                     const size_t oo = (size_t)m * p.ldc + p.c_coff + col;
                     if (p.out_f32) reinterpret_cast<float*>(p.out)[oo] = x;
@@ -105,22 +110,23 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, f3
             // cris_bn_finalize merges the blocks with Chan's formula.  No atomics, no E[x^2]-E[x]^2 cancellation.
             float s1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int ig = 0; ig < FM * NG; ++ig)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s1 += vals[i][r];                 // invalid rows hold 0
-            s1 += __shfl_xor(s1, 16, 64);
+                for (int r = 0; r < 4; ++r) s1 += vals[ig][r];                // invalid rows hold 0
+            if (MT == 16) s1 += __shfl_xor(s1, 16, 64);                       // lanes sharing this column
             s1 += __shfl_xor(s1, 32, 64);
             const float mu = part_cnt > 0 ? s1 / (float)part_cnt : 0.f;
             float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < FM; ++i)
+            for (int ig = 0; ig < FM * NG; ++ig)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int m = row0 + i * 16 + fg * 4 + r;
-                    const float d = vals[i][r] - mu;
+                    const int i = ig / NG, g = ig % NG;
+                    const int m = row0 + i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4) + r;
+                    const float d = vals[ig][r] - mu;
                     q += (m < p.M) ? d * d : 0.f;
                 }
-            q += __shfl_xor(q, 16, 64);
+            if (MT == 16) q += __shfl_xor(q, 16, 64);
             q += __shfl_xor(q, 32, 64);
             if (fg == 0 && cvalid && part_cnt > 0) {          // parts = ceil(M / rows-per-part): none beyond the last row
                 p.colsum[(size_t)part * p.N + col] = s1;
@@ -143,8 +149,12 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_params p) {
     constexpr int WTM = BM / WAVES_M;          // wave tile rows
     constexpr int WTN = BN / WAVES_N;
-    constexpr int FM = WTM / 16;
-    constexpr int FN = WTN / 16;
+    // v_mfma_f32_32x32x16_bf16: one 16-B A chunk + one 16-B B chunk per lane feed 32x32x16 MACs - half the LDS read
+    // traffic per flop of the 16x16x32 shape (LDS read bandwidth, 128 B/clk/CU, is what caps the 16x16 form at 64x64
+    // wave tiles).  A/B lane layout: row = lane&31, k = (lane>>5)*8 .. +8.
+    constexpr int MT = 32;
+    constexpr int FM = WTM / MT;
+    constexpr int FN = WTN / MT;
     constexpr int NA = BM / 32;                // DMA instructions per wave per K-step (A): 8 rows each, 4 waves
     constexpr int NB = BN / 32;
     constexpr int A_BYTES = BM * 128;
@@ -232,17 +242,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
         }
     };
 
-    f32x4 acc[FM][FN];
+    f32x16 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
     // prologue: STAGES-1 K-steps in flight (steps beyond nk read zeros: keeps the vmcnt arithmetic uniform)
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s) issue_stage(s);
-    const int fr = lane & 15, fg = lane >> 4;
+    const int fr = lane & 31, fh = lane >> 5;
     int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
         CRIS_VMCNT((STAGES - 2) * (NA + NB));       // this wave's share of K-step kt has landed ...
@@ -255,40 +267,42 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
         const unsigned char* sa = smem + buf * STAGE_BYTES;
         const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < 4; ++ks) {            // 4 k-slices of 16 per 64-wide step
             bf16x8 af[FM], bfr[FN];
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
-                const int row = wm * WTM + i * 16 + fr;
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(row, ks * 4 + fg));
+                const int row = wm * WTM + i * MT + fr;
+                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(row, ks * 2 + fh));
             }
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                const int row = wn * WTN + j * 16 + fr;
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(row, ks * 4 + fg));
+                const int row = wn * WTN + j * MT + fr;
+                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(row, ks * 2 + fh));
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);          // keep this step's LDS reads / MFMAs ahead of the next barrier
         if (++buf == STAGES) buf = 0;
     }
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 
-    gemm_epilogue<FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
+    gemm_epilogue<MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
 }
 
 // Skinny kernel (M <= FM*16 rows, 1x1 geometry: text encoder / per-sample vectors).  Such GEMMs are pure latency: one
-// block owns all rows x 32 columns and its 4 waves split K (interleaved 32-wide chunks, so the block reads contiguous
-// 256-B runs), fragments loaded straight from L2 into registers (no LDS staging, no barrier in the loop), partial
-// accumulators reduced through LDS, full epilogue by wave 0.
+// block owns all rows x 32 columns and its 8 waves split K (interleaved 32-wide chunks, so the block reads contiguous
+// 512-B runs); fragments go straight from L2/HBM into registers (no LDS staging, no barrier in the loop), two K-chunks
+// per trip with all loads issued before the first MFMA; the partial accumulators are summed through LDS in a fixed wave
+// order (deterministic); full epilogue by wave 0.
+#define SK_WAVES 8
 template <int FM>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(const cris_conv_gemm_params p) {
+__global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_conv_gemm_params p) {
     constexpr int FN = 2;
-    __shared__ float red[3][FM * FN * 4][64];
+    __shared__ float red[FM * FN * 4][64];
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fg = lane >> 4;
@@ -311,40 +325,52 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(const cris_conv_gemm_p
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const uint4 z = make_uint4(0, 0, 0, 0);
-    for (int kb = wave * 32; kb < p.K; kb += 128) {                 // wave-uniform trip count (MFMA ignores EXEC)
-        const int k = kb + fg * 8;
-        const bool kv = k < p.K;                                     // K % 8 == 0: a chunk is either whole or absent
-        uint4 av[FM], bv[FN];
+    constexpr int KSTEP = 32 * SK_WAVES;
+    for (int kb = wave * 32; kb < p.K; kb += 2 * KSTEP) {              // wave-uniform trip count (MFMA ignores EXEC)
+        const int k0 = kb + fg * 8, k1 = k0 + KSTEP;                  // K % 8 == 0: a chunk is either whole or absent
+        const bool v0 = k0 < p.K, v1 = k1 < p.K;
+        uint4 av0[FM], bv0[FN], av1[FM], bv1[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) av[i] = (kv && arow[i]) ? *reinterpret_cast<const uint4*>(arow[i] + k) : z;
+        for (int i = 0; i < FM; ++i) av0[i] = (v0 && arow[i]) ? *reinterpret_cast<const uint4*>(arow[i] + k0) : z;
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bv[j] = (kv && brow[j]) ? *reinterpret_cast<const uint4*>(brow[j] + k) : z;
+        for (int j = 0; j < FN; ++j) bv0[j] = (v0 && brow[j]) ? *reinterpret_cast<const uint4*>(brow[j] + k0) : z;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) av1[i] = (v1 && arow[i]) ? *reinterpret_cast<const uint4*>(arow[i] + k1) : z;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bv1[j] = (v1 && brow[j]) ? *reinterpret_cast<const uint4*>(brow[j] + k1) : z;
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&av[i]), *reinterpret_cast<bf16x8*>(&bv[j]),
+            for (int j = 0; j < FN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&av0[i]), *reinterpret_cast<bf16x8*>(&bv0[j]),
                                                                     acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&av1[i]), *reinterpret_cast<bf16x8*>(&bv1[j]),
+                                                                    acc[i][j], 0, 0, 0);
+            }
     }
-    if (wave > 0) {
+    // fixed-order sum over the waves: SK_WAVES-1 .. 1 add into LDS one after the other, wave 0 finishes
+    for (int w = SK_WAVES - 1; w >= 1; --w) {
+        if (wave == w) {
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
+            for (int i = 0; i < FM; ++i)
 #pragma unroll
-            for (int j = 0; j < FN; ++j)
+                for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) red[wave - 1][(i * FN + j) * 4 + r][lane] = acc[i][j][r];
+                    for (int r = 0; r < 4; ++r) {
+                        float* slot = &red[(i * FN + j) * 4 + r][lane];
+                        *slot = (w == SK_WAVES - 1) ? acc[i][j][r] : *slot + acc[i][j][r];
+                    }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (wave == 0) {
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    acc[i][j][r] += red[0][(i * FN + j) * 4 + r][lane] + red[1][(i * FN + j) * 4 + r][lane] +
-                                    red[2][(i * FN + j) * 4 + r][lane];
-        gemm_epilogue<FM, FN>(p, acc, 0, n0, 0, lane);
+                for (int r = 0; r < 4; ++r) acc[i][j][r] += red[(i * FN + j) * 4 + r][lane];
+        gemm_epilogue<16, FM, FN>(p, acc, 0, n0, 0, lane);
     }
 }
 
@@ -402,10 +428,10 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     }
     switch (pick_variant(p)) {
         case V_SKINNY1:
-            hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);
             break;
         case V_SKINNY9:
-            hipLaunchKernelGGL(skinny_gemm_kernel<9>, dim3(cris_cdiv(p.N, 32)), dim3(256), 0, s, p);
+            hipLaunchKernelGGL(skinny_gemm_kernel<9>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);
             break;
         case V_128x64:
             hipLaunchKernelGGL(k_128x64, dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256),
@@ -474,6 +500,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
     const int xc = xvalid ? xk - xtap * p.C : 0;
     const int xkh = xtap / p.KW, xkw = xtap - xkh * p.KW;
 
+    // bias gradient (column sums of dY) rides along in the blocks of the first k-tile
+    const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     uint4 ry[8], rx[8];
     auto load_step = [&](int mb) {
 #pragma unroll
@@ -498,6 +527,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
     };
     auto store_step = [&]() {
         uint4 o[8];
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float f[8];
+                unpack8(ry[i], f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+            }
+        }
         transpose8x8(ry, o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(sy + wg_off(vec * 8 + j, mg)) = o[j];
@@ -506,48 +544,63 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
         for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(sx + wg_off(vec * 8 + j, mg)) = o[j];
     };
 
-    f32x4 acc[4][4];
+    // wave tile 64 (n) x 64 (k) as 2x2 fragments of v_mfma_f32_32x32x16_bf16 (half the LDS read traffic per flop of 16x16x32)
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 15, fg = lane >> 4;
+    const int fr = lane & 31, fh = lane >> 5;
     load_step(m_begin);
     for (int mb = m_begin; mb < m_end; mb += WG_T) {
         store_step();
         __syncthreads();
         if (mb + WG_T < m_end) load_step(mb + WG_T);       // in flight during the MFMAs
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 af[4], bfr[4];
+        for (int ks = 0; ks < 8; ++ks) {                     // 8 slices of 16 pixels per 128-pixel step
+            bf16x8 af[2], bfr[2];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sy + wg_off(wr * 64 + i * 16 + fr, ks * 4 + fg));
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sy + wg_off(wr * 64 + i * 32 + fr, ks * 2 + fh));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sx + wg_off(wc * 64 + j * 16 + fr, ks * 4 + fg));
+            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sx + wg_off(wc * 64 + j * 32 + fr, ks * 2 + fh));
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();
     }
 
+    if (do_bias) {                                   // block-wide column sums: [16 row groups][128 n] through LDS
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) red[mg * 128 + vec * 8 + j] = bsum[j];
+        __syncthreads();
+        if (t < 128 && n0 + t < p.N) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sacc += red[g * 128 + t];
+            atomicAdd(p.dbias + n0 + t, sacc);
+        }
+    }
     // epilogue: GEMM-layout gradient dW[n][k] (k contiguous: the 16 lanes of a fragment row hit 64 contiguous bytes);
     // plain stores when this block owns the whole reduction, fp32 atomics otherwise
     const bool single = p.splits == 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int n = n0 + wr * 64 + i * 16 + fg * 4 + r;
+        for (int r = 0; r < 16; ++r) {                       // C/D: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+            const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
             if (n >= p.N) continue;
             float* row = p.dW + (size_t)n * p.ldw;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = k0 + wc * 64 + j * 16 + fr;
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + wc * 64 + j * 32 + fr;
                 if (k >= p.K) continue;
                 if (single) row[k] = acc[i][j][r];
                 else atomicAdd(row + k, acc[i][j][r]);

@@ -8,6 +8,7 @@
 // BN coefficients
 // ------------------------------------------------------------------------------------------------
 #define BN_MERGE_SLICES 64      // first-level merge width for long partial lists (see cris_bn_partials_rows)
+#define BN_MERGE_MIN 512        // lists up to this long go straight to the (16-lane) final merge
 
 // Chan et al. pairwise update of (n, mean, M2) with a block (nb rows, sum sb, M2 mb)
 __device__ __forceinline__ void chan_add(float& n, float& mean, float& m2, float nb, float sb, float mb) {
@@ -47,34 +48,39 @@ __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__
     }
 }
 
-__global__ void bn_finalize_kernel(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
+// final merge + coefficients: block = 16 channels x 16 part lanes (coalesced 64-B rows), LDS tree over the part lanes
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
                                    float count, const float* gamma, const float* beta, float* rmean, float* rvar,
                                    float momentum, float eps, int C, float* scale, float* shift, float* mean_o,
                                    float* invstd_o, float* merged /* optional [2*C]: local (sum, M2) for SyncBN */,
                                    const float* global_stats /* optional [2*C]: (sum, M2 about the global mean) */) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float mean, m2;
-    if (global_stats) {
-        mean = global_stats[c] / count;
-        m2 = global_stats[C + c];
-    } else {
-        // merge per-block partials (Chan et al.) in one pass
-        float n = 0.f;
-        mean = 0.f;
-        m2 = 0.f;
-        const int M = (int)count_local;
-        for (int i = 0; i < nparts; ++i) {
-            const int rows = min(rows_per_part, M - i * rows_per_part);
-            if (rows <= 0) break;
-            chan_add(n, mean, m2, (float)rows, psum[(size_t)i * C + c], pm2[(size_t)i * C + c]);
+    __shared__ float sh[3][16][17];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (!global_stats) {
+        if (c < C) {
+            const int M = (int)count_local;
+            for (int i = pl; i < nparts; i += 16) {
+                const int rows = min(rows_per_part, M - i * rows_per_part);
+                if (rows > 0) chan_add(n, mean, m2, (float)rows, psum[(size_t)i * C + c], pm2[(size_t)i * C + c]);
+            }
         }
+        sh[0][pl][cl] = n; sh[1][pl][cl] = mean; sh[2][pl][cl] = m2;
+        __syncthreads();
+        if (pl != 0 || c >= C) return;
+#pragma unroll
+        for (int j = 1; j < 16; ++j) chan_add(n, mean, m2, sh[0][j][cl], sh[1][j][cl] * sh[0][j][cl], sh[2][j][cl]);
         if (merged) {                       // hand the local (sum, M2) to the SyncBN exchange; finalize runs again after it
             merged[c] = mean * n;
             merged[C + c] = m2;
             mean_o[c] = mean;               // local mean, needed to re-centre M2 about the global mean
             return;
         }
+    } else {
+        if (pl != 0 || c >= C) return;
+        mean = global_stats[c] / count;
+        m2 = global_stats[C + c];
     }
     const float var = fmaxf(m2 / count, 0.f);
     const float inv = rsqrtf(var + eps);
@@ -91,7 +97,7 @@ __global__ void bn_finalize_kernel(const float* psum, const float* pm2, int npar
 }
 
 // rows the caller must allocate for a partials buffer of `nparts` parts (room for the level-1 merge output)
-extern "C" int cris_bn_partials_rows(int nparts) { return nparts > 2 * BN_MERGE_SLICES ? nparts + BN_MERGE_SLICES : nparts; }
+extern "C" int cris_bn_partials_rows(int nparts) { return nparts > BN_MERGE_MIN ? nparts + BN_MERGE_SLICES : nparts; }
 
 extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
                                 float count, const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -99,7 +105,7 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
                                 float* merged, const float* global_stats, void* stream) {
     CRIS_CHECK_ARG((global_stats || (psum && pm2 && nparts > 0 && rows_per_part > 0)) && gamma && beta && mean && C > 0 && count > 0.f, "bad args");
     CRIS_CHECK_ARG(merged || (scale && shift && invstd), "bad args");
-    if (!global_stats && nparts > 2 * BN_MERGE_SLICES) {
+    if (!global_stats && nparts > BN_MERGE_MIN) {
         // two-level merge: BN_MERGE_SLICES slices written behind the partials (rows nparts .. nparts+slices)
         const int pps = cris_cdiv(nparts, BN_MERGE_SLICES);
         const int slices = cris_cdiv(nparts, pps);
@@ -113,7 +119,7 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
         nparts = slices;
         rows_per_part *= pps;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
                        count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
                        merged, global_stats);
     CRIS_LAUNCH_CHECK();

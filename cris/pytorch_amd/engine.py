@@ -82,6 +82,10 @@ class Engine:
         # the text encoder (12 layers of M = B*L ~ 136-row GEMMs: latency-bound, ~16 workgroups each) is independent of
         # the visual encoder until the neck: it runs on a second HIP stream, forward and backward, underneath the convs
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # weight gradients only feed the gradient arena (read by the exchange / optimizer at the end): they run on a third
+        # stream behind the dgrad + BatchNorm chain of the launch stream, filling the CUs those mid-size kernels leave idle
+        self.wstream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self._keepalive = []
         self._tables = {}
         self._build_grad_arena()
         self._build_packs()
@@ -211,6 +215,18 @@ class Engine:
         t = (self.zeros if zero else self.empty)(Bn * H * W, ld, dtype=dtype)
         return Act(t, Bn, H, W, C, ld)
 
+    def wgrad_async(self, fn, *keep):
+        """run `fn` (weight-gradient launches) on the wgrad stream after everything issued so far on the current stream;
+        `keep`: temporaries it reads, kept alive until backward() joins the streams"""
+        if self.wstream is None:
+            fn()
+            return
+        cur = torch.cuda.current_stream()
+        self.wstream.wait_stream(cur)
+        with torch.cuda.stream(self.wstream):
+            fn()
+        self._keepalive.extend(keep)
+
     def drop(self, layer, site):
         p = self.head.dropout if self.training else 0.0
         return Drop(p, self.seed, layer * 8 + site, self.seed_dev) if p > 0 else NO_DROP
@@ -255,14 +271,15 @@ class Engine:
                 gy_ld, gy_coff = pad8(N), 0
             else:
                 gy, gy_ld, gy_coff = out.g, out.ld, out.coff
-            if w_transposed:
-                # parameter stored [in, out] (used as x @ P): dP = x^T dY - same kernel with the operand roles swapped
-                ops.conv_wgrad(x.t, gy, Geom.linear(out.M, pad8(N)), x.C, Gw, ldy=x.ld, y_coff=x.coff, N_ld=x.C, ldx=gy_ld,
-                               x_coff=gy_coff)
-            else:
-                ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff)
-            if bias is not None:
-                ops.colsum(gy, out.M, N, self.G[bias][n0:n0 + N], ldx=gy_ld, coff=gy_coff)
+            def wg():
+                if w_transposed:
+                    # parameter stored [in, out] (used as x @ P): dP = x^T dY - same kernel with the operand roles swapped
+                    ops.conv_wgrad(x.t, gy, Geom.linear(out.M, pad8(N)), x.C, Gw, ldy=x.ld, y_coff=x.coff, N_ld=x.C, ldx=gy_ld,
+                                   x_coff=gy_coff)
+                else:
+                    ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff,
+                                   dbias=None if bias is None else self.G[bias][n0:n0 + N])
+            self.wgrad_async(wg, gy)
             if no_dgrad:
                 return
             assert N % 8 == 0, "dgrad path needs N % 8 == 0 (pad the gradient buffer otherwise)"
@@ -740,8 +757,8 @@ class Engine:
                 dwb = self._dwb                                        # fp32 [B, ld] filled by dynconv_bwd
                 gy = self.empty(state.M, wb.ld)
                 ops.cast_f32_bf16(dwb, gy)
-                ops.conv_wgrad(gy, state.t, g, nwb, self.G[p + ".weight"], ldy=wb.ld, N_ld=wb.ld, ldx=state.ld, x_coff=state.coff)
-                ops.colsum(gy, state.M, nwb, self.G[p + ".bias"], ldx=wb.ld)
+                self.wgrad_async(lambda: ops.conv_wgrad(gy, state.t, g, nwb, self.G[p + ".weight"], ldy=wb.ld, N_ld=wb.ld,
+                                                        ldx=state.ld, x_coff=state.coff, dbias=self.G[p + ".bias"]), gy)
                 gx, acc = state.grad_target()
                 gD = Geom.linear(state.M, wb.ld)
                 ops.conv_gemm(gy, self.WD[p + ".weight"], gD, state.C, lda=wb.ld, out=gx, ldc=state.ld, c_coff=state.coff,
@@ -818,11 +835,16 @@ class Engine:
         marks = dict(self._stage_marks)                 # tape index at which a stage's closures START
         (t0, t1), (v0, v1) = self._ranges["text"], self._ranges["visual"]
         head_start = max(t1, v1)                        # neck / decoder / projector closures: main stream
+        def join_wgrads():
+            if self.wstream is not None:
+                torch.cuda.current_stream().wait_stream(self.wstream)
+
         for i in range(len(self.tape) - 1, head_start - 1, -1):
             self.tape[i]()
             if on_stage_done is not None and i in marks:
                 for st in marks[i]:
                     if st >= 2:
+                        join_wgrads()
                         on_stage_done(st)
         # the two encoders' backward passes are independent: text on the side stream, visual on the launch stream
         main = torch.cuda.current_stream()
@@ -838,6 +860,8 @@ class Engine:
             self.tape[i]()
         if self.side is not None:
             main.wait_stream(self.side)
+        join_wgrads()
+        self._keepalive = []
         if on_stage_done is not None:
             on_stage_done(1)
             on_stage_done(0)

@@ -38,7 +38,8 @@ class WgradParams(C.Structure):
                 ("Bn", I), ("H", I), ("W", I), ("C", I),
                 ("OH", I), ("OW", I), ("KH", I), ("KW", I), ("stride", I), ("pad", I),
                 ("M", I), ("N", I), ("K", I),
-                ("ldw", I), ("splits", I)]
+                ("ldw", I), ("splits", I),
+                ("dbias", P)]
 
 
 class PackDesc(C.Structure):

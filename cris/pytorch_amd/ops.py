@@ -168,7 +168,7 @@ def wgrad_splits(M: int, N: int, K: int) -> int:
     return max(1, min(want, (steps + 3) // 4, 512))
 
 
-def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, ldw=None, splits=None):
+def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, ldw=None, splits=None, dbias=None):
     p = hip.WgradParams()
     p.dY, p.X, p.dW = ptr(dY), ptr(X), ptr(dW)
     p.ldy = ldy if ldy is not None else dY.shape[-1]
@@ -180,6 +180,7 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
     p.OH, p.OW, p.KH, p.KW, p.stride, p.pad = g.OH, g.OW, g.KH, g.KW, g.stride, g.pad
     p.M, p.N, p.K = g.M, N, g.K
     p.ldw = ldw if ldw is not None else dW.shape[-1]
+    p.dbias = ptr(dbias)
     p.splits = splits if splits is not None else wgrad_splits(g.M, N, g.K)
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.launch("conv_wgrad", 2.0 * g.M * N * g.K, 2.0 * (g.M * N + g.M * g.C) + 4.0 * N * g.K, "cris_conv_wgrad", C.byref(p),
@@ -247,7 +248,7 @@ def colsum(x, M, N, out, ldx=None, coff=0):
 # ---- BatchNorm ---------------------------------------------------------------------------------
 def partials_rows(nparts: int) -> int:
     """rows a partials buffer needs (room for bn_finalize's first-level merge; cris_bn_partials_rows)"""
-    return nparts + 64 if nparts > 128 else nparts
+    return hip.load().cris_bn_partials_rows(nparts)
 
 
 class Stats:

@@ -82,6 +82,7 @@ typedef struct {
     int M, N, K;
     int ldw;                 /* row stride of dW (>= K) */
     int splits;              /* grid.z; each split covers ceil(M/splits) rows rounded up to 128 */
+    float* dbias;            /* optional [N]: += column sums of dY (bias gradient), fp32 atomics; or NULL */
 } cris_wgrad_params;
 int cris_conv_wgrad(const cris_wgrad_params* p, void* stream);
 

@@ -168,7 +168,9 @@ def test_conv_wgrad(case):
     dy = dy.to(BF).float()
     for splits in (None, 1):                                  # atomics path (split reduction) and plain-store path
         dWg = torch.zeros(N, k * k * C_, device=DEV)           # GEMM layout [n][tap][c]
-        ops.conv_wgrad(bf(dy), bf(x), g, N, dWg, splits=splits)
+        dbias = torch.zeros(N, device=DEV)
+        ops.conv_wgrad(bf(dy), bf(x), g, N, dWg, splits=splits, dbias=dbias)
+        check(dbias, dy[:, :N].sum(0), 1e-5, "bias gradient fused into wgrad %s" % case)
         dW = dWg.view(N, k * k, C_)[:, :, :C_real].permute(0, 2, 1).reshape(N, C_real, k, k)
         # reference: autograd of conv2d wrt weight
         wt = torch.zeros(N, C_real, k, k, requires_grad=True)
@@ -236,7 +238,7 @@ def test_bn_finalize_two_level_merge():
     M, C_ = 40000, 72                                        # 1250 parts of 32 rows, ragged last slice
     y = (rnd(M, C_) * 2.0 + 3.0).to(BF).float()
     st = ops.colstats(bf(y), M, C_, 32, DEV)
-    assert st.nparts > 128 and st.t.shape[1] == st.nparts + 64
+    assert st.nparts > 512 and st.t.shape[1] == st.nparts + 64
     outs = [torch.empty(C_, device=DEV) for _ in range(4)]
     ops.bn_finalize(st, M, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs)
     check(outs[2], y.double().mean(0), 1e-6, "mean")
