@@ -56,7 +56,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the captured HIP graph")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the Python schedule (no graph / command list)")
+    ap.add_argument("--launch", default=None, choices=["graph", "cmdlist", "eager"], help="default: graph on 1 GPU, cmdlist on N > 1")
     ap.add_argument("--shape-table", default=None, help="write the per-shape GEMM timing table (tsv) here")
     args = ap.parse_args()
 
@@ -80,7 +81,7 @@ def main():
 
     clip, head = arch.specs_by_name(args.spec)
     sd = arch.synthetic_state_dict(clip, head, 0)
-    tr = NativeTrainer(clip, head, sd, dev, comm=comm, sync_bn=world > 1, use_graph=not args.no_graph)
+    tr = NativeTrainer(clip, head, sd, dev, comm=comm, sync_bn=world > 1, use_graph=not args.no_graph, launch=args.launch)
     del sd
     nb = 4
     batches = [tuple(t.to(dev) for t in synth.make_batch(args.batch, args.size, head.word_len, rank, s)) for s in range(nb)]
@@ -132,7 +133,7 @@ def main():
                                    % (args.spec.upper(), args.size, args.size, args.batch,
                                       "" if world == 1 else "; x%d GPUs = configs[2] recipe: SyncBN + gradient all-reduce over RCCL" % world),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first_loss, "final_loss": loss_v,
-                       "launch": "hip_graph" if tr._graph is not None else "eager", "graph_error": tr.graph_error},
+                       "launch": tr.launch, "graph_error": tr.graph_error},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12),
                               "hbm_frac_alg": (sps / world * ALG_BYTES_PER_SAMPLE + steps_s * ADAM_BYTES_PER_STEP) / (HBM_PEAK * 1e9)},
         }

@@ -40,3 +40,13 @@ extern "C" long cris_echo_conv_gemm(const void* vp) {
     h = h * 31 + p->drop_seed; h = h * 31 + p->drop_stream;
     return h;
 }
+
+extern "C" int cris_zero_bytes(void* p, size_t nbytes, void* stream) {
+    if (!p || nbytes == 0) return 0;
+    hipError_t e = hipMemsetAsync(p, 0, nbytes, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        cris_set_error("cris_zero_bytes: %s", hipGetErrorString(e));
+        return (int)e;
+    }
+    return 0;
+}

@@ -13,6 +13,7 @@ Reference call graph being restated (file:line in DerrickWang005/CRIS.pytorch):
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, List, Optional
 
 import torch
@@ -55,7 +56,7 @@ class Act:
         if r._g is None:
             # a channel slice writes only its columns: the rest must read as zero for later accumulation
             partial = self.C < r.t.shape[-1]
-            r._g = torch.zeros_like(r.t) if partial else torch.empty_like(r.t)
+            r._g = ops.zero_(torch.empty_like(r.t)) if partial else torch.empty_like(r.t)
             return r._g, partial
         return r._g, True
 
@@ -84,7 +85,8 @@ class Engine:
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         # weight gradients only feed the gradient arena (read by the exchange / optimizer at the end): they run on a third
         # stream behind the dgrad + BatchNorm chain of the launch stream, filling the CUs those mid-size kernels leave idle
-        self.wstream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        self.wstream = (torch.cuda.Stream(device=device)
+                        if torch.device(device).type == "cuda" and os.environ.get("CRIS_WGRAD_STREAM", "0") == "1" else None)
         self._keepalive = []
         self._tables = {}
         self._build_grad_arena()
@@ -205,7 +207,7 @@ class Engine:
     # small helpers
     # ------------------------------------------------------------------------------------------
     def zeros(self, *shape, dtype=F32):
-        return torch.zeros(*shape, dtype=dtype, device=self.dev)
+        return ops.zero_(torch.empty(*shape, dtype=dtype, device=self.dev))
 
     def empty(self, *shape, dtype=BF16):
         return torch.empty(*shape, dtype=dtype, device=self.dev)
@@ -222,7 +224,7 @@ class Engine:
             fn()
             return
         cur = torch.cuda.current_stream()
-        self.wstream.wait_stream(cur)
+        ops.torch_op(lambda: self.wstream.wait_stream(cur))
         with torch.cuda.stream(self.wstream):
             fn()
         self._keepalive.extend(keep)
@@ -312,9 +314,9 @@ class Engine:
             gcount = count * self.comm.world
             merged = self.zeros(2 * C)
             ops.bn_finalize(st, count, count, gamma, beta, None, None, BN_MOM, BN_EPS, C, None, None, mean, None, merged=merged)
-            self.comm.allreduce_sum(merged[:C])
+            ops.torch_op(lambda: self.comm.allreduce_sum(merged[:C]))
             ops.bn_recentre(merged[C:], mean, merged[:C], count, gcount, C)
-            self.comm.allreduce_sum(merged[C:])
+            ops.torch_op(lambda: self.comm.allreduce_sum(merged[C:]))
             ops.bn_finalize(None, count, gcount, gamma, beta, rm, rv, BN_MOM, BN_EPS, C, scale, shift, mean, invstd,
                             global_stats=merged)
             return scale, shift, mean, invstd, gcount
@@ -364,7 +366,7 @@ class Engine:
 
             def between(s):
                 ops.axpy_f32(arena_block, s, 1.0)
-                self.comm.allreduce_sum(s)
+                ops.torch_op(lambda: self.comm.allreduce_sum(s))
 
             need_z = relu and not pool and (ident is not None or y2 is not None)
             ops.bn_bwd(out.g, y.t, scale, shift, mean, invstd, sums, dy, y.Bn, y.H, y.W, C, gcount, lddz=out.ld, dz_coff=out.coff,
@@ -584,7 +586,7 @@ class Engine:
             def bwd_eot():
                 gx, acc = xf.grad_target()
                 if not acc:
-                    gx.zero_()
+                    ops.zero_(gx)
                 ops.eot_scatter_add(eot, rows.g, B, L, D, gx)
             self.tape.append(bwd_eot)
         state = self.gemm(rows, "backbone.text_projection", self.clip.embed_dim, w_transposed=True)
@@ -774,14 +776,14 @@ class Engine:
         self._dgrad_outT = None
         self._stage_marks = {}
         if training:
-            self.grad_arena.zero_()
+            ops.zero_(self.grad_arena)
         self.repack_weights()
         word = word.contiguous()
         main = torch.cuda.current_stream()
         starts = {1: 0}
         self._text_tape_start = 0
         if self.side is not None:
-            self.side.wait_stream(main)
+            ops.torch_op(lambda: self.side.wait_stream(main))
             with torch.cuda.stream(self.side):
                 txt, state = self._encode_text(word)
         else:
@@ -789,7 +791,7 @@ class Engine:
         starts[0] = len(self.tape)
         v3, v4, v5, feats = self._encode_image(img.contiguous().float())
         if self.side is not None:
-            main.wait_stream(self.side)
+            ops.torch_op(lambda: main.wait_stream(self.side))
         starts[2] = len(self.tape)
         self._ranges = dict(text=(starts[1], starts[0]), visual=(starts[0], starts[2]))
         fq = self._fpn(v3, v4, v5, state)
@@ -837,7 +839,8 @@ class Engine:
         head_start = max(t1, v1)                        # neck / decoder / projector closures: main stream
         def join_wgrads():
             if self.wstream is not None:
-                torch.cuda.current_stream().wait_stream(self.wstream)
+                cur = torch.cuda.current_stream()
+                ops.torch_op(lambda: cur.wait_stream(self.wstream))
 
         for i in range(len(self.tape) - 1, head_start - 1, -1):
             self.tape[i]()
@@ -849,7 +852,7 @@ class Engine:
         # the two encoders' backward passes are independent: text on the side stream, visual on the launch stream
         main = torch.cuda.current_stream()
         if self.side is not None:
-            self.side.wait_stream(main)
+            ops.torch_op(lambda: self.side.wait_stream(main))
             with torch.cuda.stream(self.side):
                 for i in range(t1 - 1, t0 - 1, -1):
                     self.tape[i]()
@@ -859,7 +862,7 @@ class Engine:
         for i in range(v1 - 1, v0 - 1, -1):
             self.tape[i]()
         if self.side is not None:
-            main.wait_stream(self.side)
+            ops.torch_op(lambda: main.wait_stream(self.side))
         join_wgrads()
         self._keepalive = []
         if on_stage_done is not None:

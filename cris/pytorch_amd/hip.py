@@ -197,6 +197,7 @@ _SIGS = {
     "cris_bce_bwd": (I, [P, P, L, P, P, P]),
     "cris_train_metric": (I, [P, P, I, I, F, F, P, P]),
     "cris_memset_f32": (I, [P, F, L, P]),
+    "cris_zero_bytes": (I, [P, C.c_size_t, P]),
     "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, P]),
     "cris_adam_block_elems": (I, []),
     "cris_unpack_grads": (I, [P, I, I, P]),
@@ -238,11 +239,36 @@ def check(rc, what=""):
         raise HipLibraryError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
 
 
+class CommandList:
+    """Host-side command list of one step: every libcris_hip launch (function + ctypes arguments, stream included) and
+    every torch-level op (stream wait, collective) in issue order.  Replaying it costs a few microseconds of Python per
+    entry instead of the schedule's Python (closures, struct filling, allocations) - the launch mode used where a HIP graph
+    is not (collectives inside the step).  All buffers the commands point to must stay allocated (trainer.py: MemPool)."""
+
+    def __init__(self):
+        self.cmds = []
+
+    def replay(self):
+        for fn, args, name in self.cmds:
+            if args is None:
+                fn()
+            else:
+                rc = fn(*args)
+                if rc != 0:
+                    check(rc, name)
+
+
+RECORDER = None          # a CommandList while a step is being recorded
+
+
 def call(name, *args):
     """Invoke an exported launcher and raise on a non-zero return code."""
-    rc = getattr(load(), name)(*args)
+    fn = getattr(load(), name)
+    rc = fn(*args)
     if rc != 0:
         check(rc, name)
+    if RECORDER is not None:
+        RECORDER.cmds.append((fn, args, name))
 
 
 def ptr(t):

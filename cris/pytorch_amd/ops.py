@@ -527,6 +527,29 @@ def train_metric(logits, target, Bn, HW, out, thr=0.35, pr_iou=0.5):
     hip.call("cris_train_metric", ptr(logits), ptr(target), Bn, HW, float(thr), float(pr_iou), ptr(out), _stream())
 
 
+def zero_(t):
+    """zero fill through the library (hipMemsetAsync on the launch stream): recorded / captured like every other launch"""
+    hip.call("cris_zero_bytes", ptr(t), t.numel() * t.element_size(), _stream())
+    return t
+
+
+def torch_op(fn):
+    """Run a torch-level op of the step now (stream wait, collective) and, while a step is being recorded, put it on the
+    command list bound to the stream that is current now."""
+    fn()
+    rec = hip.RECORDER
+    if rec is not None:
+        s = torch.cuda.current_stream()
+
+        def run():
+            if torch.cuda.current_stream() == s:
+                fn()
+            else:
+                with torch.cuda.stream(s):
+                    fn()
+        rec.cmds.append((run, None, "torch_op"))
+
+
 def memset_f32(t, v=0.0):
     hip.call("cris_memset_f32", ptr(t), float(v), t.numel(), _stream())
 

@@ -11,6 +11,13 @@ HIP graph (torch.cuda.CUDAGraph over the launch stream; the independent text-enc
 stream and so becomes a parallel branch of the graph) and replayed per step: one host call per step instead of one per
 kernel.  What changes from step to step lives in device memory: the input batch (static buffers the caller's tensors
 are copied into), the step counter (Adam bias corrections) and the dropout seed (`cris_step_advance`).
+
+With more than one rank the step contains RCCL collectives (SyncBN statistics, gradient exchange).  There the default
+launch mode is a host-side COMMAND LIST (hip.CommandList): the second step is executed once more by the Python schedule
+while every library call (function pointer + ctypes arguments) and every torch-level op (stream wait, collective) is
+recorded, with all of its buffers allocated from a private torch MemPool so their addresses stay valid; later steps
+replay the list - a few microseconds of Python per launch, collectives issued by torch.distributed as usual.
+`launch=` / CRIS_LAUNCH selects "graph", "cmdlist" or "eager" explicitly.
 """
 import os
 from typing import Optional
@@ -31,7 +38,7 @@ def split_state_dict(sd, device):
 
 class NativeTrainer:
     def __init__(self, clip: ClipSpec, head: HeadSpec, state_dict, device, base_lr=1e-4, lr_multi=0.1, weight_decay=0.0,
-                 comm=None, sync_bn=False, use_graph: Optional[bool] = None):
+                 comm=None, sync_bn=False, use_graph: Optional[bool] = None, launch: Optional[str] = None):
         self.device = device
         params, buffers = split_state_dict(state_dict, device)
         self.engine = Engine(clip, head, params, buffers, device, comm=comm, sync_bn=sync_bn)
@@ -49,10 +56,21 @@ class NativeTrainer:
         # per-step device state: steps done (int32) and the dropout seed of the running step
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)
-        if use_graph is None:
-            use_graph = os.environ.get("CRIS_NO_GRAPH", "0") != "1"
-        self.use_graph = bool(use_graph) and torch.device(device).type == "cuda"
+        if launch is None:
+            launch = os.environ.get("CRIS_LAUNCH")
+        if launch is None:
+            if use_graph is False or os.environ.get("CRIS_NO_GRAPH", "0") == "1":
+                launch = "eager"
+            else:
+                launch = "graph" if self.comm.world == 1 else "cmdlist"
+        if torch.device(device).type != "cuda":
+            launch = "eager"
+        assert launch in ("graph", "cmdlist", "eager"), launch
+        self.launch = launch
+        self.use_graph = launch != "eager"
         self._graph = None
+        self._cmds = None
+        self._pool = None
         self._static = None
         self._eager_steps = 0
         self.graph_error = None
@@ -63,8 +81,8 @@ class NativeTrainer:
 
     def set_group_lrs(self, lr_backbone, lr_head):
         self.adam.set_lrs([lr_backbone if self.group[n] == 0 else lr_head for n in self.names])
-        self._graph = None                       # learning rates live in the device table: no re-capture needed, but
-        self._eager_steps = 0                    # the table buffer was re-uploaded (new address) -> capture again
+        self._graph = self._cmds = None          # learning rates live in the device table, which was re-uploaded (new
+        self._eager_steps = 0                    # address): capture / record again
 
     # ------------------------------------------------------------------------------------------------
     def _step_body(self, img, word, mask, host_seed: Optional[int]):
@@ -79,13 +97,13 @@ class NativeTrainer:
         if self.comm.world > 1:
             def on_stage(st):
                 lo, hi = e.stage_ranges[st]
-                self.comm.allreduce_async(e.grad_arena[lo:hi])
+                ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))
             e.backward(on_stage_done=on_stage)
-            self.comm.wait_all()
+            ops.torch_op(self.comm.wait_all)
         else:
             e.backward()
         self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
-        self.metric.zero_()
+        ops.zero_(self.metric)
         ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         return loss, pred, msk
 
@@ -97,19 +115,26 @@ class NativeTrainer:
             return loss, self.metric
         key = (tuple(img.shape), tuple(word.shape), tuple(mask.shape))
         if self._static is not None and self._static[0] != key:
-            self._graph, self._static, self._eager_steps = None, None, 0      # new shapes: new schedule
-        if self._graph is None:
+            self._graph, self._cmds, self._static, self._eager_steps = None, None, None, 0      # new shapes: new schedule
+        if self._graph is None and self._cmds is None:
             if self._eager_steps < 1:
                 # first step with these shapes runs eagerly: constant tables get uploaded, the allocator warms up
                 self._eager_steps += 1
                 self._static = (key, img.clone(), word.clone(), mask.clone())
                 loss, _, _ = self._step_body(self._static[1], self._static[2], self._static[3], None)
                 return loss, self.metric
+            if self.launch == "cmdlist":
+                _, s_img, s_word, s_mask = self._static
+                s_img.copy_(img, non_blocking=True)
+                s_word.copy_(word, non_blocking=True)
+                s_mask.copy_(mask, non_blocking=True)
+                return self._record(), self.metric            # this call executes the step while recording it
             try:
                 self._capture()
             except Exception as ex:              # noqa: BLE001 - e.g. a collective that cannot be captured
                 self.graph_error = repr(ex)
                 self.use_graph = False
+                self.launch = "eager"
                 torch.cuda.synchronize(self.device)
                 loss, _, _ = self._step_body(img, word, mask, None)
                 return loss, self.metric
@@ -117,7 +142,10 @@ class NativeTrainer:
         s_img.copy_(img, non_blocking=True)
         s_word.copy_(word, non_blocking=True)
         s_mask.copy_(mask, non_blocking=True)
-        self._graph.replay()
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._cmds.replay()
         return self._loss, self.metric
 
     def _capture(self):
@@ -127,6 +155,22 @@ class NativeTrainer:
         with torch.cuda.graph(g):
             loss, pred, msk = self._step_body(s_img, s_word, s_mask, None)
         self._graph, self._loss, self._keep = g, loss, (pred, msk)
+
+    def _record(self):
+        """Execute one step through the Python schedule while recording it as a command list; every buffer it allocates
+        comes from a private MemPool that stays reserved, so the recorded addresses remain valid for the replays."""
+        from . import hip
+        _, s_img, s_word, s_mask = self._static
+        self._pool = torch.cuda.MemPool()
+        rec = hip.CommandList()
+        with torch.cuda.use_mem_pool(self._pool):
+            hip.RECORDER = rec
+            try:
+                loss, pred, msk = self._step_body(s_img, s_word, s_mask, None)
+            finally:
+                hip.RECORDER = None
+        self._cmds, self._loss, self._keep = rec, loss, (pred, msk)
+        return loss
 
     @torch.no_grad()
     def eval_forward(self, img, word):

@@ -300,6 +300,8 @@ int cris_train_metric(const float* logits, const float* target, int Bn, int HW, 
                       void* stream);
 /* elementwise multiply by per-(batch,channel) scalar handled inside cris_bn_apply (mul) */
 int cris_memset_f32(float* p, float v, long n, void* stream);
+/* zero fill of any buffer (hipMemsetAsync on `stream`; capturable into a HIP graph) */
+int cris_zero_bytes(void* p, size_t nbytes, void* stream);
 
 /* fused multi-tensor Adam (torch.optim.Adam semantics, train.py:105-107): table of {p,g,m,v,n}.
  * p/m/v are in the parameter layout; g is in the parameter layout when taps == 0, else in the GEMM layout

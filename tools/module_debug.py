@@ -34,6 +34,12 @@ for use_scaler in (False, True):
         d = float((a - b).norm() / (b.norm() + 1e-30))
         worst.append((d, n, bool(torch.isfinite(p.grad).all())))
     worst.sort(reverse=True)
+    Gm = model._engine.grads_param_layout()
+    exp = sorted(((float((p.grad.float() / scale - Gm[n].float() / scale).norm() / (Gm[n].float().norm() / scale + 1e-30)), n)
+                  for n, p in model.named_parameters() if p.grad is not None), reverse=True)
+    print("  export (p.grad vs module engine arena) worst:", exp[:3])
+    eng = sorted(((float((Gm[n].float() / scale - G[n].float()).norm() / (G[n].float().norm() + 1e-30)), n) for n in G if n in Gm), reverse=True)
+    print("  module engine arena vs trainer engine arena worst:", eng[:4])
     print("scaler", use_scaler, "loss", float(loss), float(l2), "pred equal", bool(torch.equal(pred, p2)))
     print("  worst grad rel diff:", worst[:6])
     print("  all finite:", all(w[2] for w in worst))
