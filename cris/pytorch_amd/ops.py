@@ -528,7 +528,7 @@ def train_metric(logits, target, Bn, HW, out, thr=0.35, pr_iou=0.5):
 
 
 def zero_(t):
-    """zero fill through the library (hipMemsetAsync on the launch stream): recorded / captured like every other launch"""
+    """zero fill through the library: recorded / captured like every other launch"""
     hip.call("cris_zero_bytes", ptr(t), t.numel() * t.element_size(), _stream())
     return t
 

@@ -300,7 +300,7 @@ int cris_train_metric(const float* logits, const float* target, int Bn, int HW, 
                       void* stream);
 /* elementwise multiply by per-(batch,channel) scalar handled inside cris_bn_apply (mul) */
 int cris_memset_f32(float* p, float v, long n, void* stream);
-/* zero fill of any buffer (hipMemsetAsync on `stream`; capturable into a HIP graph) */
+/* zero fill of any 16-byte aligned buffer */
 int cris_zero_bytes(void* p, size_t nbytes, void* stream);
 
 /* fused multi-tensor Adam (torch.optim.Adam semantics, train.py:105-107): table of {p,g,m,v,n}.

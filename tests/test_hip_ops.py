@@ -721,3 +721,10 @@ def test_adam_gemm_layout_gradient_and_device_step():
         tab.step_count = 100                                  # host counter deliberately wrong: the device count must win
         tab.step(step_dev=step_dev)
     check(dev_p, rp.data, 1e-6, "adam gemm-layout")
+
+
+def test_zero_bytes():
+    for n in (1, 15, 16, 17, 4099, 1 << 20):
+        t = torch.full((n + 32,), 7, dtype=torch.uint8, device=DEV)
+        ops.zero_(t[:n])
+        assert int(t[:n].max()) == 0 and int(t[n:].min()) == 7, n
