@@ -146,6 +146,15 @@ def main():
                                "frac": ach / MFMA_PEAK, "traffic": None,
                                "launches_per_step": d["launches"] / timer_steps, "avg_launch_us": 1000.0 * d["ms"] / d["launches"],
                                "share_of_step": (d["ms"] / timer_steps) / (1000.0 * dt / args.steps)}
+            # HBM bytes per launch of the same kernel from the PMC passes of tools/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE /
+            # WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction): a committed measurement, not taken live
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["kernels"]["conv_gemm_kernel"]
+                out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc, eager launches)"
+                out["roofline"]["algorithmic_bytes_per_launch"] = d["bytes"] / d["launches"]
+            except Exception:               # noqa: BLE001
+                pass
             out["roofline"]["timing"] = "HIP events around each launch, %d-step eager pass after the timed region" % timer_steps
             out["kernels"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                   "launches_per_step": v["launches"] / timer_steps} for k, v in summ.items()}

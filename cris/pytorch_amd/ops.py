@@ -112,7 +112,8 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
         st = Stats((g.M + rows - 1) // rows, N, rows, A.device)
         p.colsum, p.colsq = ptr(st[0]), ptr(st[1])
     if KERNEL_TIMER is not None:
-        KERNEL_TIMER.launch("conv_gemm_n128" if N > 64 else "conv_gemm_n64", 2.0 * g.M * N * g.K,
+        rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))
+        KERNEL_TIMER.launch("skinny_gemm" if rows in (16, 144) else "conv_gemm", 2.0 * g.M * N * g.K,
                             2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p),
                             tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
         return st

@@ -1,0 +1,48 @@
+"""Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/gpu_pmc.sh).
+FETCH_SIZE is in KiB and, on gfx950, reports HALF the bytes of wide coalesced reads (MI355X_MICROARCH.md, section HBM):
+it is doubled here.  WRITE_SIZE (KiB) is used as reported (uncalibrated).  Writes profiles/<tag>_hbm_traffic.json:
+{kernel: {launches, fetch_bytes_per_launch, write_bytes_per_launch, traffic_bytes_per_launch}}."""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(db_path, counter):
+    cur = sqlite3.connect(db_path).cursor()
+    rows = cur.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name",
+                       (counter,)).fetchall()
+    return {r[0]: (r[1], r[2] * 1024.0) for r in rows}
+
+
+def short(name):
+    return name.split("(")[0].split("<")[0].replace("void ", "")
+
+
+def main(fetch_db, write_db, out):
+    f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(f) | set(w)):
+        nf, fb = f.get(k, (0, 0.0))
+        nw, wb = w.get(k, (0, 0.0))
+        fpl = 2.0 * fb / nf if nf else 0.0
+        wpl = wb / nw if nw else 0.0
+        key = short(k)
+        if key in res:          # template variants share a short name: merge launch-weighted
+            a = res[key]
+            n0 = a["launches"]
+            a["fetch_bytes_per_launch"] = (a["fetch_bytes_per_launch"] * n0 + fpl * nf) / (n0 + nf)
+            a["write_bytes_per_launch"] = (a["write_bytes_per_launch"] * n0 + wpl * nf) / (n0 + nf)
+            a["launches"] = n0 + nf
+        else:
+            res[key] = {"launches": nf, "fetch_bytes_per_launch": fpl, "write_bytes_per_launch": wpl}
+    for a in res.values():
+        a["traffic_bytes_per_launch"] = a["fetch_bytes_per_launch"] + a["write_bytes_per_launch"]
+    json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported; eager launches, %s" % fetch_db, "kernels": res},
+              open(out, "w"), indent=1)
+    for k, a in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"])[:12]:
+        print("%-28s n=%5d fetch/launch %8.2f MB write/launch %8.2f MB" % (k, a["launches"], a["fetch_bytes_per_launch"] / 1e6,
+                                                                             a["write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2], sys.argv[3])
