@@ -9,6 +9,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;       // MFMA 16x16x3
 typedef __attribute__((ext_vector_type(4))) short s16x4;         // MFMA 16x16x16 A/B fragment (2 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float f32x4;         // MFMA 16x16 C/D fragment
 typedef __attribute__((ext_vector_type(16))) float f32x16;       // MFMA 32x32 C/D fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte raw buffer load
 
 #define CRIS_WAVE 64
 

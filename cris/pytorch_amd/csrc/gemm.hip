@@ -307,37 +307,40 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
     const int lane = t & 63, wave = t >> 6;
     const int fr = lane & 15, fg = lane >> 4;
     const int n0 = blockIdx.x * (FN * 16);
-    const bf16_t* arow[FM];
-    const bf16_t* brow[FN];
+    // raw buffer loads: rows >= M / columns >= N / K tails are out-of-range offsets (hardware zeros), no branches
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)((size_t)p.M * p.lda * 2),
+                                                                        CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wt), 0, (int)((size_t)p.N * p.ldb * 2),
+                                                                        CRIS_BUF_FLAGS);
+    unsigned aoff[FM], boff[FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
         const int m = i * 16 + fr;
-        arow[i] = m < p.M ? p.A + (size_t)m * p.lda + p.a_coff : nullptr;
+        aoff[i] = m < p.M ? ((unsigned)m * (unsigned)p.lda + (unsigned)p.a_coff) * 2u : CRIS_OOB;
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int n = n0 + j * 16 + fr;
-        brow[j] = n < p.N ? p.Wt + (size_t)n * p.ldb : nullptr;
+        boff[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb * 2u : CRIS_OOB;
     }
     f32x4 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const uint4 z = make_uint4(0, 0, 0, 0);
     constexpr int KSTEP = 32 * SK_WAVES;
     for (int kb = wave * 32; kb < p.K; kb += 2 * KSTEP) {              // wave-uniform trip count (MFMA ignores EXEC)
         const int k0 = kb + fg * 8, k1 = k0 + KSTEP;                  // K % 8 == 0: a chunk is either whole or absent
-        const bool v0 = k0 < p.K, v1 = k1 < p.K;
-        uint4 av0[FM], bv0[FN], av1[FM], bv1[FN];
+        const unsigned o0 = k0 < p.K ? (unsigned)k0 * 2u : CRIS_OOB, o1 = k1 < p.K ? (unsigned)k1 * 2u : CRIS_OOB;
+        u32x4 av0[FM], bv0[FN], av1[FM], bv1[FN];
 #pragma unroll
-        for (int i = 0; i < FM; ++i) av0[i] = (v0 && arow[i]) ? *reinterpret_cast<const uint4*>(arow[i] + k0) : z;
+        for (int i = 0; i < FM; ++i) av0[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (aoff[i] | o0) >= CRIS_OOB ? CRIS_OOB : aoff[i] + o0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bv0[j] = (v0 && brow[j]) ? *reinterpret_cast<const uint4*>(brow[j] + k0) : z;
+        for (int j = 0; j < FN; ++j) bv0[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (boff[j] | o0) >= CRIS_OOB ? CRIS_OOB : boff[j] + o0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) av1[i] = (v1 && arow[i]) ? *reinterpret_cast<const uint4*>(arow[i] + k1) : z;
+        for (int i = 0; i < FM; ++i) av1[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (aoff[i] | o1) >= CRIS_OOB ? CRIS_OOB : aoff[i] + o1, 0, 0);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) bv1[j] = (v1 && brow[j]) ? *reinterpret_cast<const uint4*>(brow[j] + k1) : z;
+        for (int j = 0; j < FN; ++j) bv1[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (boff[j] | o1) >= CRIS_OOB ? CRIS_OOB : boff[j] + o1, 0, 0);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -503,26 +506,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
     // bias gradient (column sums of dY) rides along in the blocks of the first k-tile
     const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    uint4 ry[8], rx[8];
+    // Loads are raw buffer loads: an invalid element (row beyond this split, channel tail, spatial padding) is an
+    // out-of-range byte offset that the hardware returns as zeros - a branch-free select, so the 16 loads of a step are
+    // issued back to back and stay in flight underneath the MFMAs of the previous step (with per-element branches the
+    // compiler waits for them right after issue).
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dY), 0, (int)((size_t)p.M * p.ldy * 2),
+                                                                        CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.X), 0, (int)((size_t)p.Bn * p.H * p.W * p.ldx * 2), CRIS_BUF_FLAGS);
+    u32x4 ry[8], rx[8];
     auto load_step = [&](int mb) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = mb + mg * 8 + i;
-            uint4 vy = make_uint4(0, 0, 0, 0), vx = make_uint4(0, 0, 0, 0);
-            if (m < m_end) {
-                if (yvalid) vy = *reinterpret_cast<const uint4*>(p.dY + (size_t)m * p.ldy + p.y_coff + yn);
-                if (xvalid) {
-                    const int b = m / OHW;
-                    const int r = m - b * OHW;
-                    const int oh = r / p.OW;
-                    const int ow = r - oh * p.OW;
-                    const int ih = oh * p.stride - p.pad + xkh, iw = ow * p.stride - p.pad + xkw;
-                    if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-                        vx = *reinterpret_cast<const uint4*>(p.X + (size_t)((b * p.H + ih) * p.W + iw) * p.ldx + p.x_coff + xc);
-                }
-            }
-            ry[i] = vy;
-            rx[i] = vx;
+            const bool mv = m < m_end;
+            const int b = m / OHW;
+            const int r = m - b * OHW;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            const int ih = oh * p.stride - p.pad + xkh, iw = ow * p.stride - p.pad + xkw;
+            const bool xv = mv && xvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const unsigned yo = ((unsigned)m * (unsigned)p.ldy + (unsigned)(p.y_coff + yn)) * 2u;
+            const unsigned xo = ((unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.ldx + (unsigned)(p.x_coff + xc)) * 2u;
+            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (mv && yvalid) ? yo : CRIS_OOB, 0, 0);
+            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xv ? xo : CRIS_OOB, 0, 0);
         }
     };
     auto store_step = [&]() {
@@ -531,15 +538,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 float f[8];
-                unpack8(ry[i], f);
+                unpack8(*reinterpret_cast<const uint4*>(&ry[i]), f);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) bsum[j] += f[j];
             }
         }
-        transpose8x8(ry, o);
+        transpose8x8(reinterpret_cast<const uint4*>(ry), o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(sy + wg_off(vec * 8 + j, mg)) = o[j];
-        transpose8x8(rx, o);
+        transpose8x8(reinterpret_cast<const uint4*>(rx), o);
 #pragma unroll
         for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(sx + wg_off(vec * 8 + j, mg)) = o[j];
     };
@@ -617,6 +624,8 @@ extern "C" int cris_conv_wgrad(const cris_wgrad_params* pp, void* stream) {
     CRIS_CHECK_ARG((p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && (p.N_ld & 7) == 0 && p.N_ld >= p.N, "dY ld/offset/N_ld");
     CRIS_CHECK_ARG(p.K == p.KH * p.KW * p.C && p.M == p.Bn * p.OH * p.OW, "geometry");
     CRIS_CHECK_ARG(p.ldw >= p.K, "ldw < K");
+    CRIS_CHECK_ARG((size_t)p.M * p.ldy * 2 < (1UL << 31) && (size_t)p.Bn * p.H * p.W * p.ldx * 2 < (1UL << 31),
+                   "operand extent must stay below 2 GiB (32-bit buffer offsets)");
     dim3 grid(cris_cdiv(p.K, WG_T), cris_cdiv(p.N, WG_T), p.splits);
     hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
