@@ -49,17 +49,35 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
     const float dscale = has_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
     const int Hh = p.outT ? p.T_E / 64 : 1;
     const int part_cnt = max(0, min(FM * MT, p.M - row0));
+    // residual reads and output writes go through raw buffer descriptors: an element outside the problem (row >= M,
+    // column >= N) is an out-of-range offset - reads return 0, writes are dropped - so the epilogue has no per-element
+    // branches and its residual loads are issued together instead of one wait per element
+    const bool has_res = p.resid != nullptr, has_out = p.out != nullptr;
+    const unsigned res_es = p.resid_f32 ? 4u : 2u, out_es = p.out_f32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.resid), 0, has_res ? (int)((size_t)p.M * p.ldr * res_es) : 0, CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, has_out ? (int)((size_t)p.M * p.ldc * out_es) : 0,
+                                                                        CRIS_BUF_FLAGS);
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int col = col0 + j * MT + fr;
         const bool cvalid = col < p.N;
-        const float bias = (p.bias && cvalid) ? p.bias[col] : 0.f;
+        const float bias = p.bias ? p.bias[cvalid ? col : 0] : 0.f;
         float vals[FM * NG][4];
 #pragma unroll
         for (int ig = 0; ig < FM * NG; ++ig) {
             const int i = ig / NG, g = ig % NG;
             const int rowb = row0 + i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4);
-            float v[4];
+            float v[4], rres[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = rowb + r;
+                    const unsigned off = (cvalid && m < p.M) ? ((unsigned)m * (unsigned)p.ldr + (unsigned)(p.r_coff + col)) * res_es : CRIS_OOB;
+                    if (p.resid_f32) rres[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
+                    else rres[r] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsR, off, 0, 0));
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = rowb + r;
@@ -68,18 +86,14 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 else if (p.act == 2) x = x / (1.0f + __expf(-1.702f * x));
                 if (has_drop) x = cris_keep(dkey, (uint32_t)m * (uint32_t)p.N + (uint32_t)col, dthr) ? x * dscale : 0.f;
                 const bool valid = cvalid && m < p.M;
-                if (valid && p.resid) {
-                    const size_t ro = (size_t)m * p.ldr + p.r_coff + col;
-                    x += p.resid_f32 ? reinterpret_cast<const float*>(p.resid)[ro]
-                                     : bf2f(reinterpret_cast<const bf16_t*>(p.resid)[ro]);
-                }
+                x += rres[r];
                 if (!valid) x = 0.f;
                 v[r] = x;
                 vals[ig][r] = x;
-                if (valid && p.out) {
-                    const size_t oo = (size_t)m * p.ldc + p.c_coff + col;
-                    if (p.out_f32) reinterpret_cast<float*>(p.out)[oo] = x;
-                    else reinterpret_cast<bf16_t*>(p.out)[oo] = f2bf(x);
+                if (has_out) {
+                    const unsigned off = valid ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(p.c_coff + col)) * out_es : CRIS_OOB;
+                    if (p.out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(x), rsO, off, 0, 0);
                 }
             }
             if (p.outT && cvalid && rowb < p.M) {
@@ -415,7 +429,8 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
                    "bad transposed-store geometry");
     CRIS_CHECK_ARG((uintptr_t)p.A % 16 == 0 && (uintptr_t)p.Wt % 16 == 0, "operands must be 16-byte aligned");
     CRIS_CHECK_ARG((long)p.M * p.N < (1L << 32) || p.drop_thresh == 0u, "dropout index overflow");
-    CRIS_CHECK_ARG((size_t)p.Bn * p.H * p.W * p.lda * 2 < (1UL << 31) && ((size_t)p.N + 256) * p.ldb * 2 < (1UL << 31),
+    CRIS_CHECK_ARG((size_t)p.Bn * p.H * p.W * p.lda * 2 < (1UL << 31) && ((size_t)p.N + 256) * p.ldb * 2 < (1UL << 31) &&
+                       (!p.out || (size_t)p.M * p.ldc * 4 < (1UL << 31)) && (!p.resid || (size_t)p.M * p.ldr * 4 < (1UL << 31)),
                    "operand extent must stay below 2 GiB (32-bit buffer offsets)");
     hipStream_t s = (hipStream_t)stream;
     // <= 72 KB per block: two blocks (8 waves) share a CU's 160 KB LDS and hide each other's barriers / epilogues
