@@ -73,6 +73,12 @@ void cris_set_error(const char* fmt, ...);
         }                                                                            \
     } while (0)
 
+#include <stdlib.h>
+// tuning knob read once from the environment (launch geometry only - never changes results)
+static inline int cris_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
 static inline int cris_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline int cris_grid_1d(long work_items, int per_block, int cap = 8192) {
     long g = (work_items + per_block - 1) / per_block;

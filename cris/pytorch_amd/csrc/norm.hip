@@ -411,9 +411,12 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     CRIS_CHECK_ARG(!p.relu || p.pool || p.z || (p.scale && p.shift), "relu mask source");
     CRIS_CHECK_ARG(!p.pool || (p.scale && p.shift && !p.y2 && !p.mul), "pool backward needs scale/shift, plain BN");
     const int M = p.Bn * p.H * p.W;
-    int blocks = 1024;
+    // every block ends with 2C (4C) global atomics onto the same addresses: few, fat blocks
+    static const int max_blocks = cris_env_int("CRIS_BN_RED_BLOCKS", 512);
+    static const int min_rows = cris_env_int("CRIS_BN_RED_ROWS", 32);
+    int blocks = max_blocks;
     int rpb = cris_cdiv(M, blocks);
-    if (rpb < 16) rpb = 16;
+    if (rpb < min_rows) rpb = min_rows;
     blocks = cris_cdiv(M, rpb);
     const size_t shm = (size_t)(p.y2 ? 4 : 2) * p.C * sizeof(float);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), shm, (hipStream_t)stream, p, rpb);
@@ -707,7 +710,8 @@ extern "C" int cris_ln_bwd(const cris_ln_bwd_params* pp, void* stream) {
     CRIS_CHECK_ARG(p.dy || p.dypos || p.dout_f32, "no incoming gradient");
     CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 64 * 8 * LN_MAXV && (p.ldx & 7) == 0, "C must be a multiple of 8, <= 2048");
     CRIS_CHECK_ARG(!p.dx_accum || p.dx_f32, "accumulate only into fp32");
-    const int grid = cris_grid_1d(p.rows, 4, 256);
+    static const int max_grid = cris_env_int("CRIS_LN_BWD_BLOCKS", 128);
+    const int grid = cris_grid_1d(p.rows, 4, max_grid);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return 0;
