@@ -81,8 +81,10 @@ def smoke():
     print("smoke:", {k: (round(v, 6) if isinstance(v, float) else v) for k, v in rep.items()})
     assert rep["mask_equal"], "nearest mask resize is an index op: must be bit exact"
     assert math.isfinite(rep["loss_hip"]) and math.isfinite(rep["loss_step2"]) and rep["params_finite"]
-    # bf16 path vs fp32 oracle: loss within 2e-2 absolute on an O(0.7) BCE, logits within 3x the bf16-storage noise
-    # floor of the oracle itself (+5e-2), gradients pointing the same way
-    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < 2e-2, rep
-    assert rep["pred_rel_vs_fp32"] < 3.0 * rep["emul_rel_vs_fp32"] + 5e-2, rep
-    assert rep["grad_cos_median"] > 0.98 and rep["grad_cos_min"] > 0.5, rep
+    # bf16 path vs fp32 oracle, bounded by 3x what the oracle itself shows when it is run with bf16 storage rounding at the
+    # same points (the noise floor of any bf16 implementation of this network) - the rule of tests/test_engine_gpu.py
+    k = 3.0
+    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < k * abs(rep["loss_emul"] - rep["loss_oracle"]) + 1e-2, rep
+    assert rep["pred_rel_vs_fp32"] < k * rep["emul_rel_vs_fp32"] + 1e-2, rep
+    assert 1.0 - rep["grad_cos_median"] < k * (1.0 - rep["emul_grad_cos_median"]) + 5e-3, rep
+    assert 1.0 - rep["grad_cos_min"] < k * (1.0 - rep["emul_grad_cos_min"]) + 5e-2, rep
