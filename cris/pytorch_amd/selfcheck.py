@@ -17,7 +17,7 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0"):
+def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", word_len=None):
     """Returns a dict of parity figures: HIP engine vs fp32 oracle (and vs the oracle run with bf16 storage rounding,
     the noise floor every bf16 implementation shares)."""
     from . import arch, synth
@@ -26,7 +26,7 @@ def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0"):
     from oracle.bf16_emulation import bf16_storage
 
     clip, head = arch.specs_by_name(spec)
-    head = dataclasses.replace(head, dropout=dropout)
+    head = dataclasses.replace(head, dropout=dropout, **({} if word_len is None else {"word_len": word_len}))
     sd = arch.synthetic_state_dict(clip, head, 0)
     img, word, mask = synth.make_batch(batch, size, head.word_len, 0, 0)
     dev = torch.device(device)

@@ -1,0 +1,104 @@
+"""Two ranks on ONE GPU (gloo carries the collectives; NCCL/RCCL needs one GPU per rank, the gpurun box has one): the
+data-parallel path for real - SyncBN statistics exchange in forward and backward, staged gradient all-reduce, 1/world in
+Adam - against the property the reference's DDP + SyncBN recipe guarantees (train.py:97-102): an N-rank run equals the
+1-rank run on the concatenated batch."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+STEPS = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard(rank, step):
+    from cris.pytorch_amd import synth
+    return synth.make_batch(4, 64, 9, rank, step)
+
+
+def _worker(rank, world, port, launch, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cris.pytorch_amd import arch
+        from cris.pytorch_amd.dist import TorchDistComm
+        from cris.pytorch_amd.trainer import NativeTrainer
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        clip, head = arch.specs_by_name("tiny")
+        sd = arch.synthetic_state_dict(clip, head, 0)
+        tr = NativeTrainer(clip, head, sd, dev, comm=TorchDistComm(dev), sync_bn=True, launch=launch)
+        losses = []
+        for step in range(STEPS):
+            img, word, mask = (t.to(dev) for t in _shard(rank, step))
+            loss, _ = tr.train_step(img, word, mask)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        probe = {k: tr.engine.P[k].double().sum().item() for k in ("backbone.visual.layer1.0.conv2.weight", "neck.f2_cat.1.weight",
+                                                                     "decoder.layers.0.ffn.0.weight", "proj.txt.weight")}
+        rm = tr.engine.Bf["backbone.visual.bn1.running_mean"].double().sum().item()
+        q.put((rank, losses, probe, rm, tr.launch))
+    finally:
+        dist.destroy_process_group()
+
+
+def _single():
+    from cris.pytorch_amd import arch
+    from cris.pytorch_amd.trainer import NativeTrainer
+    dev = torch.device("cuda:0")
+    clip, head = arch.specs_by_name("tiny")
+    sd = arch.synthetic_state_dict(clip, head, 0)
+    tr = NativeTrainer(clip, head, sd, dev, launch="eager")
+    losses = []
+    for step in range(STEPS):
+        parts = [_shard(r, step) for r in range(2)]
+        img, word, mask = (torch.cat([p[i] for p in parts]).to(dev) for i in range(3))
+        loss, _ = tr.train_step(img, word, mask)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    probe = {k: tr.engine.P[k].double().sum().item() for k in ("backbone.visual.layer1.0.conv2.weight", "neck.f2_cat.1.weight",
+                                                                 "decoder.layers.0.ffn.0.weight", "proj.txt.weight")}
+    rm = tr.engine.Bf["backbone.visual.bn1.running_mean"].double().sum().item()
+    return losses, probe, rm
+
+
+@pytest.mark.parametrize("launch", ["eager", "cmdlist"])
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(launch):
+    # dropout 0 for this comparison (mask indices are rank-local); everything else as in training.  The switch is an
+    # environment variable so that the spawned ranks see it too.
+    os.environ["CRIS_TEST_TINY_DROPOUT0"] = "1"
+    ref_losses, ref_probe, ref_rm = _single()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, launch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    os.environ.pop("CRIS_TEST_TINY_DROPOUT0", None)
+    (_, l0, p0, rm0, m0), (_, l1, p1, rm1, m1) = res
+    assert m0 == launch and m1 == launch
+    print("rank losses", l0, l1, "single", ref_losses)
+    for step in range(STEPS):
+        both = 0.5 * (l0[step] + l1[step])                       # mean BCE over 8 samples = mean of the two 4-sample means
+        assert abs(both - ref_losses[step]) < 5e-3, (step, both, ref_losses[step])
+    for k in ref_probe:                                          # parameters stay in lock-step across ranks and track the 1-rank run
+        assert abs(p0[k] - p1[k]) <= 1e-6 * max(1.0, abs(p0[k])), (k, p0[k], p1[k])
+        assert abs(p0[k] - ref_probe[k]) <= 2e-3 * max(1.0, abs(ref_probe[k])), (k, p0[k], ref_probe[k])
+    assert abs(rm0 - rm1) < 1e-6 and abs(rm0 - ref_rm) < 1e-3 * max(1.0, abs(ref_rm))     # SyncBN: global running stats

@@ -64,6 +64,21 @@ def test_r50_small_step_matches_oracle():
     assert abs(rep["loss_oracle"] - float(g["loss"])) < 2e-4
 
 
+def test_r101_step_matches_oracle():
+    """BASELINE.json configs[3]: the deeper visual encoder (layer3 x23, embed_dim 512, fpn_in [512,1024,512]), 160x160, batch 2."""
+    rep = selfcheck.run("r101", batch=2, size=160, dropout=0.0, seed=7)
+    print(rep)
+    _assert_parity(rep)
+
+
+def test_r50_480_long_text_step_matches_oracle():
+    """BASELINE.json configs[4] shape family: 480-pixel-style geometry (odd feature maps: 240 -> 60/30/15/8... here 224 with
+    L = 22 tokens: 56/28/14/7 maps) and G-Ref-length expressions (word_len 22)."""
+    rep = selfcheck.run("r50", batch=2, size=224, dropout=0.1, seed=9, word_len=22)
+    print(rep)
+    _assert_parity(rep)
+
+
 def test_stage_isolated_parity():
     """Every stage (bottlenecks, attnpool, text encoder, FPN, decoder with/without dropout, projector + loss) fed with the
     oracle's bf16-rounded inputs and a random upstream gradient: errors cannot compound across stages here, so the bounds
