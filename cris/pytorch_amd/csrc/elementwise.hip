@@ -573,13 +573,14 @@ __global__ __launch_bounds__(256) void dynconv_fwd_kernel(const bf16_t* __restri
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
+                    // branch-free taps: clamped address + 0/1 weight, so the 9 loads of a pixel are issued together
                     const int ih = oh + kh - 1, iw = ow + kw - 1;
-                    if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-                        float v[8];
-                        ld8bf(x + (((size_t)b * H + ih) * W + iw) * C + cl * 8, v);
+                    const float ok = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? 1.f : 0.f;
+                    const int ihc = min(max(ih, 0), H - 1), iwc = min(max(iw, 0), W - 1);
+                    float v[8];
+                    ld8bf(x + (((size_t)b * H + ihc) * W + iwc) * C + cl * 8, v);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) acc += v[j] * w[kh * 3 + kw][j];
-                    }
+                    for (int j = 0; j < 8; ++j) acc += ok * v[j] * w[kh * 3 + kw][j];
                 }
         }
         for (int o = LP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
@@ -632,19 +633,18 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const bf16_t* __restri
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
             for (int kw = 0; kw < 3; ++kw) {
+                // branch-free taps (clamped address, 0/1 weight): all loads of a pixel in flight together
                 const int oh = ph - kh + 1, ow = pw - kw + 1;
-                if ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) {
-                    const float g = dp[oh * W + ow];
+                const float okg = ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) ? 1.f : 0.f;
+                const float g = okg * dp[min(max(oh, 0), H - 1) * W + min(max(ow, 0), W - 1)];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) gx[j] += g * w[kh * 3 + kw][j];
-                }
+                for (int j = 0; j < 8; ++j) gx[j] += g * w[kh * 3 + kw][j];
                 const int ih = ph + kh - 1, iw = pw + kw - 1;
-                if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-                    float v[8];
-                    ld8bf(x + (((size_t)b * H + ih) * W + iw) * C + cl * 8, v);
+                const float okx = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? g0 : 0.f;
+                float v[8];
+                ld8bf(x + (((size_t)b * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)) * C + cl * 8, v);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) dw[kh * 3 + kw][j] += g0 * v[j];
-                }
+                for (int j = 0; j < 8; ++j) dw[kh * 3 + kw][j] += okx * v[j];
             }
         st8bf(dx + ((size_t)b * HW + pix) * C + cl * 8, gx);
     }

@@ -181,8 +181,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
 
-    // XCD-aware tile order: blocks b, b+8, b+16.. run on the same XCD (round-robin dispatch); give each XCD a
-    // contiguous run of tiles, n fastest, so its L2 keeps one A panel and sweeps the weights.
+    // XCD-aware tile order: blocks b, b+8, b+16.. run on the same XCD (round-robin dispatch); each XCD gets a contiguous
+    // run of tiles so that its private 4 MB L2 keeps the panel the run shares.  Which index runs fastest decides what is
+    // re-streamed: n fastest keeps an A (activation) panel and sweeps the weights - right while the whole weight matrix
+    // fits the L2; once it does not (N*K*2 B > 2 MB: the 3x3 / wide 1x1 layers of the neck, decoder and layers 3-4), m
+    // fastest keeps ONE 128-column weight panel resident and streams the (much smaller per tile) activation rows once.
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
@@ -192,8 +195,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid / tiles_n;
-    const int tile_n = bid - tile_m * tiles_n;
+    int tile_m, tile_n;
+    if ((long)p.N * p.K > (1L << 20)) {
+        tile_n = bid / tiles_m;
+        tile_m = bid - tile_n * tiles_m;
+    } else {
+        tile_m = bid / tiles_n;
+        tile_n = bid - tile_m * tiles_n;
+    }
     const int m0 = tile_m * BM;
     const int n0 = tile_n * BN;
 
@@ -498,11 +507,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
-    const int k0 = blockIdx.x * WG_T;
-    const int n0 = blockIdx.y * WG_T;
+    // XCD-aware order over the flattened (k-tile fastest, n-tile, split) grid: the blocks one XCD runs are consecutive
+    // k-tiles of the same dY tile and pixel range, which then stays in that XCD's L2
+    int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    {
+        const int nblk = gridDim.x * gridDim.y * gridDim.z;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int bx = bid % gridDim.x, by = (bid / gridDim.x) % gridDim.y, bz = bid / (gridDim.x * gridDim.y);
+    const int k0 = bx * WG_T;
+    const int n0 = by * WG_T;
     int rows_per = (p.M + p.splits - 1) / p.splits;
     rows_per = (rows_per + WG_T - 1) / WG_T * WG_T;
-    const int m_begin = blockIdx.z * rows_per;
+    const int m_begin = bz * rows_per;
     const int m_end = min(p.M, m_begin + rows_per);
     if (m_begin >= m_end) return;
 
@@ -519,7 +538,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
     const int xkh = xtap / p.KW, xkw = xtap - xkh * p.KW;
 
     // bias gradient (column sums of dY) rides along in the blocks of the first k-tile
-    const bool do_bias = p.dbias != nullptr && blockIdx.x == 0;
+    const bool do_bias = p.dbias != nullptr && bx == 0;
     float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // Loads are raw buffer loads: an invalid element (row beyond this split, channel tail, spatial padding) is an
     // out-of-range byte offset that the hardware returns as zeros - a branch-free select, so the 16 loads of a step are

@@ -30,6 +30,7 @@ BN_EPS, BN_MOM, LN_EPS = 1e-5, 0.1, 1e-5
 class Act:
     """A [M, ld] activation buffer (or a channel slice of one) plus its gradient buffer."""
     __slots__ = ("t", "Bn", "H", "W", "C", "ld", "coff", "root", "_g", "aux")
+    _engine = None        # the Engine whose step is being scheduled (zero-filled gradient buffers come from its slab)
 
     def __init__(self, t, Bn, H, W, C, ld=None, coff=0, root=None):
         self.t, self.Bn, self.H, self.W, self.C = t, Bn, H, W, C
@@ -56,7 +57,11 @@ class Act:
         if r._g is None:
             # a channel slice writes only its columns: the rest must read as zero for later accumulation
             partial = self.C < r.t.shape[-1]
-            r._g = ops.zero_(torch.empty_like(r.t)) if partial else torch.empty_like(r.t)
+            if partial:
+                eng = Act._engine
+                r._g = eng.zeros(*r.t.shape, dtype=r.t.dtype) if eng is not None else ops.zero_(torch.empty_like(r.t))
+            else:
+                r._g = torch.empty_like(r.t)
             return r._g, partial
         return r._g, True
 
@@ -88,6 +93,7 @@ class Engine:
         self.wstream = (torch.cuda.Stream(device=device)
                         if torch.device(device).type == "cuda" and os.environ.get("CRIS_WGRAD_STREAM", "0") == "1" else None)
         self._keepalive = []
+        self._zslab, self._zcur, self._zneed, self._zneed_last = None, 0, 0, 0
         self._tables = {}
         self._build_grad_arena()
         self._build_packs()
@@ -206,7 +212,26 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     # small helpers
     # ------------------------------------------------------------------------------------------
+    # Zero-filled temporaries (padded outputs, partial-slice gradient buffers, small accumulators: ~70 per step) are carved
+    # from one slab that is cleared by a single launch at the start of the step; its size is what the previous step used.
+    def _zero_slab_begin(self):
+        need = self._zneed_last
+        if need and (self._zslab is None or self._zslab.numel() < need):
+            self._zslab = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        if self._zslab is not None:
+            ops.zero_(self._zslab)
+        self._zcur = self._zneed = 0
+
     def zeros(self, *shape, dtype=F32):
+        n = dtype.itemsize
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 255) // 256 * 256
+        self._zneed += n_al
+        if n > 0 and self._zslab is not None and self._zcur + n_al <= self._zslab.numel():
+            t = self._zslab[self._zcur:self._zcur + n].view(dtype).view(*shape)
+            self._zcur += n_al
+            return t
         return ops.zero_(torch.empty(*shape, dtype=dtype, device=self.dev))
 
     def empty(self, *shape, dtype=BF16):
@@ -775,6 +800,8 @@ class Engine:
         self.tape = []
         self._dgrad_outT = None
         self._stage_marks = {}
+        Act._engine = self
+        self._zero_slab_begin()
         if training:
             ops.zero_(self.grad_arena)
         self.repack_weights()
@@ -809,6 +836,7 @@ class Engine:
             taps.update(layer1=feats[0], layer2=feats[1], layer3=feats[2], layer4=feats[3], attnpool=v5, word=txt, state=state,
                         fq_neck=fq, fq_dec=fqd, pred=pred)
         if not training:
+            Act._engine = None
             return pred
         B, _, OH, OW = pred.shape
         msk = self.empty(B, 1, OH, OW, dtype=F32)
@@ -865,6 +893,8 @@ class Engine:
             ops.torch_op(lambda: main.wait_stream(self.side))
         join_wgrads()
         self._keepalive = []
+        self._zneed_last = max(self._zneed_last, self._zneed)
+        Act._engine = None
         if on_stage_done is not None:
             on_stage_done(1)
             on_stage_done(0)

@@ -65,6 +65,7 @@ class Ctx:
     def begin(self, seed=5):
         e = self.eng
         e.training, e.seed, e.tape, e._dgrad_outT = True, seed, [], None
+        Act._engine = None
         e.grad_arena.zero_()
         e.repack_weights()
         self.leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in self.sd.items()}

@@ -35,6 +35,7 @@ def main(spec="tiny", B=4, S=64):
     with torch.no_grad():
         O.cris_forward(sd, clip, head, img, word, mask, training=True, taps=ot)
     eng.training, eng.seed, eng.tape, eng._dgrad_outT = True, 0, [], None
+    Act._engine = None
     eng.repack_weights()
     # determinism of the full forward
     t1, t2 = {}, {}
