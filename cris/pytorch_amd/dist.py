@@ -4,10 +4,11 @@ over xGMI), mirroring the reference's DDP + SyncBatchNorm semantics (train.py:80
   * SyncBN: per BatchNorm layer the (sum, M2) statistics are all-reduced in forward and (sum g, sum g*xhat) in
     backward (engine.Engine uses `allreduce_sum` for both) - N-GPU training equals 1-GPU training on the
     concatenated batch;
-  * gradients: the flat fp32 gradient arena is laid out in forward-compute order, so backward completes it from
-    its end; each finished stage (proj, decoder, neck, text, visual) is all-reduced as ONE large message on a side
-    HIP stream while the earlier stages' backward still runs (xGMI is point-to-point and per-link bound: few big
-    messages, not DDP's 25 MB buckets); Adam applies the 1/world averaging through its grad_scale.
+  * gradients: the flat fp32 gradient arena is laid out stage by stage (stem+layer1, layer2, layer3, layer4+attnpool,
+    text, neck, decoder, projector); as backward finishes a stage its range is all-reduced as ONE large message on a
+    side HIP stream while the remaining backward still runs - projector, decoder, neck first, then the text encoder
+    (from its own stream) and the visual layer groups 4..1 (xGMI is point-to-point and per-link bound: eight big
+    messages of 24-254 MB, not DDP's 25 MB buckets); Adam applies the 1/world averaging through its grad_scale.
 The path shards by sample only; there is no other data-path collective.
 """
 import torch

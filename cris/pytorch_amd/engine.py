@@ -138,11 +138,20 @@ class Engine:
         # forward-compute order (visual, text, neck, decoder, proj) so that backward completes the arena from its
         # end towards its start and contiguous suffixes can be all-reduced while earlier layers still run
         def stage(name):
+            # arena stages = units of the gradient exchange: 0 stem+layer1, 1 layer2, 2 layer3, 3 layer4+attnpool, 4 text,
+            # 5 neck, 6 decoder, 7 projector.  Backward finishes them 7, 6, 5, then 4 (side stream) and 3, 2, 1, 0.
             if name.startswith("backbone.visual."):
+                rest = name[len("backbone.visual."):]
+                if rest.startswith("layer2"):
+                    return 1
+                if rest.startswith("layer3"):
+                    return 2
+                if rest.startswith(("layer4", "attnpool")):
+                    return 3
                 return 0
             if name.startswith("backbone."):
-                return 1
-            return {"neck": 2, "decoder": 3, "proj": 4}[name.split(".")[0]]
+                return 4
+            return {"neck": 5, "decoder": 6, "proj": 7}[name.split(".")[0]]
         names = sorted(self.P.keys(), key=lambda k: stage(k))          # stable: keeps module order inside a stage
         order, seen = [], set()
         for name in names:
@@ -174,7 +183,7 @@ class Engine:
         self.grad_order = order
         self.grad_offsets = offs
         self.bn_pairs = pairs
-        # arena [start, end) of each stage (0 visual, 1 text, 2 neck, 3 decoder, 4 proj)
+        # arena [start, end) of each stage
         self.stage_ranges = {}
         for name in order:
             st = stage(name)
@@ -519,6 +528,8 @@ class Engine:
         feats = []
         inpl = w
         for li, nblk in enumerate(self.clip.vision_layers):
+            if li > 0:
+                self._vis_stage_start[li] = len(self.tape)      # arena stage li = this layer group (3 also takes attnpool)
             planes = w * (1, 2, 4, 8)[li]
             for bi in range(nblk):
                 stride = 2 if (li > 0 and bi == 0) else 1
@@ -807,29 +818,30 @@ class Engine:
         self.repack_weights()
         word = word.contiguous()
         main = torch.cuda.current_stream()
-        starts = {1: 0}
         self._text_tape_start = 0
+        self._vis_stage_start = {}
         if self.side is not None:
             ops.torch_op(lambda: self.side.wait_stream(main))
             with torch.cuda.stream(self.side):
                 txt, state = self._encode_text(word)
         else:
             txt, state = self._encode_text(word)
-        starts[0] = len(self.tape)
+        v0 = len(self.tape)
+        self._vis_stage_start[0] = v0
         v3, v4, v5, feats = self._encode_image(img.contiguous().float())
         if self.side is not None:
             ops.torch_op(lambda: main.wait_stream(self.side))
-        starts[2] = len(self.tape)
-        self._ranges = dict(text=(starts[1], starts[0]), visual=(starts[0], starts[2]))
+        v1 = len(self.tape)
+        self._ranges = dict(text=(0, v0), visual=(v0, v1))
+        head_marks = {5: v1}
         fq = self._fpn(v3, v4, v5, state)
-        self._dec_tape_start = starts[3] = len(self.tape)
+        self._dec_tape_start = head_marks[6] = len(self.tape)
         fqd = self._decoder(fq, Act(txt.t, txt.Bn, txt.H, 1, txt.C, root=txt.root), word)
-        starts[4] = len(self.tape)
+        head_marks[7] = len(self.tape)
         pred, x, wb = self._projector(fqd, state)
-        # a stage's parameter gradients are complete once the closure at its start index has run, EXCEPT that the text
-        # encoder's output feeds the decoder/neck/projector (its closures all sit in [starts[1], starts[2]) anyway)
+        # a stage's parameter gradients are complete once the closure at its start index has run in backward
         self._stage_marks = {}
-        for st, idx in starts.items():
+        for st, idx in list(head_marks.items()) + list(self._vis_stage_start.items()):
             self._stage_marks.setdefault(idx, []).append(st)
         if taps is not None:
             taps.update(self._neck_taps)
@@ -859,8 +871,9 @@ class Engine:
 
     def backward(self, gscale: Optional[torch.Tensor] = None, on_stage_done: Optional[Callable[[int], None]] = None):
         """Run the tape in reverse.  `gscale`: optional 1-element fp32 device tensor multiplying dloss (GradScaler).
-        `on_stage_done(stage)` fires when every gradient of arena stage 4 (proj) .. 0 (visual) has been issued on the
-        stream - the hook the data-parallel gradient exchange overlaps with the rest of backward."""
+        `on_stage_done(stage)` fires when every gradient of an arena stage (7 projector .. 0 stem+layer1, see
+        _build_grad_arena) has been issued on the current stream - the hook the data-parallel gradient exchange uses to
+        overlap with the rest of backward."""
         self._gscale = gscale
         marks = dict(self._stage_marks)                 # tape index at which a stage's closures START
         (t0, t1), (v0, v1) = self._ranges["text"], self._ranges["visual"]
@@ -870,13 +883,15 @@ class Engine:
                 cur = torch.cuda.current_stream()
                 ops.torch_op(lambda: cur.wait_stream(self.wstream))
 
+        def fire(i):
+            if on_stage_done is not None and i in marks:
+                join_wgrads()
+                for st in marks[i]:
+                    on_stage_done(st)
+
         for i in range(len(self.tape) - 1, head_start - 1, -1):
             self.tape[i]()
-            if on_stage_done is not None and i in marks:
-                for st in marks[i]:
-                    if st >= 2:
-                        join_wgrads()
-                        on_stage_done(st)
+            fire(i)
         # the two encoders' backward passes are independent: text on the side stream, visual on the launch stream
         main = torch.cuda.current_stream()
         if self.side is not None:
@@ -884,19 +899,21 @@ class Engine:
             with torch.cuda.stream(self.side):
                 for i in range(t1 - 1, t0 - 1, -1):
                     self.tape[i]()
+                if on_stage_done is not None:
+                    on_stage_done(4)                     # issued from the side stream: the exchange waits for it only
         else:
             for i in range(t1 - 1, t0 - 1, -1):
                 self.tape[i]()
+            if on_stage_done is not None:
+                on_stage_done(4)
         for i in range(v1 - 1, v0 - 1, -1):
             self.tape[i]()
+            fire(i)                                      # visual stages 3, 2, 1, 0 as their layer groups finish
         if self.side is not None:
             ops.torch_op(lambda: main.wait_stream(self.side))
         join_wgrads()
         self._keepalive = []
         self._zneed_last = max(self._zneed_last, self._zneed)
         Act._engine = None
-        if on_stage_done is not None:
-            on_stage_done(1)
-            on_stage_done(0)
         self.tape = []
         return self.G
