@@ -401,14 +401,21 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
 }
 
 // tile selection (host).  Returns the rows per BatchNorm-statistics partial of the chosen variant.
-enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x128, V_128x128 };
+enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128 };
 static int pick_variant(const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
     if (lin && p.M <= 16) return V_SKINNY1;
     if (lin && p.M <= SKINNY_MAX_M) return V_SKINNY9;
     if (p.N <= 64) return V_128x64;
-    // fewer than ~1.75 tiles per CU at 128x128: halve the tile (2 blocks of 72 KB LDS fit a CU)
-    if ((long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128) < 448) return V_64x128;
+    // too few 128x128 tiles to occupy the chip: halve the tile (2 blocks of 72 KB LDS fit a CU)
+    static const int t128_min = cris_env_int("CRIS_GEMM_T128_MIN", 448);
+    if ((long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128) < t128_min) {
+        // latency-bound mid-size problems: more, smaller blocks (3 per CU at 48 KB LDS) hide each other's pipeline fill,
+        // barriers and epilogues
+        static const int t64_max = cris_env_int("CRIS_GEMM_T64_MAX", 1024);
+        if ((long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128) < t64_max) return V_64x64;
+        return V_64x128;
+    }
     return V_128x128;
 }
 static int variant_stat_rows(int v) {
@@ -444,9 +451,11 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     // <= 72 KB per block: two blocks (8 waves) share a CU's 160 KB LDS and hide each other's barriers / epilogues
     constexpr int LDS_128x64 = 3 * (128 + 64) * 128, LDS_64x128 = 3 * (64 + 128) * 128, LDS_128x128 = 2 * (128 + 128) * 128;
+    constexpr int LDS_64x64 = 3 * (64 + 64) * 128;
     void (*const k_128x64)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 64, 4, 1, 3>;
     void (*const k_64x128)(const cris_conv_gemm_params) = conv_gemm_kernel<64, 128, 2, 2, 3>;
     void (*const k_128x128)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 128, 2, 2, 2>;
+    void (*const k_64x64)(const cris_conv_gemm_params) = conv_gemm_kernel<64, 64, 2, 2, 3>;
     static const int lds_ready = set_lds((const void*)k_128x64, LDS_128x64) | set_lds((const void*)k_64x128, LDS_64x128) |
                                  set_lds((const void*)k_128x128, LDS_128x128);
     if (lds_ready != 0) {
@@ -463,6 +472,9 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
         case V_128x64:
             hipLaunchKernelGGL(k_128x64, dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256),
                                LDS_128x64, s, p);
+            break;
+        case V_64x64:
+            hipLaunchKernelGGL(k_64x64, dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
             break;
         case V_64x128:
             hipLaunchKernelGGL(k_64x128, dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256),

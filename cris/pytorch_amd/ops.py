@@ -6,6 +6,7 @@ current HIP stream.  Every function launches on `torch.cuda.current_stream()`.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -160,12 +161,15 @@ class KernelTimer:
 KERNEL_TIMER = None
 
 
+_WGRAD_BLOCKS = int(os.environ.get("CRIS_WGRAD_BLOCKS", "512"))      # launch-geometry knob (never changes results)
+
+
 def wgrad_splits(M: int, N: int, K: int) -> int:
     """split the pixel reduction only as far as needed to put ~2 blocks on each of the 256 CUs; every split costs a
     128x128 tile of fp32 atomics, so long reductions per block win"""
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     steps = (M + 127) // 128
-    want = max(1, (512 + tiles // 2) // tiles)
+    want = max(1, (_WGRAD_BLOCKS + tiles // 2) // tiles)
     return max(1, min(want, (steps + 3) // 4, 512))
 
 
