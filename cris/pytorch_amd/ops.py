@@ -80,7 +80,7 @@ NO_DROP = Drop(0.0, 0, 0)
 
 def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None, act=0, resid=None, ldr=None, r_coff=0,
               out=None, ldc=None, c_coff=0, outT=None, T_L=0, T_Lpad=0, T_E=0, T_sec_stride=0, stats=False,
-              drop: Drop = NO_DROP):
+              drop: Drop = NO_DROP, bnr=None):
     """out[M,N] = epi(A_im2col @ Wt^T).  A bf16 NHWC buffer (row stride lda), Wt bf16 [N][ldb].
     stats=True: also returns the BatchNorm statistics partials (Stats) of the output columns."""
     p = hip.ConvGemmParams()
@@ -107,6 +107,10 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
         p.T_L, p.T_Lpad, p.T_E, p.T_sec_stride = T_L, T_Lpad, T_E, T_sec_stride
     p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
     p.drop_seed_dev = ptr(drop.dev)
+    if bnr is not None:        # (y, ldy, y_coff, scale, shift, mean, invstd, sums): fused BatchNorm-backward reduction
+        y, p.bnr_ldy, p.bnr_coff = bnr[0], bnr[1], bnr[2]
+        p.bnr_y, p.bnr_scale, p.bnr_shift, p.bnr_mean, p.bnr_invstd, p.bnr_sums = (ptr(y), ptr(bnr[3]), ptr(bnr[4]), ptr(bnr[5]),
+                                                                                   ptr(bnr[6]), ptr(bnr[7]))
     st = None
     if stats:
         rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))          # depends on the tile variant the library picks
@@ -315,8 +319,9 @@ def bn_apply(y, scale, shift, z, Bn, H, W, C_, *, ldy=None, y_coff=0, ldz=None, 
 def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, lddz=None, dz_coff=0, ldy=None, y_coff=0,
            lddy=None, dy_coff=0, relu=True, pool=False, z=None, ldz=None, z_coff=0, y2=None, ldy2=None, y2_coff=0, mean2=None,
            invstd2=None, scale2=None, dy2=None, lddy2=None, dy2_coff=0, mul=None, dmul=None, dident=None, lddi=None,
-           di_coff=0, dident_accum=False, between=None):
-    """reduce + apply.  `between(sums)` (optional) runs between the two launches (SyncBN all-reduce)."""
+           di_coff=0, dident_accum=False, between=None, skip_reduce=False):
+    """reduce + apply.  `between(sums)` (optional) runs between the two launches (SyncBN all-reduce).  skip_reduce: the
+    sums were already accumulated by the consumer conv's input-gradient GEMM (conv_gemm(bnr=...))."""
     p = hip.BnBwdParams()
     p.dz, p.lddz, p.dz_coff = ptr(dz), lddz if lddz is not None else dz.shape[-1], dz_coff
     if z is not None:
@@ -337,7 +342,8 @@ def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, 
     p.relu, p.pool = int(relu), int(pool)
     p.count = float(count)
     s = _stream()
-    hip.call("cris_bn_bwd_reduce", C.byref(p), s)
+    if not skip_reduce:
+        hip.call("cris_bn_bwd_reduce", C.byref(p), s)
     if between is not None:
         between(sums)
     hip.call("cris_bn_bwd_apply", C.byref(p), s)
