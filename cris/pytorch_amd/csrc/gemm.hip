@@ -142,9 +142,9 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
             }
             bs0 += __shfl_xor(bs0, 32, 64);
             bs1 += __shfl_xor(bs1, 32, 64);
-            if (fg == 0 && cvalid) {
-                atomicAdd(p.bnr_sums + col, bs0);
-                atomicAdd(p.bnr_sums + p.N + col, bs1);
+            if (fg == 0 && cvalid && part_cnt > 0) {          // per wave-tile partials, summed by cris_sum_partials
+                p.bnr_sums[(size_t)part * 2 * p.N + col] = bs0;
+                p.bnr_sums[(size_t)part * 2 * p.N + p.N + col] = bs1;
             }
         }
         if (p.colsum) {

@@ -96,6 +96,28 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, con
     }
 }
 
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int nparts, int ncol, float* __restrict__ out) {
+    __shared__ float sh[16][17];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float a = 0.f;
+    if (c < ncol)
+        for (int i = pl; i < nparts; i += 16) a += part[(size_t)i * ncol + c];
+    sh[pl][cl] = a;
+    __syncthreads();
+    if (pl == 0 && c < ncol) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) a += sh[j][cl];
+        out[c] += a;
+    }
+}
+extern "C" int cris_sum_partials(const float* part, int nparts, int ncol, float* out, void* stream) {
+    CRIS_CHECK_ARG(part && out && nparts > 0 && ncol > 0, "bad args");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, part, nparts, ncol, out);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
 // rows the caller must allocate for a partials buffer of `nparts` parts (room for the level-1 merge output)
 extern "C" int cris_bn_partials_rows(int nparts) { return nparts > BN_MERGE_MIN ? nparts + BN_MERGE_SLICES : nparts; }
 

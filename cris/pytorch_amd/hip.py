@@ -158,6 +158,7 @@ _SIGS = {
     "cris_colsum_bf16": (I, [P, I, I, I, I, P, P]),
     "cris_conv_gemm_stat_rows": (I, [P]),
     "cris_bn_partials_rows": (I, [I]),
+    "cris_sum_partials": (I, [P, I, I, P, P]),
     "cris_bn_finalize": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P, P]),
     "cris_bn_recentre": (I, [P, P, P, F, F, I, P]),
     "cris_colstats_bf16": (I, [P, I, I, I, I, I, P, P, P]),

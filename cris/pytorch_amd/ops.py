@@ -107,10 +107,13 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
         p.T_L, p.T_Lpad, p.T_E, p.T_sec_stride = T_L, T_Lpad, T_E, T_sec_stride
     p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
     p.drop_seed_dev = ptr(drop.dev)
+    bnr_part = None
     if bnr is not None:        # (y, ldy, y_coff, scale, shift, mean, invstd, sums): fused BatchNorm-backward reduction
         y, p.bnr_ldy, p.bnr_coff = bnr[0], bnr[1], bnr[2]
-        p.bnr_y, p.bnr_scale, p.bnr_shift, p.bnr_mean, p.bnr_invstd, p.bnr_sums = (ptr(y), ptr(bnr[3]), ptr(bnr[4]), ptr(bnr[5]),
-                                                                                   ptr(bnr[6]), ptr(bnr[7]))
+        p.bnr_y, p.bnr_scale, p.bnr_shift, p.bnr_mean, p.bnr_invstd = ptr(y), ptr(bnr[3]), ptr(bnr[4]), ptr(bnr[5]), ptr(bnr[6])
+        rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))
+        bnr_part = torch.empty((g.M + rows - 1) // rows, 2 * N, dtype=torch.float32, device=A.device)
+        p.bnr_sums = ptr(bnr_part)
     st = None
     if stats:
         rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))          # depends on the tile variant the library picks
@@ -121,8 +124,12 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
         KERNEL_TIMER.launch("skinny_gemm" if rows in (16, 144) else "conv_gemm", 2.0 * g.M * N * g.K,
                             2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p),
                             tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
+        if bnr_part is not None:
+            hip.call("cris_sum_partials", ptr(bnr_part), bnr_part.shape[0], 2 * N, ptr(bnr[7]), _stream())
         return st
     hip.call("cris_conv_gemm", C.byref(p), _stream())
+    if bnr_part is not None:      # per-row-block partials -> the BatchNorm's [sum g | sum g*xhat] block (+=)
+        hip.call("cris_sum_partials", ptr(bnr_part), bnr_part.shape[0], 2 * N, ptr(bnr[7]), _stream())
     return st
 
 

@@ -63,9 +63,10 @@ typedef struct {
     uint32_t drop_seed, drop_stream;
     const uint32_t* drop_seed_dev; /* optional device word added to drop_seed (per-step seed of a replayed HIP graph) */
     /* optional fused BatchNorm-backward reduction: when this GEMM is the input-gradient of the conv that consumes
-     * z = relu(bn(y)), its output IS dz; the epilogue then also accumulates bnr_sums[c] += sum_m g and
-     * bnr_sums[N + c] += sum_m g * xhat with g = dz * [y*scale+shift > 0], xhat = (y - mean) * invstd
-     * (what cris_bn_bwd_reduce computes in a separate pass over dz and y).  y: [M][bnr_ldy] (+bnr_coff). */
+     * z = relu(bn(y)), its output IS dz; the epilogue then also writes, per row-block of cris_conv_gemm_stat_rows(p)
+     * rows (the same blocks as colsum), bnr_sums[part][c] = sum_m g and bnr_sums[part][N + c] = sum_m g * xhat with
+     * g = dz * [y*scale+shift > 0], xhat = (y - mean) * invstd - what cris_bn_bwd_reduce computes in a separate pass
+     * over dz and y.  cris_sum_partials adds the blocks into the [2N] sums.  y: [M][bnr_ldy] (+bnr_coff). */
     const cris_bf16* bnr_y;
     const float* bnr_scale; const float* bnr_shift; const float* bnr_mean; const float* bnr_invstd;
     float* bnr_sums;
@@ -124,6 +125,8 @@ int cris_colsum_bf16(const cris_bf16* x, int ldx, int coff, int M, int N, float*
  * floats each (the first-level result is written behind the nparts partial rows).
  * ---------------------------------------------------------------------------------------------- */
 int cris_bn_partials_rows(int nparts);
+/* out[c] += sum_p part[p][c]  (p < nparts, c < ncol): deterministic column sums of a partials table */
+int cris_sum_partials(const float* part, int nparts, int ncol, float* out, void* stream);
 int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local, float count,
                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                      float eps, int C, float* scale, float* shift, float* mean, float* invstd, float* merged,
