@@ -93,6 +93,10 @@ class Engine:
         self.wstream = (torch.cuda.Stream(device=device)
                         if torch.device(device).type == "cuda" and os.environ.get("CRIS_WGRAD_STREAM", "0") == "1" else None)
         self._keepalive = []
+        # Folding a BatchNorm's backward reduction into its consumer conv's input-gradient GEMM epilogue is implemented and
+        # parity-tested, but MEASURED SLOWER (21.0 -> 22.0 ms/step at R50/416/B=8: the per-element y reads and extra
+        # arithmetic lengthen every block's epilogue by more than the separate reduction pass costs): off by default.
+        self.fuse_bn_bwd = os.environ.get("CRIS_FUSE_BN_BWD", "0") == "1"
         self._zslab, self._zcur, self._zneed, self._zneed_last = None, 0, 0, 0
         self._tables = {}
         self._build_grad_arena()
@@ -327,7 +331,7 @@ class Engine:
             dT = self._dgrad_outT
             if dT is not None:
                 tkw = dict(outT=dT["buf"], T_L=dT["L"], T_Lpad=dT["Lpad"], T_E=dT["E"], T_sec_stride=dT["sec_stride"])
-            src = x.root.aux.get("bnsrc") if (fuse_bn_bwd and not acc and x.coff == 0) else None
+            src = x.root.aux.get("bnsrc") if (fuse_bn_bwd and self.fuse_bn_bwd and not acc and x.coff == 0) else None
             if src is not None:
                 Cb = src["C"]
                 if self.sync_bn:
