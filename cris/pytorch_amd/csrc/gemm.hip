@@ -35,7 +35,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; 
 // Epilogue of one wave tile (FM x FN fragments of 16x16, C/D layout col = lane&15, row = (lane>>4)*4 + r) whose first
 // row / column are row0 / col0: bias, activation, dropout, residual, bf16|fp32 store, head-split transposed copy and the
 // BatchNorm statistics partial `part` (sum, M2 about the part mean over the FM*16 rows of this wave tile).
-template <int MT, int FM, int FN, typename ACC>
+// LEAN: compile-time promise of the plain conv / dgrad case (bf16 output, optional bf16 residual, optional statistics;
+// no bias, activation, dropout, transposed copy, fp32 I/O or fused BN-backward sums) - the epilogue every block of the ~190
+// convolution GEMMs per step runs; the general form costs thousands of instructions per wave.
+template <bool LEAN, int MT, int FM, int FN, typename ACC>
 __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, ACC (&acc)[FM][FN], int row0, int col0, int part,
                                               int lane) {
     // MT = 16: v_mfma_f32_16x16x32 C/D layout  col = lane&15, row = (lane>>4)*4 + r            (r = 0..3)
@@ -43,17 +46,19 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
     // both: per lane NG groups of 4 consecutive rows of one column
     constexpr int NG = MT == 16 ? 1 : 4;
     const int fr = lane & (MT - 1), fg = lane / MT;
-    const bool has_drop = p.drop_thresh > 0u;
-    const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
+    const bool has_drop = !LEAN && p.drop_thresh > 0u;
+    const uint32_t dkey = LEAN ? 0u : cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const uint32_t dthr = p.drop_thresh;
     const float dscale = has_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-    const int Hh = p.outT ? p.T_E / 64 : 1;
+    const int Hh = (!LEAN && p.outT) ? p.T_E / 64 : 1;
     const int part_cnt = max(0, min(FM * MT, p.M - row0));
     // residual reads and output writes go through raw buffer descriptors: an element outside the problem (row >= M,
     // column >= N) is an out-of-range offset - reads return 0, writes are dropped - so the epilogue has no per-element
     // branches and its residual loads are issued together instead of one wait per element
     const bool has_res = p.resid != nullptr, has_out = p.out != nullptr;
-    const unsigned res_es = p.resid_f32 ? 4u : 2u, out_es = p.out_f32 ? 4u : 2u;
+    const bool res_f32 = !LEAN && p.resid_f32, out_f32 = !LEAN && p.out_f32;
+    const int act = LEAN ? 0 : p.act;
+    const unsigned res_es = res_f32 ? 4u : 2u, out_es = out_f32 ? 4u : 2u;
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.resid), 0, has_res ? (int)((size_t)p.M * p.ldr * res_es) : 0, CRIS_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, has_out ? (int)((size_t)p.M * p.ldc * out_es) : 0,
@@ -64,10 +69,10 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
     for (int j = 0; j < FN; ++j) {
         const int col = col0 + j * MT + fr;
         const bool cvalid = col < p.N;
-        const float bias = p.bias ? p.bias[cvalid ? col : 0] : 0.f;
+        const float bias = (!LEAN && p.bias) ? p.bias[cvalid ? col : 0] : 0.f;
         float vals[FM * NG][4];
         // fused BatchNorm-backward reduction (see cris_conv_gemm_params.bnr_*)
-        const bool bnr = p.bnr_y != nullptr;
+        const bool bnr = !LEAN && p.bnr_y != nullptr;
         float bsc = 0.f, bsh = 0.f, bmu = 0.f, biv = 0.f, bs0 = 0.f, bs1 = 0.f;
         if (bnr) {
             const int cc = cvalid ? col : 0;
@@ -83,7 +88,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 for (int r = 0; r < 4; ++r) {
                     const int m = rowb + r;
                     const unsigned off = (cvalid && m < p.M) ? ((unsigned)m * (unsigned)p.ldr + (unsigned)(p.r_coff + col)) * res_es : CRIS_OOB;
-                    if (p.resid_f32) rres[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
+                    if (res_f32) rres[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
                     else rres[r] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsR, off, 0, 0));
                 }
             }
@@ -91,8 +96,8 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
             for (int r = 0; r < 4; ++r) {
                 const int m = rowb + r;
                 float x = acc[i][j][g * 4 + r] + bias;
-                if (p.act == 1) x = fmaxf(x, 0.f);
-                else if (p.act == 2) x = x / (1.0f + __expf(-1.702f * x));
+                if (act == 1) x = fmaxf(x, 0.f);
+                else if (act == 2) x = x / (1.0f + __expf(-1.702f * x));
                 if (has_drop) x = cris_keep(dkey, (uint32_t)m * (uint32_t)p.N + (uint32_t)col, dthr) ? x * dscale : 0.f;
                 const bool valid = cvalid && m < p.M;
                 x += rres[r];
@@ -108,11 +113,11 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 }
                 if (has_out) {
                     const unsigned off = valid ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(p.c_coff + col)) * out_es : CRIS_OOB;
-                    if (p.out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, 0);
+                    if (out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(x), rsO, off, 0, 0);
                 }
             }
-            if (p.outT && cvalid && rowb < p.M) {
+            if (!LEAN && p.outT && cvalid && rowb < p.M) {
                 const int sec = col / p.T_E;
                 const int e = col - sec * p.T_E;
                 const int h = e >> 6, d = e & 63;
@@ -187,7 +192,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
 // descriptors over the activation / weight extents: zero fill (spatial padding, M / N / K tails) = an out-of-range byte
 // offset, which the hardware returns as 0 - a branch-free per-lane select, so every wave issues exactly NA + NB DMAs per
 // K-step and the counted vmcnt below is exact.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool LEAN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_params p) {
     constexpr int WTM = BM / WAVES_M;          // wave tile rows
     constexpr int WTN = BN / WAVES_N;
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     }
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 
-    gemm_epilogue<MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
+    gemm_epilogue<LEAN, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
 }
 
 // Skinny kernel (M <= FM*16 rows, 1x1 geometry: text encoder / per-sample vectors).  Such GEMMs are pure latency: one
@@ -424,7 +429,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
             for (int j = 0; j < FN; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] += red[(i * FN + j) * 4 + r][lane];
-        gemm_epilogue<16, FM, FN>(p, acc, 0, n0, 0, lane);
+        gemm_epilogue<false, 16, FM, FN>(p, acc, 0, n0, 0, lane);
     }
 }
 
@@ -483,16 +488,21 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     // <= 72 KB per block: two blocks (8 waves) share a CU's 160 KB LDS and hide each other's barriers / epilogues
     constexpr int LDS_128x64 = 3 * (128 + 64) * 128, LDS_64x128 = 3 * (64 + 128) * 128, LDS_128x128 = 2 * (128 + 128) * 128;
     constexpr int LDS_64x64 = 3 * (64 + 64) * 128;
-    void (*const k_128x64)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 64, 4, 1, 3>;
-    void (*const k_64x128)(const cris_conv_gemm_params) = conv_gemm_kernel<64, 128, 2, 2, 3>;
-    void (*const k_128x128)(const cris_conv_gemm_params) = conv_gemm_kernel<128, 128, 2, 2, 2>;
-    void (*const k_64x64)(const cris_conv_gemm_params) = conv_gemm_kernel<64, 64, 2, 2, 3>;
-    static const int lds_ready = set_lds((const void*)k_128x64, LDS_128x64) | set_lds((const void*)k_64x128, LDS_64x128) |
-                                 set_lds((const void*)k_128x128, LDS_128x128);
+    typedef void (*kern_t)(const cris_conv_gemm_params);
+    // [variant][lean]
+    static const kern_t k_128x64[2] = {conv_gemm_kernel<128, 64, 4, 1, 3, false>, conv_gemm_kernel<128, 64, 4, 1, 3, true>};
+    static const kern_t k_64x128[2] = {conv_gemm_kernel<64, 128, 2, 2, 3, false>, conv_gemm_kernel<64, 128, 2, 2, 3, true>};
+    static const kern_t k_128x128[2] = {conv_gemm_kernel<128, 128, 2, 2, 2, false>, conv_gemm_kernel<128, 128, 2, 2, 2, true>};
+    static const kern_t k_64x64[2] = {conv_gemm_kernel<64, 64, 2, 2, 3, false>, conv_gemm_kernel<64, 64, 2, 2, 3, true>};
+    static const int lds_ready = set_lds((const void*)k_128x64[0], LDS_128x64) | set_lds((const void*)k_128x64[1], LDS_128x64) |
+                                 set_lds((const void*)k_64x128[0], LDS_64x128) | set_lds((const void*)k_64x128[1], LDS_64x128) |
+                                 set_lds((const void*)k_128x128[0], LDS_128x128) | set_lds((const void*)k_128x128[1], LDS_128x128);
     if (lds_ready != 0) {
         cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, lds_ready);
         return lds_ready;
     }
+    const int lean = (!p.bias && p.act == 0 && p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32) &&
+                      !p.bnr_y) ? 1 : 0;
     switch (pick_variant(p)) {
         case V_SKINNY1:
             hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);
@@ -501,19 +511,16 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
             hipLaunchKernelGGL(skinny_gemm_kernel<9>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);
             break;
         case V_128x64:
-            hipLaunchKernelGGL(k_128x64, dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256),
-                               LDS_128x64, s, p);
+            hipLaunchKernelGGL(k_128x64[lean], dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256), LDS_128x64, s, p);
             break;
         case V_64x64:
-            hipLaunchKernelGGL(k_64x64, dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
+            hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
             break;
         case V_64x128:
-            hipLaunchKernelGGL(k_64x128, dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256),
-                               LDS_64x128, s, p);
+            hipLaunchKernelGGL(k_64x128[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256), LDS_64x128, s, p);
             break;
         default:
-            hipLaunchKernelGGL(k_128x128, dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128)), dim3(256),
-                               LDS_128x128, s, p);
+            hipLaunchKernelGGL(k_128x128[lean], dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128)), dim3(256), LDS_128x128, s, p);
     }
     CRIS_LAUNCH_CHECK();
     return 0;
