@@ -273,7 +273,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     int kh = tap / p.KW;
     int kw = tap - kh * p.KW;
 
-    auto issue_stage = [&](int buf) {
+    // general K-step issue: the 8-channel chunk of a lane may sit in any tap (C not a multiple of 64)
+    auto issue_gen = [&](int buf) {
         unsigned char* sa = smem + buf * STAGE_BYTES + wave * 1024;          // wave-uniform LDS base of DMA j: + j*4096
         unsigned char* sb = sa + A_BYTES;
         const bool kvalid = kcur < p.K;
@@ -297,6 +298,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
             if (++kw == p.KW) { kw = 0; ++kh; }
         }
     };
+    // fast K-step issue for C % 64 == 0 (every layer of the real networks except the stem): a whole 64-wide K-step lies in
+    // ONE tap, so the tap is wave-uniform; the per-row pixel offsets / padding validity are recomputed only when the tap
+    // changes (every C/64 steps) and a K-step costs one v_add + v_or per DMA instead of ~20 VALU instructions - the main
+    // loop of these kernels is otherwise bound by address arithmetic, not by MFMA or memory.
+    int f_kh = 0, f_kw = 0, f_c = 0, f_k = 0;                               // wave-uniform
+    unsigned a_base[NA];
+    const unsigned lane_k = (unsigned)kc * 16u;                             // byte offset of this lane's chunk inside a K-step
+    auto issue_fast = [&](int buf) {
+        unsigned char* sa = smem + buf * STAGE_BYTES + wave * 1024;
+        unsigned char* sb = sa + A_BYTES;
+        if (f_c == 0) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int ih = a_ih[i] + f_kh, iw = a_iw[i] + f_kw;
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                a_base[i] = ok ? ((unsigned)(a_pix[i] + ih * p.W + iw) * (unsigned)p.lda + (unsigned)p.a_coff) * 2u + lane_k : CRIS_OOB;
+            }
+        }
+        const unsigned kvm = f_k < p.K ? 0u : CRIS_OOB;                      // steps beyond K read zeros
+        const unsigned ca = (unsigned)f_c * 2u, kb = (unsigned)f_k * 2u + lane_k;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sa + i * 4096), 16, (a_base[i] + ca) | kvm, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + i * 4096), 16, (b_off[i] + kb) | kvm, 0, 0, 0);
+        f_k += BK;
+        f_c += BK;
+        if (f_c >= p.C) {
+            f_c = 0;
+            if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+        }
+    };
 
     f32x16 acc[FM][FN];
 #pragma unroll
@@ -307,43 +341,47 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    // prologue: STAGES-1 K-steps in flight (steps beyond nk read zeros: keeps the vmcnt arithmetic uniform)
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) issue_stage(s);
     const int fr = lane & 31, fh = lane >> 5;
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        CRIS_VMCNT((STAGES - 2) * (NA + NB));       // this wave's share of K-step kt has landed ...
-        __builtin_amdgcn_s_barrier();               // ... and everyone's; everyone is also done reading step kt-1
-        {
-            int nb = buf + STAGES - 1;
-            if (nb >= STAGES) nb -= STAGES;
-            issue_stage(nb);                        // refill the buffer of step kt-1 with step kt+STAGES-1
-        }
-        const unsigned char* sa = smem + buf * STAGE_BYTES;
-        const unsigned char* sb = sa + A_BYTES;
+    auto main_loop = [&](auto&& issue_stage) {
+        // prologue: STAGES-1 K-steps in flight (steps beyond nk read zeros: keeps the vmcnt arithmetic uniform)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {            // 4 k-slices of 16 per 64-wide step
-            bf16x8 af[FM], bfr[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int row = wm * WTM + i * MT + fr;
-                af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(row, ks * 2 + fh));
+        for (int s = 0; s < STAGES - 1; ++s) issue_stage(s);
+        int buf = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            CRIS_VMCNT((STAGES - 2) * (NA + NB));       // this wave's share of K-step kt has landed ...
+            __builtin_amdgcn_s_barrier();               // ... and everyone's; everyone is also done reading step kt-1
+            {
+                int nb = buf + STAGES - 1;
+                if (nb >= STAGES) nb -= STAGES;
+                issue_stage(nb);                        // refill the buffer of step kt-1 with step kt+STAGES-1
             }
+            const unsigned char* sa = smem + buf * STAGE_BYTES;
+            const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
-            for (int j = 0; j < FN; ++j) {
-                const int row = wn * WTN + j * MT + fr;
-                bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(row, ks * 2 + fh));
+            for (int ks = 0; ks < 4; ++ks) {            // 4 k-slices of 16 per 64-wide step
+                bf16x8 af[FM], bfr[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int row = wm * WTM + i * MT + fr;
+                    af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(row, ks * 2 + fh));
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const int row = wn * WTN + j * MT + fr;
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(row, ks * 2 + fh));
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);          // keep this step's LDS reads / MFMAs ahead of the next barrier
+            if (++buf == STAGES) buf = 0;
         }
-        __builtin_amdgcn_sched_barrier(0);          // keep this step's LDS reads / MFMAs ahead of the next barrier
-        if (++buf == STAGES) buf = 0;
-    }
+    };
+    if ((p.C & 63) == 0) main_loop(issue_fast);
+    else main_loop(issue_gen);
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 
     gemm_epilogue<LEAN, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
