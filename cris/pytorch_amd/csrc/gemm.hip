@@ -319,11 +319,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
         const unsigned kvm = f_k < p.K ? 0u : CRIS_OOB;                      // steps beyond K read zeros
         const unsigned ca = (unsigned)f_c * 2u, kb = (unsigned)f_k * 2u + lane_k;
 #pragma unroll
-        for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sa + i * 4096), 16, (a_base[i] + ca) | kvm, 0, 0, 0);
+        for (int i = 0; i < NA; ++i) {       // (braces matter: hipcc 7.2's host pass drops the kernel stub for a brace-less body)
+            const unsigned off = (a_base[i] + ca) | kvm;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(sa + i * 4096), 16, off, 0, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + i * 4096), 16, (b_off[i] + kb) | kvm, 0, 0, 0);
+        for (int i = 0; i < NB; ++i) {
+            const unsigned off = (b_off[i] + kb) | kvm;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + i * 4096), 16, off, 0, 0, 0);
+        }
         f_k += BK;
         f_c += BK;
         if (f_c >= p.C) {
@@ -342,7 +346,12 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
 
     const int nk = (p.K + BK - 1) / BK;
     const int fr = lane & 31, fh = lane >> 5;
-    auto main_loop = [&](auto&& issue_stage) {
+    const bool fastk = (p.C & 63) == 0;             // wave-uniform
+    auto issue_stage = [&](int b_) {
+        if (fastk) issue_fast(b_);
+        else issue_gen(b_);
+    };
+    {
         // prologue: STAGES-1 K-steps in flight (steps beyond nk read zeros: keeps the vmcnt arithmetic uniform)
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s) issue_stage(s);
@@ -379,9 +388,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
             __builtin_amdgcn_sched_barrier(0);          // keep this step's LDS reads / MFMAs ahead of the next barrier
             if (++buf == STAGES) buf = 0;
         }
-    };
-    if ((p.C & 63) == 0) main_loop(issue_fast);
-    else main_loop(issue_gen);
+    }
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 
     gemm_epilogue<LEAN, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
