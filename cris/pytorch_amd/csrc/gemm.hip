@@ -644,21 +644,46 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(p.X), 0, (int)((size_t)p.Bn * p.H * p.W * p.ldx * 2), CRIS_BUF_FLAGS);
     u32x4 ry[8], rx[8];
+    // (b, oh, ow) of this thread's first row, kept incrementally: no integer division inside the pixel loop (16 per step
+    // otherwise - the loop was bound by that arithmetic, not by MFMA or memory)
+    const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;      // pixel index == row index
+    int rb, roh, row_;
+    {
+        const int m = m_begin + mg * 8;
+        rb = m / OHW;
+        const int r = m - rb * OHW;
+        roh = r / p.OW;
+        row_ = r - roh * p.OW;
+    }
+    const int dq = WG_T / p.OW, dr = WG_T - dq * p.OW;                             // one step = WG_T rows further
     auto load_step = [&](int mb) {
+        int b = rb, oh = roh, ow = row_;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int m = mb + mg * 8 + i;
             const bool mv = m < m_end;
-            const int b = m / OHW;
-            const int r = m - b * OHW;
-            const int oh = r / p.OW;
-            const int ow = r - oh * p.OW;
-            const int ih = oh * p.stride - p.pad + xkh, iw = ow * p.stride - p.pad + xkw;
-            const bool xv = mv && xvalid && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
             const unsigned yo = ((unsigned)m * (unsigned)p.ldy + (unsigned)(p.y_coff + yn)) * 2u;
-            const unsigned xo = ((unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.ldx + (unsigned)(p.x_coff + xc)) * 2u;
+            unsigned xo;
+            bool xv = mv && xvalid;
+            if (lin) {
+                xo = ((unsigned)m * (unsigned)p.ldx + (unsigned)(p.x_coff + xc)) * 2u;
+            } else {
+                const int ih = oh * p.stride - p.pad + xkh, iw = ow * p.stride - p.pad + xkw;
+                xv = xv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                xo = ((unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.ldx + (unsigned)(p.x_coff + xc)) * 2u;
+                if (++ow == p.OW) {                                              // next row of this thread's 8-row group
+                    ow = 0;
+                    if (++oh == p.OH) { oh = 0; ++b; }
+                }
+            }
             ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (mv && yvalid) ? yo : CRIS_OOB, 0, 0);
             rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xv ? xo : CRIS_OOB, 0, 0);
+        }
+        if (!lin) {                                                              // advance the group's first row by WG_T rows
+            row_ += dr;
+            roh += dq;
+            if (row_ >= p.OW) { row_ -= p.OW; ++roh; }
+            while (roh >= p.OH) { roh -= p.OH; ++rb; }
         }
     };
     auto store_step = [&]() {
