@@ -15,6 +15,7 @@
 //   split over m only as far as needed to fill the chip, fp32 atomics when split, plain stores otherwise.
 #include "common.h"
 #include "../../../include/cris_hip.h"
+#include <type_traits>
 
 #define BK 64
 #define SKINNY_MAX_M 144      // M <= this and a 1x1 geometry -> skinny kernel (no LDS staging, K split over the waves)
@@ -192,14 +193,17 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
 // descriptors over the activation / weight extents: zero fill (spatial padding, M / N / K tails) = an out-of-range byte
 // offset, which the hardware returns as 0 - a branch-free per-lane select, so every wave issues exactly NA + NB DMAs per
 // K-step and the counted vmcnt below is exact.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool LEAN>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool LEAN, int MT_ = 32>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_params p) {
     constexpr int WTM = BM / WAVES_M;          // wave tile rows
     constexpr int WTN = BN / WAVES_N;
     // v_mfma_f32_32x32x16_bf16: one 16-B A chunk + one 16-B B chunk per lane feed 32x32x16 MACs - half the LDS read
     // traffic per flop of the 16x16x32 shape (LDS read bandwidth, 128 B/clk/CU, is what caps the 16x16 form at 64x64
-    // wave tiles).  A/B lane layout: row = lane&31, k = (lane>>5)*8 .. +8.
-    constexpr int MT = 32;
+    // wave tiles).  A/B lane layout: row = lane&31, k = (lane>>5)*8 .. +8.  The 64x64 block tile (32x32 wave tile) uses the
+    // 16x16x32 shape instead: four independent accumulators per wave keep the matrix pipe issuing where a single 32x32
+    // accumulator would serialise on its own result (SQ_WAIT_INST_ANY 23 % of the wave cycles, profiles/r01_sq_counters).
+    constexpr int MT = MT_;
+    using acc_t = typename std::conditional<MT == 32, f32x16, f32x4>::type;
     constexpr int FM = WTM / MT;
     constexpr int FN = WTN / MT;
     constexpr int NA = BM / 32;                // DMA instructions per wave per K-step (A): 8 rows each, 4 waves
@@ -336,16 +340,18 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
         }
     };
 
-    f32x16 acc[FM][FN];
+    acc_t acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) acc[i][j][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    const int fr = lane & 31, fh = lane >> 5;
+    const int fr = lane & (MT - 1), fh = lane / MT;             // fragment row, 16-B chunk inside a k-slice
+    constexpr int KSL = MT == 32 ? 4 : 2;                       // k-slices per 64-wide step (16 or 32 deep)
+    constexpr int CPS = 8 / KSL;                                // 16-B chunks per slice
     const bool fastk = (p.C & 63) == 0;             // wave-uniform
     auto issue_stage = [&](int b_) {
         if (fastk) issue_fast(b_);
@@ -367,23 +373,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
             const unsigned char* sa = smem + buf * STAGE_BYTES;
             const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {            // 4 k-slices of 16 per 64-wide step
+            for (int ks = 0; ks < KSL; ++ks) {
                 bf16x8 af[FM], bfr[FN];
 #pragma unroll
                 for (int i = 0; i < FM; ++i) {
                     const int row = wm * WTM + i * MT + fr;
-                    af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(row, ks * 2 + fh));
+                    af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(row, ks * CPS + fh));
                 }
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
                     const int row = wn * WTN + j * MT + fr;
-                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(row, ks * 2 + fh));
+                    bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(row, ks * CPS + fh));
                 }
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < FN; ++j) {
+                        if constexpr (MT == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    }
             }
             __builtin_amdgcn_sched_barrier(0);          // keep this step's LDS reads / MFMAs ahead of the next barrier
             if (++buf == STAGES) buf = 0;
@@ -538,7 +546,9 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     static const kern_t k_128x64[2] = {conv_gemm_kernel<128, 64, 4, 1, 3, false>, conv_gemm_kernel<128, 64, 4, 1, 3, true>};
     static const kern_t k_64x128[2] = {conv_gemm_kernel<64, 128, 2, 2, 3, false>, conv_gemm_kernel<64, 128, 2, 2, 3, true>};
     static const kern_t k_128x128[2] = {conv_gemm_kernel<128, 128, 2, 2, 2, false>, conv_gemm_kernel<128, 128, 2, 2, 2, true>};
-    static const kern_t k_64x64[2] = {conv_gemm_kernel<64, 64, 2, 2, 3, false>, conv_gemm_kernel<64, 64, 2, 2, 3, true>};
+    static const kern_t k_64x64[2] = {conv_gemm_kernel<64, 64, 2, 2, 3, false, 16>, conv_gemm_kernel<64, 64, 2, 2, 3, true, 16>};
+    static const kern_t k_64x64_s2[2] = {conv_gemm_kernel<64, 64, 2, 2, 2, false, 16>, conv_gemm_kernel<64, 64, 2, 2, 2, true, 16>};
+    static const int st64 = cris_env_int("CRIS_GEMM_64_STAGES", 3);
     static const int lds_ready = set_lds((const void*)k_128x64[0], LDS_128x64) | set_lds((const void*)k_128x64[1], LDS_128x64) |
                                  set_lds((const void*)k_64x128[0], LDS_64x128) | set_lds((const void*)k_64x128[1], LDS_64x128) |
                                  set_lds((const void*)k_128x128[0], LDS_128x128) | set_lds((const void*)k_128x128[1], LDS_128x128);
@@ -559,7 +569,10 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
             hipLaunchKernelGGL(k_128x64[lean], dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256), LDS_128x64, s, p);
             break;
         case V_64x64:
-            hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
+            if (st64 == 2)
+                hipLaunchKernelGGL(k_64x64_s2[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64 * 2 / 3, s, p);
+            else
+                hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
             break;
         case V_64x128:
             hipLaunchKernelGGL(k_64x128[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256), LDS_64x128, s, p);
