@@ -199,9 +199,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     constexpr int WTN = BN / WAVES_N;
     // v_mfma_f32_32x32x16_bf16: one 16-B A chunk + one 16-B B chunk per lane feed 32x32x16 MACs - half the LDS read
     // traffic per flop of the 16x16x32 shape (LDS read bandwidth, 128 B/clk/CU, is what caps the 16x16 form at 64x64
-    // wave tiles).  A/B lane layout: row = lane&31, k = (lane>>5)*8 .. +8.  The 64x64 block tile (32x32 wave tile) uses the
-    // 16x16x32 shape instead: four independent accumulators per wave keep the matrix pipe issuing where a single 32x32
-    // accumulator would serialise on its own result (SQ_WAIT_INST_ANY 23 % of the wave cycles, profiles/r01_sq_counters).
+    // wave tiles).  A/B lane layout: row = lane&31, k = (lane>>5)*8 .. +8.  MT_ = 16 selects the 16x16x32 shape (four
+    // independent accumulators on a 32x32 wave tile); measured no better on the 64x64 block tile, so unused.
     constexpr int MT = MT_;
     using acc_t = typename std::conditional<MT == 32, f32x16, f32x4>::type;
     constexpr int FM = WTM / MT;
@@ -546,9 +545,9 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     static const kern_t k_128x64[2] = {conv_gemm_kernel<128, 64, 4, 1, 3, false>, conv_gemm_kernel<128, 64, 4, 1, 3, true>};
     static const kern_t k_64x128[2] = {conv_gemm_kernel<64, 128, 2, 2, 3, false>, conv_gemm_kernel<64, 128, 2, 2, 3, true>};
     static const kern_t k_128x128[2] = {conv_gemm_kernel<128, 128, 2, 2, 2, false>, conv_gemm_kernel<128, 128, 2, 2, 2, true>};
-    static const kern_t k_64x64[2] = {conv_gemm_kernel<64, 64, 2, 2, 3, false, 16>, conv_gemm_kernel<64, 64, 2, 2, 3, true, 16>};
-    static const kern_t k_64x64_s2[2] = {conv_gemm_kernel<64, 64, 2, 2, 2, false, 16>, conv_gemm_kernel<64, 64, 2, 2, 2, true, 16>};
-    static const int st64 = cris_env_int("CRIS_GEMM_64_STAGES", 3);
+    // (measured alternatives for this variant: 16x16x32 MFMA with four accumulators 19.50 vs 19.39 ms/step, a 2-stage ring
+    // with 5 blocks per CU 20.00 ms/step - neither helps)
+    static const kern_t k_64x64[2] = {conv_gemm_kernel<64, 64, 2, 2, 3, false>, conv_gemm_kernel<64, 64, 2, 2, 3, true>};
     static const int lds_ready = set_lds((const void*)k_128x64[0], LDS_128x64) | set_lds((const void*)k_128x64[1], LDS_128x64) |
                                  set_lds((const void*)k_64x128[0], LDS_64x128) | set_lds((const void*)k_64x128[1], LDS_64x128) |
                                  set_lds((const void*)k_128x128[0], LDS_128x128) | set_lds((const void*)k_128x128[1], LDS_128x128);
@@ -569,10 +568,7 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
             hipLaunchKernelGGL(k_128x64[lean], dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256), LDS_128x64, s, p);
             break;
         case V_64x64:
-            if (st64 == 2)
-                hipLaunchKernelGGL(k_64x64_s2[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64 * 2 / 3, s, p);
-            else
-                hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
+            hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
             break;
         case V_64x128:
             hipLaunchKernelGGL(k_64x128[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256), LDS_64x128, s, p);
