@@ -23,6 +23,10 @@ class TorchDistComm:
         self.device = device
         self.side = torch.cuda.Stream(device=device) if (device is not None and torch.device(device).type == "cuda") else None
         self._pending = []
+        # the gradient exchange gets its OWN communicator: collectives of one communicator execute in issue order, so on
+        # the default group the tiny SyncBN all-reduces of the layers still in backward would queue behind 100+ MB
+        # gradient messages and stall the compute stream
+        self.grad_group = dist.new_group(ranks=list(range(self.world)))
 
     # SyncBN exchanges run inline on the compute stream (they sit on the critical path by construction)
     def allreduce_sum(self, t):
@@ -31,13 +35,13 @@ class TorchDistComm:
     # gradient exchange: overlapped
     def allreduce_async(self, t):
         if self.side is None:
-            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.grad_group, async_op=True))
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
-            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True))
+            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.grad_group, async_op=True))
 
     def wait_all(self):
         for w in self._pending:
