@@ -19,10 +19,11 @@
 
 #define NEG_INF (-__builtin_inff())
 
-__device__ __forceinline__ bf16x8 ld_frag16(const bf16_t* p, bool ok) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (ok) v = *reinterpret_cast<const uint4*>(p);
-    return __builtin_bit_cast(bf16x8, v);
+// Fragment loads are UNCONDITIONAL: rows beyond the sequence are read from the last valid row (clamped index) and their
+// scores / probabilities are masked afterwards.  A per-lane `if (ok) load` makes hipcc branch around every load and wait
+// for it inside the branch, which serialises the loads of a step (these kernels sat at 75 % wave-wait cycles).
+__device__ __forceinline__ bf16x8 ld_frag16(const bf16_t* p) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p));
 }
 // two 8-byte pieces (reduction slots j=0..3 and j=4..7)
 __device__ __forceinline__ bf16x8 ld_frag8x2(const bf16_t* p0, const bf16_t* p1) {
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const cris_attn_params p)
     const bool qok = q < p.Lq;
 
     const bf16_t* Qp = p.Q + (size_t)(b * p.Lq + q) * p.ldq + h * 64 + fg * 8;
-    const bf16x8 bq0 = ld_frag16(Qp, qok), bq1 = ld_frag16(Qp + 32, qok);
+    const bf16x8 bq0 = ld_frag16(Qp), bq1 = ld_frag16(Qp + 32);
 
     const bf16_t* Kb = p.K + (size_t)b * p.Lk * p.ldk + h * 64 + fg * 8;
     const bf16_t* Vt = p.Vt + (size_t)bh * 64 * p.Lk_pad;
@@ -75,12 +76,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const cris_attn_params p)
     const int kend = p.causal ? min(p.Lk, q0 + 16) : p.Lk;
     for (int k0 = 0; k0 < kend; k0 += 32) {
         float s[8];
+        // V^T fragments of this step: issued first, in flight under the QK^T MFMAs and the softmax
+        bf16x8 av[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16_t* vp = Vt + (size_t)(db * 16 + fr) * p.Lk_pad + k0 + fg * 4;
+            av[db] = ld_frag8x2(vp, vp + 16);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int key = k0 + kb * 16 + fr;
-            const bool kok = key < p.Lk;
-            const bf16_t* kp = Kb + (size_t)key * p.ldk;
-            const bf16x8 a0 = ld_frag16(kp, kok), a1 = ld_frag16(kp + 32, kok);
+            const bf16_t* kp = Kb + (size_t)min(key, p.Lk - 1) * p.ldk;
+            const bf16x8 a0 = ld_frag16(kp), a1 = ld_frag16(kp + 32);
             f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f};
             st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq0, st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, st, 0, 0, 0);
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const cris_attn_params p)
                 const int kk = k0 + kb * 16 + fg * 4 + r;
                 float v = st[r] * p.scale;
                 bool masked = kk >= p.Lk || (p.causal && kk > q);
-                if (!masked && toks) masked = toks[kk] == 0;
+                if (toks) masked = masked || toks[min(kk, p.Lk - 1)] == 0;
                 s[kb * 4 + r] = masked ? NEG_INF : v;
             }
         }
@@ -127,11 +134,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const cris_attn_params p)
         }
         const bf16x8 bp = pack_frag(pv);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            const bf16_t* vp = Vt + (size_t)(db * 16 + fr) * p.Lk_pad + k0 + fg * 4;
-            const bf16x8 av = ld_frag8x2(vp, vp + 16);
-            o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bp, o[db], 0, 0, 0);
-        }
+        for (int db = 0; db < 4; ++db) o[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[db], bp, o[db], 0, 0, 0);
     }
     const float inv_l = l_run > 0.f ? 1.f / l_run : 0.f;
     if (qok) {
@@ -178,10 +181,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const cris_attn_params
     const int q = q0 + fr;
     const bool qok = q < p.Lq;
 
-    const bf16_t* Qp = p.Q + (size_t)(b * p.Lq + q) * p.ldq + h * 64 + fg * 8;
-    const bf16x8 bq0 = ld_frag16(Qp, qok), bq1 = ld_frag16(Qp + 32, qok);
-    const bf16_t* dOp = p.dO + (size_t)(b * p.Lq + q) * p.lddo + h * 64 + fg * 8;
-    const bf16x8 bd0 = ld_frag16(dOp, qok), bd1 = ld_frag16(dOp + 32, qok);
+    const int qcl = min(q, p.Lq - 1);                      // rows beyond Lq read the last row; they are masked (!qok)
+    const bf16_t* Qp = p.Q + (size_t)(b * p.Lq + qcl) * p.ldq + h * 64 + fg * 8;
+    const bf16x8 bq0 = ld_frag16(Qp), bq1 = ld_frag16(Qp + 32);
+    const bf16_t* dOp = p.dO + (size_t)(b * p.Lq + qcl) * p.lddo + h * 64 + fg * 8;
+    const bf16x8 bd0 = ld_frag16(dOp), bd1 = ld_frag16(dOp + 32);
     // delta = sum_d dO*O for this query (this lane covers d = fg*8..+7 and 32+fg*8..+7)
     float delta = 0.f;
     {
@@ -221,14 +225,19 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const cris_attn_params
     const int kend = p.causal ? min(p.Lk, q0 + 16) : p.Lk;
     for (int k0 = 0; k0 < kend; k0 += 32) {
         float ds[8];
+        bf16x8 akt[4];                                   // K^T fragments of this step, in flight under the score MFMAs
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const bf16_t* kp = Kt + (size_t)(db * 16 + fr) * p.Lk_pad + k0 + fg * 4;
+            akt[db] = ld_frag8x2(kp, kp + 16);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            const int key = k0 + kb * 16 + fr;
-            const bool kok = key < p.Lk;
+            const int key = min(k0 + kb * 16 + fr, p.Lk - 1);
             const bf16_t* kp = Kb + (size_t)key * p.ldk;
             const bf16_t* vp = Vb + (size_t)key * p.ldv;
-            const bf16x8 a0 = ld_frag16(kp, kok), a1 = ld_frag16(kp + 32, kok);
-            const bf16x8 v0 = ld_frag16(vp, kok), v1 = ld_frag16(vp + 32, kok);
+            const bf16x8 a0 = ld_frag16(kp), a1 = ld_frag16(kp + 32);
+            const bf16x8 v0 = ld_frag16(vp), v1 = ld_frag16(vp + 32);
             f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = st;
             st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq0, st, 0, 0, 0);
             st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq1, st, 0, 0, 0);
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const cris_attn_params
             for (int r = 0; r < 4; ++r) {
                 const int kk = k0 + kb * 16 + fg * 4 + r;
                 bool masked = kk >= p.Lk || (p.causal && kk > q) || !qok;
-                if (!masked && toks) masked = toks[kk] == 0;
+                if (toks) masked = masked || toks[min(kk, p.Lk - 1)] == 0;
                 float pr = masked ? 0.f : __expf(st[r] * p.scale - lse);
                 float dpv = dp[r];
                 if (has_drop) dpv = cris_keep(dkey, didx0 + (uint32_t)kk, p.drop_thresh) ? dpv * inv_keep : 0.f;
@@ -247,11 +256,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const cris_attn_params
         }
         const bf16x8 bds = pack_frag(ds);
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            const bf16_t* kp = Kt + (size_t)(db * 16 + fr) * p.Lk_pad + k0 + fg * 4;
-            const bf16x8 ak = ld_frag8x2(kp, kp + 16);
-            dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bds, dq[db], 0, 0, 0);
-        }
+        for (int db = 0; db < 4; ++db) dq[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(akt[db], bds, dq[db], 0, 0, 0);
     }
     if (qok) {
         bf16_t* op = p.dQ + (size_t)(b * p.Lq + q) * p.lddq + h * 64 + fg * 4;
@@ -292,10 +297,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const cris_attn_param
     if (kok && p.key_tokens) kmask = p.key_tokens[(size_t)b * p.Lk + key] == 0;
 
     // B operands (col = key): K[key][d], V[key][d]
-    const bf16_t* Kp = p.K + (size_t)(b * p.Lk + key) * p.ldk + h * 64 + fg * 8;
-    const bf16_t* Vp = p.V + (size_t)(b * p.Lk + key) * p.ldv + h * 64 + fg * 8;
-    const bf16x8 bk0 = ld_frag16(Kp, kok), bk1 = ld_frag16(Kp + 32, kok);
-    const bf16x8 bv0 = ld_frag16(Vp, kok), bv1 = ld_frag16(Vp + 32, kok);
+    const int keyc = min(key, p.Lk - 1);                   // keys beyond Lk read the last key; nothing is stored for them
+    const bf16_t* Kp = p.K + (size_t)(b * p.Lk + keyc) * p.ldk + h * 64 + fg * 8;
+    const bf16_t* Vp = p.V + (size_t)(b * p.Lk + keyc) * p.ldv + h * 64 + fg * 8;
+    const bf16x8 bk0 = ld_frag16(Kp), bk1 = ld_frag16(Kp + 32);
+    const bf16x8 bv0 = ld_frag16(Vp), bv1 = ld_frag16(Vp + 32);
 
     const bf16_t* Qb = p.Q + (size_t)b * p.Lq * p.ldq + h * 64 + fg * 8;
     const bf16_t* dOb = p.dO + (size_t)b * p.Lq * p.lddo + h * 64 + fg * 8;
@@ -314,14 +320,20 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const cris_attn_param
     const int qstart = p.causal ? (kk0 / 32) * 32 : 0;      // queries < key never attend under the causal mask
     for (int q0 = qstart; q0 < p.Lq; q0 += 32) {
         float pd[8], ds[8];
+        bf16x8 ado[4], aqt[4];                           // dO^T / Q^T fragments of this step, issued first
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+            const size_t ro = (size_t)(db * 16 + fr) * p.Lq_pad + q0 + fg * 4;
+            ado[db] = ld_frag8x2(dOt + ro, dOt + ro + 16);
+            aqt[db] = ld_frag8x2(Qt + ro, Qt + ro + 16);
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            const int qrow = q0 + qb * 16 + fr;               // A-operand row of this lane
-            const bool rok = qrow < p.Lq;
+            const int qrow = min(q0 + qb * 16 + fr, p.Lq - 1);   // A-operand row of this lane (clamped: masked below)
             const bf16_t* qp = Qb + (size_t)qrow * p.ldq;
             const bf16_t* dop = dOb + (size_t)qrow * p.lddo;
-            const bf16x8 aq0 = ld_frag16(qp, rok), aq1 = ld_frag16(qp + 32, rok);
-            const bf16x8 ad0 = ld_frag16(dop, rok), ad1 = ld_frag16(dop + 32, rok);
+            const bf16x8 aq0 = ld_frag16(qp), aq1 = ld_frag16(qp + 32);
+            const bf16x8 ad0 = ld_frag16(dop), ad1 = ld_frag16(dop + 32);
             f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = sv;
             sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq0, bk0, sv, 0, 0, 0);
             sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq1, bk1, sv, 0, 0, 0);
@@ -331,11 +343,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const cris_attn_param
             for (int r = 0; r < 4; ++r) {
                 const int qq = q0 + qb * 16 + fg * 4 + r;     // C/D row of this lane = query
                 const bool ok = qq < p.Lq && !kmask && !(p.causal && key > qq);
-                float pr = 0.f, dlt = 0.f;
-                if (ok) {
-                    pr = __expf(sv[r] * p.scale - lsep[qq]);
-                    dlt = delp[qq];
-                }
+                const int qc = min(qq, p.Lq - 1);
+                const float pr = ok ? __expf(sv[r] * p.scale - lsep[qc]) : 0.f;
+                const float dlt = ok ? delp[qc] : 0.f;
                 float dpv = dp[r];
                 float prd = pr;
                 if (has_drop) {
@@ -350,11 +360,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const cris_attn_param
         const bf16x8 bp = pack_frag(pd), bds = pack_frag(ds);
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            const size_t ro = (size_t)(db * 16 + fr) * p.Lq_pad + q0 + fg * 4;
-            const bf16x8 ado = ld_frag8x2(dOt + ro, dOt + ro + 16);
-            const bf16x8 aqt = ld_frag8x2(Qt + ro, Qt + ro + 16);
-            dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado, bp, dv[db], 0, 0, 0);
-            dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqt, bds, dk[db], 0, 0, 0);
+            dv[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ado[db], bp, dv[db], 0, 0, 0);
+            dk[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aqt[db], bds, dk[db], 0, 0, 0);
         }
     }
     if (kok) {
