@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const cris_attn_params p)
     const int q = q0 + fr;
     const bool qok = q < p.Lq;
 
-    const bf16_t* Qp = p.Q + (size_t)(b * p.Lq + q) * p.ldq + h * 64 + fg * 8;
+    const bf16_t* Qp = p.Q + (size_t)(b * p.Lq + min(q, p.Lq - 1)) * p.ldq + h * 64 + fg * 8;   // clamped: masked by !qok
     const bf16x8 bq0 = ld_frag16(Qp), bq1 = ld_frag16(Qp + 32);
 
     const bf16_t* Kb = p.K + (size_t)b * p.Lk * p.ldk + h * 64 + fg * 8;
