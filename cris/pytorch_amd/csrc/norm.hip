@@ -748,7 +748,7 @@ extern "C" int cris_ln_bwd(const cris_ln_bwd_params* pp, void* stream) {
     CRIS_CHECK_ARG(p.dy || p.dypos || p.dout_f32, "no incoming gradient");
     CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 64 * 8 * LN_MAXV && (p.ldx & 7) == 0, "C must be a multiple of 8, <= 2048");
     CRIS_CHECK_ARG(!p.dx_accum || p.dx_f32, "accumulate only into fp32");
-    static const int max_grid = cris_env_int("CRIS_LN_BWD_BLOCKS", 128);
+    static const int max_grid = cris_env_int("CRIS_LN_BWD_BLOCKS", 256);
     const int grid = cris_grid_1d(p.rows, 4, max_grid);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
