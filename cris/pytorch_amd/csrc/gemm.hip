@@ -459,8 +459,8 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
                                                                     acc[i][j], 0, 0, 0);
             }
     }
-    // fixed-order sum over the waves: SK_WAVES-1 .. 1 add into LDS one after the other, wave 0 finishes
-    for (int w = SK_WAVES - 1; w >= 1; --w) {
+    // fixed-order sum over the waves (deterministic): SK_WAVES-1 .. 0 add into the LDS table one after the other
+    for (int w = SK_WAVES - 1; w >= 0; --w) {
         if (wave == w) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
@@ -474,14 +474,15 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
         }
         __syncthreads();
     }
-    if (wave == 0) {
+    // the epilogue (thousands of instructions per fragment in its general form) is spread over all waves: wave w finishes
+    // the 16x16 fragments w, w+8, ... ; one BatchNorm-statistics part per 16-row fragment row
+#pragma unroll 1
+    for (int u = wave; u < FM * FN; u += SK_WAVES) {
+        const int i = u / FN, j = u - i * FN;
+        f32x4 one[1][1];
 #pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < FN; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][j][r] += red[(i * FN + j) * 4 + r][lane];
-        gemm_epilogue<false, 16, FM, FN>(p, acc, 0, n0, 0, lane);
+        for (int r = 0; r < 4; ++r) one[0][0][r] = red[u * 4 + r][lane];
+        gemm_epilogue<false, 16, 1, 1>(p, one, i * 16, n0 + j * 16, i, lane);
     }
 }
 
@@ -506,7 +507,7 @@ static int pick_variant(const cris_conv_gemm_params& p) {
 static int variant_stat_rows(int v) {
     switch (v) {
         case V_SKINNY1: return 16;
-        case V_SKINNY9: return SKINNY_MAX_M;
+        case V_SKINNY9: return 16;
         case V_128x128: return 64;
         default: return 32;
     }

@@ -121,7 +121,7 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
         p.colsum, p.colsq = ptr(st[0]), ptr(st[1])
     if KERNEL_TIMER is not None:
         rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))
-        KERNEL_TIMER.launch("skinny_gemm" if rows in (16, 144) else "conv_gemm", 2.0 * g.M * N * g.K,
+        KERNEL_TIMER.launch("skinny_gemm" if rows == 16 else "conv_gemm", 2.0 * g.M * N * g.K,
                             2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p),
                             tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
         if bnr_part is not None:
