@@ -164,6 +164,38 @@ extern "C" int cris_bn_recentre(float* m2, const float* mean_local, const float*
     return 0;
 }
 
+// SyncBN in ONE exchange: every rank shifts its local (sum, M2 about the local mean) to moments about a reference c that is
+// identical on all ranks (the running mean before this step's update):  S1 = sum - n c,  S2 = M2 + n (mean_l - c)^2.
+// [S1 | S2] is all-reduced as a single 2C message; the sums convert back to (sum, M2 about the GLOBAL mean):
+//   mean = c + S1/N,  M2 = S2 - S1^2/N   (c tracks the batch mean, so the subtraction loses nothing that matters).
+__global__ void bn_sync_pack_kernel(float* merged, const float* mean_local, const float* ref, float n_local, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float r = ref[c];
+    const float d = mean_local[c] - r;
+    merged[c] = merged[c] - n_local * r;
+    merged[C + c] = merged[C + c] + n_local * d * d;
+}
+__global__ void bn_sync_unpack_kernel(float* merged, const float* ref, float count_global, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float s1 = merged[c], s2 = merged[C + c];
+    merged[c] = s1 + count_global * ref[c];                    // global sum
+    merged[C + c] = fmaxf(s2 - s1 * s1 / count_global, 0.f);   // M2 about the global mean
+}
+extern "C" int cris_bn_sync_pack(float* merged, const float* mean_local, const float* ref, float n_local, int C, void* stream) {
+    CRIS_CHECK_ARG(merged && mean_local && ref && C > 0, "bad args");
+    hipLaunchKernelGGL(bn_sync_pack_kernel, dim3(cris_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, merged, mean_local, ref, n_local, C);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cris_bn_sync_unpack(float* merged, const float* ref, float count_global, int C, void* stream) {
+    CRIS_CHECK_ARG(merged && ref && C > 0 && count_global > 0.f, "bad args");
+    hipLaunchKernelGGL(bn_sync_unpack_kernel, dim3(cris_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, merged, ref, count_global, C);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
 // per-row-block column statistics of a bf16 matrix in the same partial format as the GEMM epilogue
 __global__ void colstats_kernel(const bf16_t* x, int ldx, int coff, int M, int C, int rows_per_part, float* psum, float* pm2) {
     const int cv = blockIdx.x * blockDim.x + threadIdx.x;

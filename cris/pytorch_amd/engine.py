@@ -360,13 +360,14 @@ class Engine:
             ops.bn_eval_coeffs(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
             return scale, shift, mean, invstd, count
         if self.sync_bn:
-            # SyncBatchNorm (train.py:97-98): exchange (sum, M2) instead of torch's (mean, invstd, count) all_gather
+            # SyncBatchNorm (train.py:97-98): ONE all-reduce of [S1 | S2] (moments about the running mean, which every rank
+            # holds identically) instead of torch's all_gather of (mean, invstd, count)
             gcount = count * self.comm.world
             merged = self.zeros(2 * C)
             ops.bn_finalize(st, count, count, gamma, beta, None, None, BN_MOM, BN_EPS, C, None, None, mean, None, merged=merged)
-            ops.torch_op(lambda: self.comm.allreduce_sum(merged[:C]))
-            ops.bn_recentre(merged[C:], mean, merged[:C], count, gcount, C)
-            ops.torch_op(lambda: self.comm.allreduce_sum(merged[C:]))
+            ops.bn_sync_pack(merged, mean, rm, count, C)
+            ops.torch_op(lambda: self.comm.allreduce_sum(merged))
+            ops.bn_sync_unpack(merged, rm, gcount, C)
             ops.bn_finalize(None, count, gcount, gamma, beta, rm, rv, BN_MOM, BN_EPS, C, scale, shift, mean, invstd,
                             global_stats=merged)
             return scale, shift, mean, invstd, gcount
@@ -897,6 +898,7 @@ class Engine:
         _build_grad_arena) has been issued on the current stream - the hook the data-parallel gradient exchange uses to
         overlap with the rest of backward."""
         self._gscale = gscale
+        Act._engine = self                              # (another engine may have run a forward in between)
         marks = dict(self._stage_marks)                 # tape index at which a stage's closures START
         (t0, t1), (v0, v1) = self._ranges["text"], self._ranges["visual"]
         head_start = max(t1, v1)                        # neck / decoder / projector closures: main stream

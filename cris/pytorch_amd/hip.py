@@ -161,6 +161,8 @@ _SIGS = {
     "cris_sum_partials": (I, [P, I, I, P, P]),
     "cris_bn_finalize": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P, P]),
     "cris_bn_recentre": (I, [P, P, P, F, F, I, P]),
+    "cris_bn_sync_pack": (I, [P, P, P, F, I, P]),
+    "cris_bn_sync_unpack": (I, [P, P, F, I, P]),
     "cris_colstats_bf16": (I, [P, I, I, I, I, I, P, P, P]),
     "cris_bn_eval_coeffs": (I, [P, P, P, P, F, I, P, P, P]),
     "cris_bn_apply": (I, [P, P]),

@@ -294,6 +294,14 @@ def bn_recentre(m2, mean_local, gsum, n_local, count_global, C_):
     hip.call("cris_bn_recentre", ptr(m2), ptr(mean_local), ptr(gsum), float(n_local), float(count_global), C_, _stream())
 
 
+def bn_sync_pack(merged, mean_local, ref, n_local, C_):
+    hip.call("cris_bn_sync_pack", ptr(merged), ptr(mean_local), ptr(ref), float(n_local), C_, _stream())
+
+
+def bn_sync_unpack(merged, ref, count_global, C_):
+    hip.call("cris_bn_sync_unpack", ptr(merged), ptr(ref), float(count_global), C_, _stream())
+
+
 def colstats(x, M, C_, rows_per_part, device, ldx=None, coff=0) -> Stats:
     st = Stats((M + rows_per_part - 1) // rows_per_part, C_, rows_per_part, device)
     hip.call("cris_colstats_bf16", ptr(x), ldx if ldx is not None else x.shape[-1], coff, M, C_, rows_per_part, ptr(st[0]),

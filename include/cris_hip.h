@@ -119,8 +119,9 @@ int cris_colsum_bf16(const cris_bf16* x, int ldx, int coff, int M, int N, float*
  * (reference: every nn.BatchNorm2d/1d, model/clip.py:18-41,78,173-183; model/layers.py:11,16,262).
  * Statistics arrive as per-row-block partials (column sum, M2 about the block mean) from the conv GEMM
  * epilogue or cris_colstats_bf16 and are merged with Chan's parallel-variance formula.
- * SyncBN: call once with `merged` (local sum / M2 / mean out), all-reduce the sums, cris_bn_recentre the M2,
- * all-reduce the M2, then call again with `global_stats`.
+ * SyncBN: call once with `merged` (local sum / M2 / mean out), exchange (cris_bn_sync_pack + ONE all-reduce +
+ * cris_bn_sync_unpack; or all-reduce the sums, cris_bn_recentre the M2, all-reduce the M2), then call again with
+ * `global_stats`.
  * Long partial lists are merged in two levels: psum / pm2 must have room for cris_bn_partials_rows(nparts) rows of C
  * floats each (the first-level result is written behind the nparts partial rows).
  * ---------------------------------------------------------------------------------------------- */
@@ -133,6 +134,11 @@ int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_p
                      const float* global_stats, void* stream);
 int cris_bn_recentre(float* m2, const float* mean_local, const float* gsum, float n_local, float count_global, int C,
                      void* stream);
+/* single-exchange SyncBN: pack the local (sum | M2) [2C] into moments about `ref` (identical on every rank, e.g. the
+ * running mean), all-reduce the 2C floats once, unpack into (global sum | M2 about the global mean) for
+ * cris_bn_finalize(global_stats=...) */
+int cris_bn_sync_pack(float* merged, const float* mean_local, const float* ref, float n_local, int C, void* stream);
+int cris_bn_sync_unpack(float* merged, const float* ref, float count_global, int C, void* stream);
 int cris_colstats_bf16(const cris_bf16* x, int ldx, int coff, int M, int C, int rows_per_part, float* psum, float* pm2,
                        void* stream);
 /* eval mode: scale/shift from the running statistics */

@@ -32,7 +32,7 @@ def _worker(rank, world, port, q):
         mine = full[rank * 50:(rank + 1) * 50]
         s = mine.sum(0)
         m2 = ((mine - mine.mean(0)) ** 2).sum(0)
-        mean_g, var_g = merge_batchnorm_partials(s, m2, 50.0, comm)
+        mean_g, var_g = merge_batchnorm_partials(s, m2, 50.0, comm, ref=torch.full((16,), 4.5, dtype=torch.float64))
         ok_bn = torch.allclose(mean_g, full.mean(0), atol=1e-12) and torch.allclose(var_g, full.var(0, unbiased=False), atol=1e-12)
         # --- staged gradient exchange over a flat arena, issued back to front like backward does
         arena = torch.arange(1000, dtype=torch.float32) * (rank + 1)

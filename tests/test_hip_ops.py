@@ -728,3 +728,27 @@ def test_zero_bytes():
         t = torch.full((n + 32,), 7, dtype=torch.uint8, device=DEV)
         ops.zero_(t[:n])
         assert int(t[:n].max()) == 0 and int(t[n:].min()) == 7, n
+
+
+def test_syncbn_single_exchange_kernels():
+    """cris_bn_sync_pack / _unpack: two 'ranks' (row halves) exchange [S1 | S2] about a shared reference in ONE summation
+    (the all-reduce, done here by adding the two packed vectors) and recover the statistics of the concatenated batch."""
+    M, C_ = 1000, 40
+    y = (rnd(M, C_) * 1.7 + 2.5).to(BF).float()
+    ref = (y.mean(0) + 0.3 * rnd(C_, seed=9)).to(DEV)            # a running mean that lags the batch mean
+    packed = []
+    for half in (y[:400], y[400:]):
+        n = half.shape[0]
+        st = ops.colstats(bf(half), n, C_, 32, DEV)
+        merged, mean_l = torch.zeros(2 * C_, device=DEV), torch.empty(C_, device=DEV)
+        ops.bn_finalize(st, n, n, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, None, None,
+                        mean_l, None, merged=merged)
+        ops.bn_sync_pack(merged, mean_l, ref, n, C_)
+        packed.append(merged)
+    g = packed[0] + packed[1]                                     # the all-reduce
+    ops.bn_sync_unpack(g, ref, M, C_)
+    outs = [torch.empty(C_, device=DEV) for _ in range(4)]
+    ops.bn_finalize(None, 400, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs,
+                    global_stats=g)
+    check(outs[2], y.double().mean(0), 1e-6, "global mean")
+    check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), 1e-5, "global invstd")
