@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the Python schedule (no graph / command list)")
     ap.add_argument("--launch", default=None, choices=["graph", "cmdlist", "eager"], help="default: graph on 1 GPU, cmdlist on N > 1")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     ap.add_argument("--shape-table", default=None, help="write the per-shape GEMM timing table (tsv) here")
     args = ap.parse_args()
 
@@ -65,12 +66,16 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    local = local % torch.cuda.device_count()          # (ranks may share a GPU only with --backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
         from cris.pytorch_amd.dist import TorchDistComm
         comm = TorchDistComm(dev)
 
