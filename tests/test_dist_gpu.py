@@ -80,18 +80,20 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(launch):
     # dropout 0 for this comparison (mask indices are rank-local); everything else as in training.  The switch is an
     # environment variable so that the spawned ranks see it too.
     os.environ["CRIS_TEST_TINY_DROPOUT0"] = "1"
-    ref_losses, ref_probe, ref_rm = _single()
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, launch, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=600) for _ in procs)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    os.environ.pop("CRIS_TEST_TINY_DROPOUT0", None)
+    try:
+        ref_losses, ref_probe, ref_rm = _single()
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, launch, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        res = sorted(q.get(timeout=600) for _ in procs)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+    finally:
+        os.environ.pop("CRIS_TEST_TINY_DROPOUT0", None)
     (_, l0, p0, rm0, m0), (_, l1, p1, rm1, m1) = res
     assert m0 == launch and m1 == launch
     print("rank losses", l0, l1, "single", ref_losses)
