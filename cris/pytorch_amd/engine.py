@@ -197,11 +197,14 @@ class Engine:
 
     def _add_pack(self, name, N, Cin, taps, Cpad=None, want_D=True, transposed=False):
         src = self.P[name]
-        f, d = self.packs.add(src, N, Cin, taps, Cpad=Cpad, want_D=want_D, src_transposed=transposed)
+        f, d = self.packs[self.stage_of(name)].add(src, N, Cin, taps, Cpad=Cpad, want_D=want_D, src_transposed=transposed)
         self.WF[name], self.WD[name] = f, d
 
     def _build_packs(self):
-        self.packs = ops.PackTable()
+        # one pack table per arena stage: the trainer re-packs a stage right behind that stage's optimizer update, on the
+        # optimizer stream, underneath the rest of backward (packs_current); a forward that finds them stale re-packs all
+        self.packs = {st: ops.PackTable() for st in range(8)}
+        self.packs_current = False
         self.WF, self.WD = {}, {}
         for name, p in self.P.items():
             if p.dim() == 4:
@@ -211,11 +214,16 @@ class Engine:
                 self._add_pack(name, p.shape[1], p.shape[0], 1, transposed=True)      # used as x @ P
             elif p.dim() == 2 and name.endswith(("weight", "in_proj_weight")) and "embedding" not in name:
                 self._add_pack(name, p.shape[0], p.shape[1], 1)
-        self.packs.finalize(self.dev)
-        self._packed_version = None
+        for t in self.packs.values():
+            if t.descs:
+                t.finalize(self.dev)
 
     def repack_weights(self):
-        self.packs.run()
+        for t in self.packs.values():
+            t.run()
+
+    def repack_stage(self, st):
+        self.packs[st].run()
 
     def table(self, key, fn):
         if key not in self._tables:
@@ -838,7 +846,8 @@ class Engine:
         self._zero_slab_begin()
         if training:
             ops.zero_(self.grad_arena)
-        self.repack_weights()
+        if not self.packs_current:
+            self.repack_weights()
         word = word.contiguous()
         main = torch.cuda.current_stream()
         self._text_tape_start = 0

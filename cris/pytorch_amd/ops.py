@@ -583,12 +583,19 @@ def memset_f32(t, v=0.0):
 class AdamTable:
     """Device table of {p, g, m, v, n, lr}: one launch = torch.optim.Adam.step() over every tensor."""
 
-    def __init__(self, params, grads, lrs, layouts=None):
-        """layouts[i]: None (gradient in the parameter layout) or (N, Cin, taps, Cpad) (GEMM layout, see cris_conv_wgrad)"""
+    def __init__(self, params, grads, lrs, layouts=None, share_state_of=None, names=None):
+        """layouts[i]: None (gradient in the parameter layout) or (N, Cin, taps, Cpad) (GEMM layout, see cris_conv_wgrad).
+        share_state_of / names=(all_names, my_names): a table over a SUBSET of another table's tensors that uses that
+        table's m / v buffers (per-stage optimizer tables of trainer.py)."""
         lib = hip.load()
         be = lib.cris_adam_block_elems()
-        self.m = [torch.zeros_like(p) for p in params]
-        self.v = [torch.zeros_like(p) for p in params]
+        if share_state_of is not None:
+            idx = {n: i for i, n in enumerate(names[0])}
+            self.m = [share_state_of.m[idx[n]] for n in names[1]]
+            self.v = [share_state_of.v[idx[n]] for n in names[1]]
+        else:
+            self.m = [torch.zeros_like(p) for p in params]
+            self.v = [torch.zeros_like(p) for p in params]
         self.params, self.grads, self.lrs = list(params), list(grads), list(lrs)
         n = len(self.params)
         self.arr = (hip.AdamDesc * n)()

@@ -50,8 +50,11 @@ class NativeTrainer:
         self.names = names
         self.group = {n: (0 if (n.startswith("backbone") and "positional_embedding" not in n) else 1) for n in names}
         self.base_lr, self.lr_multi, self.weight_decay = base_lr, lr_multi, weight_decay
-        self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [base_lr] * len(names),
-                                  layouts=[e.gemm_layout(n) for n in names])
+        self._build_adam([base_lr] * len(names))
+        # single GPU: the optimizer update and the weight re-pack of an arena stage run on their own stream as soon as
+        # backward has finished that stage's gradients (projector, decoder, neck, text, layer groups 4..1), underneath the
+        # rest of backward; with N > 1 the gradients are only final after the exchange, so Adam stays at the end
+        self.ostream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self.metric = torch.zeros(2, device=device)
         # per-step device state: steps done (int32) and the dropout seed of the running step
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
@@ -75,12 +78,27 @@ class NativeTrainer:
         self._eager_steps = 0
         self.graph_error = None
 
+    def _build_adam(self, lrs):
+        e, names = self.engine, self.names
+        lr_of = dict(zip(names, lrs))
+        self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [lr_of[n] for n in names],
+                                  layouts=[e.gemm_layout(n) for n in names])
+        self.adam_stage = {}
+        for st in range(8):
+            sn = [n for n in names if e.stage_of(n) == st]
+            if sn:
+                self.adam_stage[st] = ops.AdamTable([e.P[n] for n in sn], [e.G[n] for n in sn], [lr_of[n] for n in sn],
+                                                    layouts=[e.gemm_layout(n) for n in sn], share_state_of=self.adam, names=(names, sn))
+
     @property
     def step_idx(self):
         return int(self.step_dev.item())
 
     def set_group_lrs(self, lr_backbone, lr_head):
-        self.adam.set_lrs([lr_backbone if self.group[n] == 0 else lr_head for n in self.names])
+        lrs = [lr_backbone if self.group[n] == 0 else lr_head for n in self.names]
+        self.adam.set_lrs(lrs)
+        for st, tab in self.adam_stage.items():
+            tab.set_lrs([lr for n, lr in zip(self.names, lrs) if self.engine.stage_of(n) == st])
         self._graph = self._cmds = None          # learning rates live in the device table, which was re-uploaded (new
         self._eager_steps = 0                    # address): capture / record again
 
@@ -100,9 +118,23 @@ class NativeTrainer:
                 ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))
             e.backward(on_stage_done=on_stage)
             ops.torch_op(self.comm.wait_all)
-        else:
+            self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
+            e.packs_current = False
+        elif self.ostream is None:
             e.backward()
-        self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
+            self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0, step_dev=self.step_dev)
+            e.packs_current = False
+        else:
+            def on_stage(st):
+                cur = torch.cuda.current_stream()
+                ops.torch_op(lambda: self.ostream.wait_stream(cur))
+                with torch.cuda.stream(self.ostream):
+                    self.adam_stage[st].step(weight_decay=self.weight_decay, grad_scale=1.0, step_dev=self.step_dev)
+                    e.repack_stage(st)
+            e.backward(on_stage_done=on_stage)
+            main = torch.cuda.current_stream()
+            ops.torch_op(lambda: main.wait_stream(self.ostream))
+            e.packs_current = True
         ops.zero_(self.metric)
         ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         return loss, pred, msk
