@@ -51,10 +51,12 @@ class NativeTrainer:
         self.group = {n: (0 if (n.startswith("backbone") and "positional_embedding" not in n) else 1) for n in names}
         self.base_lr, self.lr_multi, self.weight_decay = base_lr, lr_multi, weight_decay
         self._build_adam([base_lr] * len(names))
-        # single GPU: the optimizer update and the weight re-pack of an arena stage run on their own stream as soon as
-        # backward has finished that stage's gradients (projector, decoder, neck, text, layer groups 4..1), underneath the
-        # rest of backward; with N > 1 the gradients are only final after the exchange, so Adam stays at the end
-        self.ostream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        # Optional (CRIS_STAGED_ADAM=1, single GPU): the optimizer update and the weight re-pack of an arena stage run on their
+        # own stream as soon as backward has finished that stage's gradients, underneath the rest of backward.  Implemented
+        # and trajectory-tested, but MEASURED SLOWER (18.8 -> 21.9 ms/step: the HBM-bound update kernels take bandwidth and
+        # cache from the GEMMs they overlap with), so the default keeps one Adam + one re-pack launch at the step boundary.
+        staged = os.environ.get("CRIS_STAGED_ADAM", "0") == "1" and torch.device(device).type == "cuda"
+        self.ostream = torch.cuda.Stream(device=device) if staged else None
         self.metric = torch.zeros(2, device=device)
         # per-step device state: steps done (int32) and the dropout seed of the running step
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
