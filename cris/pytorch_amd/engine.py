@@ -4,7 +4,7 @@
 buffers, in which order - and a reverse tape for the backward pass.  It does no arithmetic itself: torch
 provides device buffers and the current stream, every FLOP is in csrc/.  Layout: activations NHWC bf16
 ([B*H*W, C] row-major; channel slices of wider buffers replace torch.cat), transformer residual streams
-fp32, parameters fp32 (bf16 GEMM-layout copies are re-packed once per step by one batched launch).
+fp32, parameters fp32 (bf16 GEMM-layout copies are re-packed once per step by batched launches, one per arena stage).
 
 Reference call graph being restated (file:line in DerrickWang005/CRIS.pytorch):
   CRIS.forward model/segmenter.py:29-62 -> ModifiedResNet.forward model/clip.py:207-223 (Bottleneck :44-57,
