@@ -5,7 +5,7 @@ weight_decay from the yaml) over two parameter groups built by the `build_segmen
 (model/__init__.py:36-48); bf16 needs no loss scaling so there is no GradScaler; the train metric
 (utils/misc.py:114-129) is computed on the device without a host sync.
 
-Launch model: the step is a static schedule of ~1400 kernel launches.  After one eager step (which fills the host-side
+Launch model: the step is a static schedule of ~1000 kernel launches.  After one eager step (which fills the host-side
 caches and the allocator) the whole step - forward, backward, gradient exchange, Adam, metric - is captured ONCE into a
 HIP graph (torch.cuda.CUDAGraph over the launch stream; the independent text-encoder branch is captured on a second
 stream and so becomes a parallel branch of the graph) and replayed per step: one host call per step instead of one per
@@ -50,13 +50,13 @@ class NativeTrainer:
         self.names = names
         self.group = {n: (0 if (n.startswith("backbone") and "positional_embedding" not in n) else 1) for n in names}
         self.base_lr, self.lr_multi, self.weight_decay = base_lr, lr_multi, weight_decay
-        self._build_adam([base_lr] * len(names))
         # Optional (CRIS_STAGED_ADAM=1, single GPU): the optimizer update and the weight re-pack of an arena stage run on their
         # own stream as soon as backward has finished that stage's gradients, underneath the rest of backward.  Implemented
         # and trajectory-tested, but MEASURED SLOWER (18.8 -> 21.9 ms/step: the HBM-bound update kernels take bandwidth and
         # cache from the GEMMs they overlap with), so the default keeps one Adam + one re-pack launch at the step boundary.
         staged = os.environ.get("CRIS_STAGED_ADAM", "0") == "1" and torch.device(device).type == "cuda"
         self.ostream = torch.cuda.Stream(device=device) if staged else None
+        self._build_adam([base_lr] * len(names))
         self.metric = torch.zeros(2, device=device)
         # per-step device state: steps done (int32) and the dropout seed of the running step
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
@@ -86,7 +86,7 @@ class NativeTrainer:
         self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [lr_of[n] for n in names],
                                   layouts=[e.gemm_layout(n) for n in names])
         self.adam_stage = {}
-        for st in range(8):
+        for st in (range(8) if self.ostream is not None else ()):
             sn = [n for n in names if e.stage_of(n) == st]
             if sn:
                 self.adam_stage[st] = ops.AdamTable([e.P[n] for n in sn], [e.G[n] for n in sn], [lr_of[n] for n in sn],
