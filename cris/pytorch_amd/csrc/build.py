@@ -21,10 +21,29 @@ def _digest():
     return h.hexdigest()
 
 
+def _current(dig):
+    return os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig
+
+
 def build(force=False, verbose=False):
+    """Content-stamped (sha256 of sources + flags), so a snapshot with arbitrary mtimes does not rebuild.  Several ranks
+    of one node may call this at once (bench.py under torch.distributed.run): an flock serialises them, the first one
+    compiles, the others find the stamp current; the library is linked to a temporary name and renamed into place."""
     dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP) and open(STAMP).read() == dig:
+    if not force and _current(dig):
         return LIB
+    import fcntl
+    with open(os.path.join(HERE, ".build_lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _current(dig):
+                return LIB
+            return _compile(dig, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _compile(dig, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
     procs = []
@@ -41,10 +60,14 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode()))
         if verbose and out:
             print(out.decode())
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp = LIB + ".tmp.%d" % os.getpid()
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode())
+    if os.path.exists(STAMP):
+        os.remove(STAMP)
+    os.replace(tmp, LIB)
     with open(STAMP, "w") as f:
         f.write(dig)
     return LIB
