@@ -36,6 +36,17 @@ def split_state_dict(sd, device):
     return params, buffers
 
 
+def epoch_group_lrs(epoch, base_lr, lr_multi, milestones, gamma):
+    """(lr_backbone, lr_head) the reference trains epoch `epoch` (0-based) with - train.py:105-110,210.
+    Adam is built with lr=base_lr over groups that carry only `initial_lr`, so epoch 0 runs BOTH groups at base_lr;
+    `scheduler.step(epoch_log)` with an explicit epoch then switches MultiStepLR to its closed form on `initial_lr`
+    (= lr_multi*base_lr for the backbone group): lr_e = initial_lr * gamma ** #{m in milestones : m <= e} for e >= 1."""
+    if epoch <= 0:
+        return base_lr, base_lr
+    f = gamma ** sum(1 for m in milestones if m <= epoch)
+    return lr_multi * base_lr * f, base_lr * f
+
+
 class NativeTrainer:
     def __init__(self, clip: ClipSpec, head: HeadSpec, state_dict, device, base_lr=1e-4, lr_multi=0.1, weight_decay=0.0,
                  comm=None, sync_bn=False, use_graph: Optional[bool] = None, launch: Optional[str] = None):
@@ -103,6 +114,10 @@ class NativeTrainer:
             tab.set_lrs([lr for n, lr in zip(self.names, lrs) if self.engine.stage_of(n) == st])
         self._graph = self._cmds = None          # learning rates live in the device table, which was re-uploaded (new
         self._eager_steps = 0                    # address): capture / record again
+
+    def set_epoch(self, epoch, milestones=(35,), gamma=0.1):
+        """Learning rates of the reference schedule for `epoch` (0-based); call at every epoch boundary."""
+        self.set_group_lrs(*epoch_group_lrs(epoch, self.base_lr, self.lr_multi, milestones, gamma))
 
     # ------------------------------------------------------------------------------------------------
     def _step_body(self, img, word, mask, host_seed: Optional[int]):
