@@ -475,6 +475,133 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_pa
     }
 }
 
+// Specialised reduce for the launches without a forward multiplier (all but one BatchNorm of the network).  Same block /
+// thread mapping and the same fixed-order LDS combine as the generic kernel above, but (a) the per-channel constants are
+// loaded ONCE per thread instead of once per row, (b) the configuration flags are template parameters, so the row loop is
+// one basic block, and (c) U rows are in flight per thread: all of their 16-byte loads are issued before the first use
+// (rows past the block's range re-read its last row with weight 0 - an unconditional load, not a branch).
+//   MASK 0: no ReLU; 1: ReLU mask from the stored forward output z; 2: ReLU mask recomputed from scale*y + shift.
+template <int MASK, bool Y2, bool POOL>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_bwd_params p, int rows_per_block) {
+    constexpr int U = Y2 ? 2 : 4;
+    __shared__ float spart[3][256 * 8];
+    const int CV = p.C >> 3;
+    const int M = p.Bn * p.H * p.W;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    const int HW = p.H * p.W, W2 = p.W >> 1, HW2 = (p.H >> 1) * W2;
+    const float gscale = POOL ? 0.25f : 1.f;
+    for (int cvb = 0; cvb < CV; cvb += 256) {
+        const int cvn = min(256, CV - cvb);
+        const int RS = 256 / cvn;
+        const int cvl = (int)threadIdx.x % cvn;
+        const int c0 = (cvb + cvl) * 8;
+        const int rsub = threadIdx.x / cvn;
+        float a0[8], a1[8], a3[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a0[j] = a1[j] = a3[j] = 0.f;
+        if (rsub < RS) {
+            float mean[8], inv[8], sc[8], sh[8], mean2[8], inv2[8];
+            load8f(p.mean + c0, mean);
+            load8f(p.invstd + c0, inv);
+            if (MASK == 2) {
+                load8f(p.scale + c0, sc);
+                load8f(p.shift + c0, sh);
+            }
+            if (Y2) {
+                load8f(p.mean2 + c0, mean2);
+                load8f(p.invstd2 + c0, inv2);
+            }
+            const bf16_t* yb = p.y + p.y_coff + c0;
+            const bf16_t* dzb = p.dz + p.dz_coff + c0;
+            const bf16_t* zb = MASK == 1 ? p.z + p.z_coff + c0 : nullptr;
+            const bf16_t* y2b = Y2 ? p.y2 + p.y2_coff + c0 : nullptr;
+            for (int m = r0 + rsub; m < r1; m += RS * U) {
+                uint4 ry[U], rdz[U], rz[U], ry2[U];
+                float wgt[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int mu = m + u * RS;
+                    wgt[u] = mu < r1 ? gscale : 0.f;
+                    const int mc = min(mu, r1 - 1);
+                    int mo = mc;
+                    if (POOL) {
+                        const int b = mc / HW;
+                        const int r = mc - b * HW;
+                        const int h = r / p.W, w = r - h * p.W;
+                        mo = b * HW2 + (h >> 1) * W2 + (w >> 1);
+                    }
+                    ry[u] = *reinterpret_cast<const uint4*>(yb + (size_t)mc * p.ldy);
+                    rdz[u] = *reinterpret_cast<const uint4*>(dzb + (size_t)mo * p.lddz);
+                    if (MASK == 1) rz[u] = *reinterpret_cast<const uint4*>(zb + (size_t)mc * p.ldz);
+                    if (Y2) ry2[u] = *reinterpret_cast<const uint4*>(y2b + (size_t)mc * p.ldy2);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    float y[8], dz[8], z[8], y2[8];
+                    unpack8(ry[u], y);
+                    unpack8(rdz[u], dz);
+                    if (MASK == 1) unpack8(rz[u], z);
+                    if (Y2) unpack8(ry2[u], y2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        bool pos = true;
+                        if (MASK == 1) pos = z[j] > 0.f;
+                        if (MASK == 2) pos = (y[j] * sc[j] + sh[j]) > 0.f;
+                        const float g = pos ? dz[j] * wgt[u] : 0.f;
+                        a0[j] += g;
+                        a1[j] += g * ((y[j] - mean[j]) * inv[j]);
+                        if (Y2) a3[j] += g * ((y2[j] - mean2[j]) * inv2[j]);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (rsub < RS) {
+            const int base = (rsub * cvn + cvl) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                spart[0][base + j] = a0[j];
+                spart[1][base + j] = a1[j];
+                spart[2][base + j] = a3[j];
+            }
+        }
+        __syncthreads();
+        const int ncol = cvn * 8;
+        for (int c = threadIdx.x; c < ncol; c += 256) {
+            float s0 = 0.f, s1 = 0.f, s3 = 0.f;
+            for (int r = 0; r < RS; ++r) {
+                s0 += spart[0][r * ncol + c];
+                s1 += spart[1][r * ncol + c];
+                if (Y2) s3 += spart[2][r * ncol + c];
+            }
+            const int col = cvb * 8 + c;
+            atomicAdd(p.sums + col, s0);
+            atomicAdd(p.sums + p.C + col, s1);
+            if (Y2) {
+                atomicAdd(p.sums + 2 * p.C + col, s0);
+                atomicAdd(p.sums + 3 * p.C + col, s3);
+            }
+        }
+    }
+}
+
+typedef void (*bn_bwd_reduce_fn)(const cris_bn_bwd_params, int);
+// [MASK][Y2][POOL]; combinations the path never produces stay on the generic kernel
+static bn_bwd_reduce_fn bn_bwd_reduce_fast_table(int mask, bool y2, bool pool) {
+    if (pool) {
+        if (y2 || mask == 1) return nullptr;
+        return mask == 2 ? bn_bwd_reduce_fast_kernel<2, false, true> : bn_bwd_reduce_fast_kernel<0, false, true>;
+    }
+    if (y2) {
+        if (mask == 2) return nullptr;
+        return mask == 1 ? bn_bwd_reduce_fast_kernel<1, true, false> : bn_bwd_reduce_fast_kernel<0, true, false>;
+    }
+    if (mask == 1) return bn_bwd_reduce_fast_kernel<1, false, false>;
+    if (mask == 2) return bn_bwd_reduce_fast_kernel<2, false, false>;
+    return bn_bwd_reduce_fast_kernel<0, false, false>;
+}
+
 extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     const cris_bn_bwd_params& p = *pp;
     CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums, "null operand");
@@ -489,6 +616,18 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     int rpb = cris_cdiv(M, blocks);
     if (rpb < min_rows) rpb = min_rows;
     blocks = cris_cdiv(M, rpb);
+    static const int use_fast = cris_env_int("CRIS_BN_RED_FAST", 1);
+    bn_bwd_reduce_fn fast = nullptr;
+    if (use_fast && !p.mul && (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && (p.lddz & 7) == 0 && (p.dz_coff & 7) == 0 &&
+        (!p.y2 || ((p.ldy2 & 7) == 0 && (p.y2_coff & 7) == 0 && p.z))) {
+        const int mask = !p.relu ? 0 : (!p.pool && (p.y2 || p.z)) ? 1 : 2;
+        if (mask != 1 || ((p.ldz & 7) == 0 && (p.z_coff & 7) == 0)) fast = bn_bwd_reduce_fast_table(mask, p.y2 != nullptr, p.pool != 0);
+    }
+    if (fast) {
+        hipLaunchKernelGGL(fast, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, rpb);
+        CRIS_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, rpb);
     CRIS_LAUNCH_CHECK();
     return 0;
