@@ -41,9 +41,20 @@ def cpu_baseline(spec, batch, size, word_len, threads):
     _, _, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=1)
     loss.backward()
     dt = time.time() - t0
+    # BASELINE.json configs[0] beside it: eval forward of ONE image + expression, a few timed iterations
+    img1, word1 = img[:1].contiguous(), word[:1].contiguous()
+    with torch.no_grad():
+        for _ in range(2):
+            O.cris_forward(sd, clip, head, img1, word1, None, training=False)
+        t1 = time.time()
+        n_eval = 5
+        for _ in range(n_eval):
+            O.cris_forward(sd, clip, head, img1, word1, None, training=False)
+        eval_ms = 1000.0 * (time.time() - t1) / n_eval
     return {"value": batch / dt, "unit": "samples/s", "cores": threads, "kind": "port",
             "sample": "1 train step (fwd+loss+bwd, fp32, no optimizer) of the CPU oracle at batch %d, %dx%d, L=%d: %.1f s"
-                      % (batch, size, size, word_len, dt)}
+                      % (batch, size, size, word_len, dt),
+            "eval_forward_bs1_ms": eval_ms}
 
 
 def main():
