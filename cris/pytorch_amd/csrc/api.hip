@@ -27,6 +27,7 @@ extern "C" int cris_sizeof(const char* name) {
     S(cris_ln_bwd_params);
     S(cris_attn_params);
     S(cris_adam_desc);
+    S(cris_p2p_params);
 #undef S
     return -1;
 }

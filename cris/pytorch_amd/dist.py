@@ -12,8 +12,61 @@ over xGMI), mirroring the reference's DDP + SyncBatchNorm semantics (train.py:80
     messages of 24-254 MB, not DDP's 25 MB buckets); Adam applies the 1/world averaging through its grad_scale.
 The path shards by sample only; there is no other data-path collective.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+
+class PeerMailboxes:
+    """EXPERIMENTAL (CRIS_SYNCBN_P2P=1): the SyncBN exchange as one kernel over peer-mapped mailboxes instead of an RCCL
+    collective per BatchNorm layer (csrc/p2p.hip, include/cris_hip.h cris_p2p_*).  Every rank allocates a fine-grained
+    mailbox, the 64-byte IPC handles travel once through torch.distributed, every rank maps every peer's mailbox."""
+
+    def __init__(self, rank, world, device, slots, max_floats):
+        from . import hip
+        self.hip, self.lib = hip, hip.load()
+        self.rank, self.world, self.slots, self.max_floats = rank, world, slots, max_floats
+        nbytes = self.lib.cris_p2p_mailbox_bytes(world, slots, max_floats)
+        own = ctypes.c_void_p()
+        hip.check(self.lib.cris_p2p_alloc(nbytes, ctypes.byref(own)), "cris_p2p_alloc")
+        self.own = own.value
+        handle = (ctypes.c_ubyte * 64)()
+        hip.check(self.lib.cris_p2p_export(self.own, handle), "cris_p2p_export")
+        handles = [None] * world
+        dist.all_gather_object(handles, bytes(handle))
+        self.peers, ptrs = [], []
+        for q, h in enumerate(handles):
+            if q == rank:
+                ptrs.append(self.own)
+                continue
+            peer = ctypes.c_void_p()
+            buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
+            hip.check(self.lib.cris_p2p_import(buf, ctypes.byref(peer)), "cris_p2p_import")
+            self.peers.append(peer.value)
+            ptrs.append(peer.value)
+        self.boxes = torch.tensor(ptrs, dtype=torch.int64, device=device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=device)
+        dist.barrier()                              # nobody writes into a mailbox that is not mapped yet
+
+    def allreduce_sum(self, t, slot, gen_dev=None, gen_host=0):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= self.max_floats and slot < self.slots
+        prm = self.hip.P2PParams()
+        prm.data, prm.boxes, prm.err = t.data_ptr(), self.boxes.data_ptr(), self.err.data_ptr()
+        prm.gen_dev = None if gen_dev is None else gen_dev.data_ptr()
+        prm.n, prm.rank, prm.world = t.numel(), self.rank, self.world
+        prm.slot, prm.slots, prm.max_floats, prm.gen_host = slot, self.slots, self.max_floats, gen_host
+        # not through hip.call: the caller (ops.torch_op) already puts this exchange on a command list being recorded
+        self.hip.check(self.lib.cris_p2p_allreduce_sum(ctypes.byref(prm), torch.cuda.current_stream().cuda_stream),
+                       "cris_p2p_allreduce_sum")
+
+    def close(self):
+        for p in self.peers:
+            self.lib.cris_p2p_close(p)
+        self.peers = []
+        if self.own:
+            self.lib.cris_p2p_free(self.own)
+            self.own = None
 
 
 class TorchDistComm:
@@ -28,6 +81,22 @@ class TorchDistComm:
         # the default group the tiny SyncBN all-reduces of the layers still in backward would queue behind 100+ MB
         # gradient messages and stall the compute stream
         self.grad_group = dist.new_group(ranks=list(range(self.world)))
+        self.p2p, self._gen_dev, self._slot = None, None, 0
+
+    def enable_p2p(self, slots, max_floats, gen_dev):
+        """Route allreduce_sum (the SyncBN exchanges) through peer mailboxes; `gen_dev` = the trainer's device step counter."""
+        self.p2p = PeerMailboxes(self.rank, self.world, self.device, slots, max_floats)
+        self._gen_dev = gen_dev
+
+    def begin_step(self):
+        self._slot = 0
+
+    def allreduce_sum_op(self, t):
+        if self.p2p is None:
+            return lambda: self.allreduce_sum(t)
+        slot = self._slot                            # exchange number inside the step, fixed at schedule time
+        self._slot += 1
+        return lambda: self.p2p.allreduce_sum(t, slot, gen_dev=self._gen_dev)
 
     # SyncBN exchanges run inline on the compute stream (they sit on the critical path by construction)
     def allreduce_sum(self, t):

@@ -73,6 +73,13 @@ class Comm:
     def allreduce_sum(self, t):  # pragma: no cover - single GPU default
         return
 
+    def begin_step(self):
+        """Called once per scheduled training step before the first exchange (exchange numbering restarts)."""
+
+    def allreduce_sum_op(self, t):
+        """The exchange of `t` as a callable bound NOW (schedule time) - what ops.torch_op runs and a command list replays."""
+        return lambda: self.allreduce_sum(t)
+
 
 class Engine:
     def __init__(self, clip: ClipSpec, head: HeadSpec, params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor],
@@ -374,7 +381,7 @@ class Engine:
             merged = self.zeros(2 * C)
             ops.bn_finalize(st, count, count, gamma, beta, None, None, BN_MOM, BN_EPS, C, None, None, mean, None, merged=merged)
             ops.bn_sync_pack(merged, mean, rm, count, C)
-            ops.torch_op(lambda: self.comm.allreduce_sum(merged))
+            ops.torch_op(self.comm.allreduce_sum_op(merged))
             ops.bn_sync_unpack(merged, rm, gcount, C)
             ops.bn_finalize(None, count, gcount, gamma, beta, rm, rv, BN_MOM, BN_EPS, C, scale, shift, mean, invstd,
                             global_stats=merged)
@@ -431,7 +438,7 @@ class Engine:
 
             def between(s):
                 ops.axpy_f32(arena_block, s, 1.0)
-                ops.torch_op(lambda: self.comm.allreduce_sum(s))
+                ops.torch_op(self.comm.allreduce_sum_op(s))
 
             need_z = relu and not pool and (ident is not None or y2 is not None)
             ops.bn_bwd(out.g, y.t, scale, shift, mean, invstd, sums, dy, y.Bn, y.H, y.W, C, gcount, lddz=out.ld, dz_coff=out.coff,
@@ -845,6 +852,7 @@ class Engine:
         Act._engine = self
         self._zero_slab_begin()
         if training:
+            self.comm.begin_step()
             ops.zero_(self.grad_arena)
         if not self.packs_current:
             self.repack_weights()

@@ -138,10 +138,19 @@ class AdamDesc(C.Structure):
                 ("cin", I), ("cpad", I)]
 
 
+class P2PParams(C.Structure):
+    _fields_ = [("data", P), ("boxes", P), ("gen_dev", P), ("err", P),
+                ("n", I), ("rank", I), ("world", I),
+                ("slot", I), ("slots", I),
+                ("max_floats", I),
+                ("gen_host", I),
+                ("pad_", I)]
+
+
 STRUCTS = {
     "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_pack_desc": PackDesc,
     "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
-    "cris_ln_bwd_params": LnBwdParams, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc,
+    "cris_ln_bwd_params": LnBwdParams, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams,
 }
 
 # name -> (restype, argtypes); struct launchers take (struct*, stream)
@@ -206,6 +215,13 @@ _SIGS = {
     "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, P]),
     "cris_adam_block_elems": (I, []),
     "cris_unpack_grads": (I, [P, I, I, P]),
+    "cris_p2p_mailbox_bytes": (C.c_size_t, [I, I, I]),
+    "cris_p2p_alloc": (I, [C.c_size_t, P]),
+    "cris_p2p_free": (I, [P]),
+    "cris_p2p_export": (I, [P, P]),
+    "cris_p2p_import": (I, [P, P]),
+    "cris_p2p_close": (I, [P]),
+    "cris_p2p_allreduce_sum": (I, [P, P]),
 }
 EXPORTS = sorted(_SIGS)
 

@@ -339,6 +339,30 @@ int cris_adam_block_elems(void);
 /* dst (param layout, desc.p) <- src (GEMM layout, desc.g) for a table of tensors; block_start as for cris_adam_step */
 int cris_unpack_grads(const cris_adam_desc* dev_table, int n_desc, int total_blocks, void* stream);
 
+/* ---- Low-latency cross-rank sum of small fp32 vectors (EXPERIMENTAL, CRIS_SYNCBN_P2P=1) -------------------------------
+ * Replaces the per-layer all_gather / all_reduce of nn.SyncBatchNorm (train.py:97-98; 142 small collectives per CRIS-R50
+ * step) by ONE kernel per exchange: every rank owns a fine-grained device mailbox that all peers map through HIP IPC; the
+ * kernel writes this rank's vector into every mailbox, publishes a generation flag, waits for the peers' flags and adds
+ * the world vectors in rank order (bit-identical on all ranks).  Mailbox layout in csrc/p2p.hip. */
+size_t cris_p2p_mailbox_bytes(int world, int slots, int max_floats);
+int cris_p2p_alloc(size_t bytes, void** dev_ptr);                     /* fine-grained device memory, zero-filled */
+int cris_p2p_free(void* dev_ptr);
+int cris_p2p_export(void* dev_ptr, void* handle_64_bytes);            /* IPC handle of a mailbox (64 bytes) */
+int cris_p2p_import(const void* handle_64_bytes, void** peer_ptr);    /* map another process's mailbox */
+int cris_p2p_close(void* peer_ptr);
+typedef struct {
+    float* data;              /* [n] in: this rank's vector; out: the sum over ranks */
+    void* const* boxes;       /* DEVICE array [world]: every rank's mailbox as mapped in this process (own one at [rank]) */
+    const int* gen_dev;       /* device step counter (graph / command-list replay) or NULL -> gen_host */
+    int* err;                 /* device int set to 1 if a peer never arrived (the output is then NaN); or NULL */
+    int n, rank, world;
+    int slot, slots;          /* which exchange of the step this is; exchanges per step the mailbox was sized for */
+    int max_floats;           /* vector capacity the mailbox was sized for */
+    int gen_host;
+    int pad_;
+} cris_p2p_params;
+int cris_p2p_allreduce_sum(const cris_p2p_params* p, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
