@@ -29,9 +29,13 @@ extern "C" size_t cris_p2p_mailbox_bytes(int world, int slots, int max_floats) {
 extern "C" int cris_p2p_alloc(size_t bytes, void** dev_ptr) {
     CRIS_CHECK_ARG(dev_ptr && bytes > 0, "bad arguments");
     void* p = nullptr;
-    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained);
+    // uncached (MTYPE_UC) by default - what RCCL uses for its own peer-visible buffers on gfx942 / gfx950; every access of
+    // the exchange kernel is a system-scope atomic anyway.  CRIS_P2P_MEM=0 selects plain fine-grained memory instead.
+    static const int mem_kind = cris_env_int("CRIS_P2P_MEM", 1);
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, mem_kind ? hipDeviceMallocUncached : hipDeviceMallocFinegrained);
     if (e != hipSuccess) {
-        cris_set_error("%s: hipExtMallocWithFlags(finegrained, %zu) failed: %s", __func__, bytes, hipGetErrorString(e));
+        cris_set_error("%s: hipExtMallocWithFlags(%s, %zu) failed: %s", __func__, mem_kind ? "uncached" : "finegrained", bytes,
+                       hipGetErrorString(e));
         return (int)e;
     }
     e = hipMemset(p, 0, bytes);
