@@ -17,6 +17,7 @@
 #include "../../../include/cris_hip.h"
 #include <string.h>
 
+#define P2P_MAXV 32                      // 256 threads x 32 = 8192 floats per exchange at most
 #define P2P_SPIN_LIMIT (1L << 25)      // several seconds of polling: a peer that never arrives raises an error instead of hanging the GPU
 
 static inline size_t p2p_data_floats(int world, int slots, int max_floats) { return (size_t)2 * slots * world * max_floats; }
@@ -97,19 +98,28 @@ extern "C" int cris_p2p_close(void* peer_ptr) {
 __device__ __forceinline__ void p2p_store_f32(float* p, float v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__device__ __forceinline__ float p2p_load_f32(const float* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
 
 __global__ __launch_bounds__(256) void p2p_allreduce_sum_kernel(const cris_p2p_params p) {
     const int gen = (p.gen_dev ? p.gen_dev[0] : p.gen_host) + 1;            // never 0 (the cleared mailbox)
     const int parity = gen & 1;
     const size_t data_floats = (size_t)2 * p.slots * p.world * p.max_floats;
     const size_t entry = ((size_t)parity * p.slots + p.slot) * p.world;      // [parity][slot][.]
-    // 1. my vector into every mailbox (own one included: the sum below then reads one place for all ranks)
+    // 1. my vector into every mailbox (own one included: the sum below then reads one place for all ranks).  The vector is
+    // read into registers first and the remote stores are issued back to back: on gfx9 stores count in vmcnt, so a
+    // load -> store loop would wait for every remote store to be acknowledged before the next element.
+    float v[P2P_MAXV];
+#pragma unroll
+    for (int k = 0; k < P2P_MAXV; ++k) {
+        const int i = threadIdx.x + k * 256;
+        v[k] = p.data[min(i, p.n - 1)];
+    }
     for (int q = 0; q < p.world; ++q) {
         float* dst = reinterpret_cast<float*>(p.boxes[q]) + (entry + p.rank) * p.max_floats;
-        for (int i = threadIdx.x; i < p.n; i += blockDim.x) p2p_store_f32(dst + i, p.data[i]);
+#pragma unroll
+        for (int k = 0; k < P2P_MAXV; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < p.n) p2p_store_f32(dst + i, v[k]);
+        }
     }
     __threadfence_system();                        // the data is visible system-wide before any flag is
     __syncthreads();
@@ -135,13 +145,17 @@ __global__ __launch_bounds__(256) void p2p_allreduce_sum_kernel(const cris_p2p_p
     }
     __syncthreads();
     __threadfence_system();
-    // 4. sum in rank order
+    // 4. sum in rank order.  Plain loads: every thread has executed the system-scope fence above (write-back + invalidate)
+    // after the acquire, and the mailbox is uncached memory, so they cannot hit stale lines of the previous generation.
     const float* mine = reinterpret_cast<const float*>(p.boxes[p.rank]) + entry * p.max_floats;
     const bool bad = s_bad != 0;
     if (bad && threadIdx.x == 0 && p.err) p.err[0] = 1;
-    for (int i = threadIdx.x; i < p.n; i += blockDim.x) {
+#pragma unroll 4
+    for (int k = 0; k < P2P_MAXV; ++k) {
+        const int i = threadIdx.x + k * 256;
+        if (i >= p.n) break;
         float s = 0.f;
-        for (int q = 0; q < p.world; ++q) s += p2p_load_f32(mine + (size_t)q * p.max_floats + i);
+        for (int q = 0; q < p.world; ++q) s += mine[(size_t)q * p.max_floats + i];
         p.data[i] = bad ? __int_as_float(0x7fc00000) : s;                   // a missing peer must not pass silently
     }
 }
@@ -151,6 +165,7 @@ extern "C" int cris_p2p_allreduce_sum(const cris_p2p_params* pp, void* stream) {
     CRIS_CHECK_ARG(p.data && p.boxes, "null operand");
     CRIS_CHECK_ARG(p.world >= 1 && p.world <= 64 && p.rank >= 0 && p.rank < p.world, "rank / world");
     CRIS_CHECK_ARG(p.n > 0 && p.n <= p.max_floats && p.slot >= 0 && p.slot < p.slots, "n / slot out of the mailbox geometry");
+    CRIS_CHECK_ARG(p.n <= 256 * P2P_MAXV, "at most 8192 floats per exchange");
     hipLaunchKernelGGL(p2p_allreduce_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return 0;
