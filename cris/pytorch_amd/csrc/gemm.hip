@@ -968,8 +968,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const cris_wgrad_par
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;               // LDS byte address of the ring
     const bool do_bias = p.dbias != nullptr && bx == 0;
-    float bsum = 0.f;                              // column (t & 127) of dY, rows of half (t >> 7) of every step
-    const int bn_ = t & 127, bhalf = t >> 7;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // columns 8*bcg .. +7 of dY over this thread's rows
+    const int bcg = (t & 15) ^ ((((t >> 4) & 7) << 1) & 15);
 
 #pragma unroll
     for (int s_ = 0; s_ < STAGES - 1; ++s_) issue_step(s_);
@@ -999,9 +999,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const cris_wgrad_par
             wg_slices<0, KSL>(acc, cur, ay, ax);
         }
         if (do_bias) {                              // block-uniform: only the blocks of the first k-tile
-            for (int r = bhalf * (MS / 2); r < (bhalf + 1) * (MS / 2); ++r) {
-                const int o = r * 256 + ((((bn_ >> 3) ^ ((r & 7) << 1)) & 15) << 4) + (bn_ & 7) * 2;
-                bsum += bf2f(*reinterpret_cast<const bf16_t*>(sy + o));
+            // thread t owns LDS slot t&15 of rows (t>>4) + 16j: row & 7 is the same for all of them, so the slot always holds
+            // the same global 8-column chunk (bcg) - MS/16 16-byte reads per step instead of one 2-byte read per row
+#pragma unroll
+            for (int j = 0; j < MS / 16; ++j) {
+                float f[8];
+                unpack8(*reinterpret_cast<const uint4*>(sy + ((t >> 4) + 16 * j) * 256 + (t & 15) * 16), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += f[e];
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -1009,12 +1014,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const cris_wgrad_par
     }
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before LDS is reused / the block retires
 
-    if (do_bias) {
+    if (do_bias) {                                   // block-wide column sums: [16 row groups][128 n] through LDS
         __syncthreads();
         float* red = reinterpret_cast<float*>(smem);
-        red[t] = bsum;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(t >> 4) * 128 + bcg * 8 + e] = bsum[e];
         __syncthreads();
-        if (t < 128 && n0 + t < p.N) atomicAdd(p.dbias + n0 + t, red[t] + red[t + 128]);
+        if (t < 128 && n0 + t < p.N) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sacc += red[g * 128 + t];
+            atomicAdd(p.dbias + n0 + t, sacc);
+        }
     }
     const bool single = p.splits == 1;
 #pragma unroll

@@ -102,14 +102,19 @@ def test_wgrad_tr_fragments_reproduce_the_tile_product():
     assert np.array_equal(got, want)
 
 
-def test_wgrad_tr_bias_column_addresses():
-    """The bias-gradient path reads column n of the dY image directly: same swizzle."""
+def test_wgrad_tr_bias_column_sums():
+    """The bias-gradient path: thread t reads the 16-byte LDS slot t&15 of rows (t>>4) + 16j and attributes it to the global
+    chunk (t&15) ^ (((t>>4)&7)<<1); 16 row groups are then added per column."""
     rng = np.random.default_rng(1)
     dY = rng.integers(-50, 50, size=(MS, 128)).astype(np.int64)
     img = fill_image(dY)
-    for n in (0, 7, 8, 63, 100, 127):
-        col = [img[(r * 256 + ((((n >> 3) ^ ((r & 7) << 1)) & 15) << 4) + (n & 7) * 2) // 2] for r in range(MS)]
-        assert col == list(dY[:, n])
+    red = np.zeros((16, 128), dtype=np.int64)
+    for t in range(256):
+        bcg = (t & 15) ^ ((((t >> 4) & 7) << 1) & 15)
+        for j in range(MS // 16):
+            a = (((t >> 4) + 16 * j) * 256 + (t & 15) * 16) // 2
+            red[t >> 4, bcg * 8: bcg * 8 + 8] += img[a: a + 8]
+    assert np.array_equal(red.sum(0), dY.sum(0))
 
 
 def test_wgrad_tr_pixel_stepping_is_division_free_and_exact():
