@@ -30,6 +30,8 @@ CASES = {
     "tiny_b2_s64": ("tiny", 2, 64),
     "tiny_b3_s96": ("tiny", 3, 96),
     "r50_b2_s160": ("r50", 2, 160),
+    "r101_b2_s96": ("r101", 2, 96),              # BASELINE.json configs[3] parameter tree (layer3 x23, embed_dim 512)
+    "tiny_b2_s96_l22": ("tiny", 2, 96, 22),      # configs[4]'s longer expressions (word_len 22), odd 3x3 / 6x6 / 12x12 maps
 }
 
 
@@ -39,8 +41,10 @@ def cfg_from(head, **over):
     return d
 
 
-def run_case(name, spec, batch, size):
+def run_case(name, spec, batch, size, word_len=None):
     clip, head = arch.specs_by_name(spec)
+    if word_len is not None:
+        head = dataclasses.replace(head, word_len=word_len)
     sd = arch.synthetic_state_dict(clip, head, seed=0)
     net = ref_harness.build_reference_cris(arch.clip_state_dict_view(sd), cfg_from(head, dropout=0.0))
     missing = net.load_state_dict(sd, strict=True)
@@ -120,7 +124,10 @@ def key_listing():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    key_listing()
-    tokenizer_vectors()
-    for name, (spec, b, s) in CASES.items():
-        run_case(name, spec, b, s)
+    if not sys.argv[1:]:
+        key_listing()
+        tokenizer_vectors()
+    only = sys.argv[1:]
+    for name, case in CASES.items():
+        if not only or name in only:
+            run_case(name, *case)

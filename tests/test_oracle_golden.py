@@ -18,11 +18,16 @@ from conftest import GOLDEN
 from cris.pytorch_amd import arch, synth
 from oracle import cris_oracle as O
 
-CASES = {"tiny_b2_s64": ("tiny", 2, 64), "tiny_b3_s96": ("tiny", 3, 96), "r50_b2_s160": ("r50", 2, 160)}
+CASES = {"tiny_b2_s64": ("tiny", 2, 64), "tiny_b3_s96": ("tiny", 3, 96), "r50_b2_s160": ("r50", 2, 160),
+         "r101_b2_s96": ("r101", 2, 96),                 # BASELINE.json configs[3] parameter tree
+         "tiny_b2_s96_l22": ("tiny", 2, 96, 22)}         # configs[4] expression length
 
 
-def _run_oracle(spec, batch, size):
+def _run_oracle(spec, batch, size, word_len=None):
+    import dataclasses
     clip, head = arch.specs_by_name(spec)
+    if word_len is not None:
+        head = dataclasses.replace(head, word_len=word_len)
     sd = arch.synthetic_state_dict(clip, head, 0)
     img, word, mask = synth.make_batch(batch, size, head.word_len, 0, 0)
     leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
@@ -36,12 +41,12 @@ def _run_oracle(spec, batch, size):
 
 @pytest.mark.parametrize("name", list(CASES))
 def test_oracle_matches_reference(name):
-    spec, b, s = CASES[name]
+    spec, b, s = CASES[name][:3]
     gtol = 2e-2 if spec == "tiny" else 5e-2     # see module docstring
-    if spec == "r50" and os.environ.get("CRIS_FAST_TESTS"):
+    if spec != "tiny" and os.environ.get("CRIS_FAST_TESTS"):
         pytest.skip("fast mode")
     g = np.load(os.path.join(GOLDEN, name + ".npz"))
-    leaf, pred, m, loss, ev, bnu = _run_oracle(spec, b, s)
+    leaf, pred, m, loss, ev, bnu = _run_oracle(*CASES[name])
     assert abs(loss.item() - float(g["loss"])) < 2e-4 * max(1.0, abs(float(g["loss"])))
     np.testing.assert_allclose(pred.detach().numpy(), g["train_pred"], rtol=2e-3, atol=3e-3)
     np.testing.assert_array_equal(m.numpy(), g["train_mask"])          # nearest resize: index op, bit exact
