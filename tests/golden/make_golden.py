@@ -110,6 +110,29 @@ def tokenizer_vectors():
     print("tokenizer vectors", len(out))
 
 
+def metric_vectors():
+    """Known answers of the reference's train metric (utils/misc.py:114-129 trainMetricGPU) on seeded logits / masks,
+    including logits exactly at the 0.35 threshold and empty masks (union 0 -> IoU 0 through the +1e-6)."""
+    ref_harness.import_reference()
+    from utils.misc import trainMetricGPU
+    out = {}
+    thr_logit = float(torch.log(torch.tensor(0.35 / 0.65)))
+    for i, (b, hw) in enumerate([(4, 26), (8, 104), (3, 13), (2, 8)]):
+        g = torch.Generator().manual_seed(500 + i)
+        pred = torch.randn(b, 1, hw, hw, generator=g) * 2.0
+        target = (torch.rand(b, 1, hw, hw, generator=g) > 0.6).float()
+        if i == 2:
+            target[0] = 0.0                                   # empty ground truth
+            pred[0] = -10.0                                   # and empty prediction: union 0
+        if i == 3:
+            pred[0, 0, 0, :4] = thr_logit                     # sigmoid == threshold up to rounding
+        iou, prec = trainMetricGPU(pred.clone(), target.clone())
+        out["iou_%d" % i] = np.array(float(iou), dtype=np.float64)
+        out["prec_%d" % i] = np.array(float(prec), dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "train_metric.npz"), **out)
+    print("train metric vectors", len(out) // 2)
+
+
 def key_listing():
     clip, head = arch.specs_by_name("r50")
     sd = arch.synthetic_state_dict(clip, head, seed=0)
@@ -127,6 +150,8 @@ if __name__ == "__main__":
     if not sys.argv[1:]:
         key_listing()
         tokenizer_vectors()
+    if not sys.argv[1:] or "train_metric" in sys.argv[1:]:
+        metric_vectors()
     only = sys.argv[1:]
     for name, case in CASES.items():
         if not only or name in only:

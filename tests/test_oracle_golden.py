@@ -93,3 +93,22 @@ def test_state_dict_keys_match_reference():
     tree = arch.build_param_tree(arch.CLIP_R50, arch.HEAD_R50)
     assert list(tree.state_dict().keys()) == ref
     assert sum(p.numel() for p in tree.parameters()) == 146849122
+
+
+def test_train_metric_matches_reference():
+    """oracle.train_metric vs the reference's trainMetricGPU (utils/misc.py:114-129) on the seeded cases of make_golden.py
+    (threshold 0.35 on the sigmoid, per-sample IoU with +1e-6, Pr@0.5, x100)."""
+    g = np.load(os.path.join(GOLDEN, "train_metric.npz"))
+    thr_logit = float(torch.log(torch.tensor(0.35 / 0.65)))
+    for i, (b, hw) in enumerate([(4, 26), (8, 104), (3, 13), (2, 8)]):
+        gen = torch.Generator().manual_seed(500 + i)
+        pred = torch.randn(b, 1, hw, hw, generator=gen) * 2.0
+        target = (torch.rand(b, 1, hw, hw, generator=gen) > 0.6).float()
+        if i == 2:
+            target[0] = 0.0
+            pred[0] = -10.0
+        if i == 3:
+            pred[0, 0, 0, :4] = thr_logit
+        iou, prec = O.train_metric(pred, target)
+        assert abs(float(iou) - float(g["iou_%d" % i])) < 1e-4, i
+        assert abs(float(prec) - float(g["prec_%d" % i])) < 1e-4, i
