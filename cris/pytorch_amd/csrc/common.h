@@ -13,6 +13,13 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16-byte raw 
 
 #define CRIS_WAVE 64
 
+// raw buffer access / LDS-DMA helpers shared by the GEMM-shaped kernels
+typedef __attribute__((address_space(3))) void lds_void_t;
+#define CRIS_BUF_FLAGS 0x00020000          // V# dword 3 for raw (stride 0) buffers on gfx9 / CDNA
+#define CRIS_OOB 0x80000000u               // byte offset beyond every descriptor used here (extents are < 2 GiB): reads as 0
+// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
+#define CRIS_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | ((((N) >> 4) & 3) << 14) | (0x7 << 4) | (0xF << 8))
+
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) {                // round to nearest even
     uint32_t u = __float_as_uint(f);

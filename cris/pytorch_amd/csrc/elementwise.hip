@@ -758,10 +758,16 @@ extern "C" int cris_train_metric(const float* logits, const float* target, int B
 #define ADAM_ELEMS 8192
 __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restrict__ tab, int n_desc, float beta1, float beta2, float eps,
                                                    float wd, float bc1, float bc2, float gscale, const int* __restrict__ step_dev) {
-    if (step_dev) {                       // step count lives on the device (HIP-graph replay): bias corrections from it
-        const float t = (float)step_dev[0];
-        bc1 = 1.f - __powf(beta1, t);
-        bc2 = 1.f - __powf(beta2, t);
+    if (step_dev) {                       // step count lives on the device (HIP-graph replay): bias corrections from it,
+        __shared__ float s_bc[2];         // in double precision like torch.optim.Adam's host arithmetic (1 - beta**t)
+        if (threadIdx.x == 0) {
+            const double t = (double)step_dev[0];
+            s_bc[0] = (float)(1.0 - pow((double)beta1, t));
+            s_bc[1] = (float)(1.0 - pow((double)beta2, t));
+        }
+        __syncthreads();
+        bc1 = s_bc[0];
+        bc2 = s_bc[1];
     }
     int lo = 0, hi = n_desc - 1;
     const int bid = blockIdx.x;

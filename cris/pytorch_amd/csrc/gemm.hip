@@ -20,11 +20,6 @@
 #define BK 64
 #define SKINNY_MAX_M 144      // M <= this and a 1x1 geometry -> skinny kernel (no LDS staging, K split over the waves)
 
-typedef __attribute__((address_space(3))) void lds_void_t;
-#define CRIS_BUF_FLAGS 0x00020000          // V# dword 3 for raw (stride 0) buffers on gfx9 / CDNA
-#define CRIS_OOB 0x80000000u               // byte offset beyond every descriptor used here (extents are < 2 GiB): reads as 0
-// s_waitcnt vmcnt(N) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14])
-#define CRIS_VMCNT(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | ((((N) >> 4) & 3) << 14) | (0x7 << 4) | (0xF << 8))
 
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad
@@ -577,504 +572,6 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
         default:
             hipLaunchKernelGGL(k_128x128[lean], dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128)), dim3(256), LDS_128x128, s, p);
     }
-    CRIS_LAUNCH_CHECK();
-    return 0;
-}
-
-// ------------------------------------------------------------------------------------------------
-// weight gradient
-// ------------------------------------------------------------------------------------------------
-#define WG_T 128          // output tile (n) x (k) and reduction step (m)
-
-__device__ __forceinline__ int wg_off(int row, int chunk) {      // rows are 256 B (128 bf16 of m)
-    return row * 256 + (((chunk ^ row) & 15) << 4);
-}
-
-// transpose an 8x8 block of bf16 held as 8 row vectors (uint4 = 8 bf16) into 8 column vectors
-__device__ __forceinline__ void transpose8x8(const uint4* r, uint4* o) {
-    const uint32_t* rw = reinterpret_cast<const uint32_t*>(r);       // rw[row*4 + word]
-    uint32_t* ow = reinterpret_cast<uint32_t*>(o);                    // ow[col*4 + word]
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int w = j >> 1;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t a = rw[(2 * q) * 4 + w], b = rw[(2 * q + 1) * 4 + w];
-            ow[j * 4 + q] = (j & 1) ? ((a >> 16) | (b & 0xffff0000u)) : ((a & 0xffffu) | (b << 16));
-        }
-    }
-}
-
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params p) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * WG_T * 256];
-    unsigned char* sy = smem;                  // dY^T tile [128 n][128 m]
-    unsigned char* sx = smem + WG_T * 256;     // X^T  tile [128 k][128 m]
-
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    // XCD-aware order over the flattened (k-tile fastest, n-tile, split) grid: the blocks one XCD runs are consecutive
-    // k-tiles of the same dY tile and pixel range, which then stays in that XCD's L2
-    int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    {
-        const int nblk = gridDim.x * gridDim.y * gridDim.z;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bx = bid % gridDim.x, by = (bid / gridDim.x) % gridDim.y, bz = bid / (gridDim.x * gridDim.y);
-    const int k0 = bx * WG_T;
-    const int n0 = by * WG_T;
-    int rows_per = (p.M + p.splits - 1) / p.splits;
-    rows_per = (rows_per + WG_T - 1) / WG_T * WG_T;
-    const int m_begin = bz * rows_per;
-    const int m_end = min(p.M, m_begin + rows_per);
-    if (m_begin >= m_end) return;
-
-    const int mg = (t & 7) + 8 * (t >> 7);     // 8-row group 0..15
-    const int vec = (t >> 3) & 15;             // 16-B vector 0..15 along n (dY) / k (X)
-    const int OHW = p.OH * p.OW;
-
-    const int yn = n0 + vec * 8;
-    const bool yvalid = yn < p.N_ld;
-    const int xk = k0 + vec * 8;
-    const bool xvalid = xk < p.K;
-    const int xtap = xvalid ? xk / p.C : 0;
-    const int xc = xvalid ? xk - xtap * p.C : 0;
-    const int xkh = xtap / p.KW, xkw = xtap - xkh * p.KW;
-
-    // bias gradient (column sums of dY) rides along in the blocks of the first k-tile
-    const bool do_bias = p.dbias != nullptr && bx == 0;
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    // Loads are raw buffer loads: an invalid element (row beyond this split, channel tail, spatial padding) is an
-    // out-of-range byte offset that the hardware returns as zeros - a branch-free select, so the 16 loads of a step are
-    // issued back to back and stay in flight underneath the MFMAs of the previous step (with per-element branches the
-    // compiler waits for them right after issue).
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dY), 0, (int)((size_t)p.M * p.ldy * 2),
-                                                                        CRIS_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.X), 0, (int)((size_t)p.Bn * p.H * p.W * p.ldx * 2), CRIS_BUF_FLAGS);
-    u32x4 ry[8], rx[8];
-    // (b, oh, ow) of this thread's first row, kept incrementally: no integer division inside the pixel loop (16 per step
-    // otherwise - the loop was bound by that arithmetic, not by MFMA or memory)
-    const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;      // pixel index == row index
-    int rb, roh, row_;
-    {
-        const int m = m_begin + mg * 8;
-        rb = m / OHW;
-        const int r = m - rb * OHW;
-        roh = r / p.OW;
-        row_ = r - roh * p.OW;
-    }
-    const int dq = WG_T / p.OW, dr = WG_T - dq * p.OW;                             // one step = WG_T rows further
-    auto load_step = [&](int mb) {
-        int b = rb, oh = roh, ow = row_;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int m = mb + mg * 8 + i;
-            const bool mv = m < m_end;
-            const unsigned yo = ((unsigned)m * (unsigned)p.ldy + (unsigned)(p.y_coff + yn)) * 2u;
-            unsigned xo;
-            bool xv = mv && xvalid;
-            if (lin) {
-                xo = ((unsigned)m * (unsigned)p.ldx + (unsigned)(p.x_coff + xc)) * 2u;
-            } else {
-                const int ih = oh * p.stride - p.pad + xkh, iw = ow * p.stride - p.pad + xkw;
-                xv = xv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                xo = ((unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.ldx + (unsigned)(p.x_coff + xc)) * 2u;
-                if (++ow == p.OW) {                                              // next row of this thread's 8-row group
-                    ow = 0;
-                    if (++oh == p.OH) { oh = 0; ++b; }
-                }
-            }
-            ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rsY, (mv && yvalid) ? yo : CRIS_OOB, 0, 0);
-            rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, xv ? xo : CRIS_OOB, 0, 0);
-        }
-        if (!lin) {                                                              // advance the group's first row by WG_T rows
-            row_ += dr;
-            roh += dq;
-            if (row_ >= p.OW) { row_ -= p.OW; ++roh; }
-            while (roh >= p.OH) { roh -= p.OH; ++rb; }
-        }
-    };
-    auto store_step = [&]() {
-        uint4 o[8];
-        if (do_bias) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float f[8];
-                unpack8(*reinterpret_cast<const uint4*>(&ry[i]), f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bsum[j] += f[j];
-            }
-        }
-        transpose8x8(reinterpret_cast<const uint4*>(ry), o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(sy + wg_off(vec * 8 + j, mg)) = o[j];
-        transpose8x8(reinterpret_cast<const uint4*>(rx), o);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) *reinterpret_cast<uint4*>(sx + wg_off(vec * 8 + j, mg)) = o[j];
-    };
-
-    // wave tile 64 (n) x 64 (k) as 2x2 fragments of v_mfma_f32_32x32x16_bf16 (half the LDS read traffic per flop of 16x16x32)
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 31, fh = lane >> 5;
-    load_step(m_begin);
-    for (int mb = m_begin; mb < m_end; mb += WG_T) {
-        store_step();
-        __syncthreads();
-        if (mb + WG_T < m_end) load_step(mb + WG_T);       // in flight during the MFMAs
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {                     // 8 slices of 16 pixels per 128-pixel step
-            bf16x8 af[2], bfr[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sy + wg_off(wr * 64 + i * 32 + fr, ks * 2 + fh));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sx + wg_off(wc * 64 + j * 32 + fr, ks * 2 + fh));
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-
-    if (do_bias) {                                   // block-wide column sums: [16 row groups][128 n] through LDS
-        float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) red[mg * 128 + vec * 8 + j] = bsum[j];
-        __syncthreads();
-        if (t < 128 && n0 + t < p.N) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) sacc += red[g * 128 + t];
-            atomicAdd(p.dbias + n0 + t, sacc);
-        }
-    }
-    // epilogue: GEMM-layout gradient dW[n][k] (k contiguous: the 16 lanes of a fragment row hit 64 contiguous bytes);
-    // plain stores when this block owns the whole reduction, fp32 atomics otherwise
-    const bool single = p.splits == 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {                       // C/D: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
-            const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (n >= p.N) continue;
-            float* row = p.dW + (size_t)n * p.ldw;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int k = k0 + wc * 64 + j * 32 + fr;
-                if (k >= p.K) continue;
-                if (single) row[k] = acc[i][j][r];
-                else atomicAdd(row + k, acc[i][j][r]);
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// weight gradient, second formulation (EXPERIMENTAL, selected by CRIS_WGRAD_TR=1..3; default off until it has been
-// through the GPU parity tests): both operand tiles are staged in their NATURAL row-major layout ([pixel][128 columns],
-// 256-B rows) by LDS-DMA - no register pass, no 8x8 register transposes, no ds_write - and the MFMA fragments, which need
-// 8 consecutive PIXELS of one column per lane, are fetched with gfx950's transposing LDS read (ds_read_b64_tr_b16: the 16
-// lanes of a group address a [4 rows][16 cols] block and receive its columns; lane mapping and layout cost measured in
-// profiles/r01_lds_tr_probe.md).  The bank-conflict swizzle (16-B chunk index ^ ((row & 7) << 1)) is applied on the
-// global side of the DMA, whose LDS destination is lane-linear.  Ring of STAGES buffers of MS pixel rows, counted vmcnt +
-// one raw barrier per step like conv_gemm_kernel.
-// ------------------------------------------------------------------------------------------------
-typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
-typedef __attribute__((ext_vector_type(8))) short wg_s16x8;
-typedef __attribute__((address_space(3))) wg_s16x4 wg_lds_s16x4;
-
-// The transposing read is issued as inline asm: with the builtin, hipcc's waitcnt pass puts an s_waitcnt vmcnt(0) in front
-// of the first read that follows an LDS-DMA (it cannot tell that the DMA targets another ring slot), which would serialise
-// the ring.  The asm is opaque to that pass, so the consumer waits are explicit: wg_wait_lds() is an s_waitcnt lgkmcnt(0)
-// that carries the fragment registers as in/out operands, which orders every use after it.
-template <int OFF>
-__device__ __forceinline__ wg_s16x4 wg_tr_read(unsigned lds_addr) {
-    wg_s16x4 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
-    return v;
-}
-struct wg_frags {
-    wg_s16x4 y[2][2], x[2][2];                     // [fragment][q]
-};
-template <int KS>
-__device__ __forceinline__ void wg_read_slice(wg_frags& f, const unsigned (&ay)[2][2], const unsigned (&ax)[2][2]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        f.y[i][0] = wg_tr_read<KS * 4096>(ay[i][0]);
-        f.y[i][1] = wg_tr_read<KS * 4096>(ay[i][1]);
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        f.x[j][0] = wg_tr_read<KS * 4096>(ax[j][0]);
-        f.x[j][1] = wg_tr_read<KS * 4096>(ax[j][1]);
-    }
-}
-__device__ __forceinline__ void wg_wait_lds(wg_frags& f) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(f.y[0][0]), "+v"(f.y[0][1]), "+v"(f.y[1][0]), "+v"(f.y[1][1]), "+v"(f.x[0][0]), "+v"(f.x[0][1]),
-                   "+v"(f.x[1][0]), "+v"(f.x[1][1]));
-}
-__device__ __forceinline__ bf16x8 wg_join(const wg_s16x4& lo, const wg_s16x4& hi) {
-    const wg_s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
-template <int KS, int KSL>
-__device__ __forceinline__ void wg_slices(f32x16 (&acc)[2][2], wg_frags& cur, const unsigned (&ay)[2][2], const unsigned (&ax)[2][2]) {
-    // `cur` holds slice KS (already waited for); fetch slice KS+1 underneath this slice's MFMAs
-    wg_frags nxt;
-    if constexpr (KS + 1 < KSL) wg_read_slice<KS + 1>(nxt, ay, ax);
-    bf16x8 af[2], bfr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) af[i] = wg_join(cur.y[i][0], cur.y[i][1]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) bfr[j] = wg_join(cur.x[j][0], cur.x[j][1]);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    if constexpr (KS + 1 < KSL) {
-        wg_wait_lds(nxt);
-        wg_slices<KS + 1, KSL>(acc, nxt, ay, ax);
-    }
-}
-
-template <int MS, int STAGES>
-__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const cris_wgrad_params p) {
-    constexpr int IMG_BYTES = MS * 256;            // one operand image: MS pixel rows x 128 bf16
-    constexpr int STAGE_BYTES = 2 * IMG_BYTES;     // dY image, then X image
-    constexpr int ND = MS / 16;                    // DMA instructions per wave per operand per step (4 rows each, 4 waves)
-    constexpr int KSL = MS / 16;                   // 16-pixel MFMA slices per step
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-    const int t = threadIdx.x;
-    const int lane = t & 63, wave = t >> 6;
-    int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    {
-        const int nblk = gridDim.x * gridDim.y * gridDim.z;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int bx = bid % gridDim.x, by = (bid / gridDim.x) % gridDim.y, bz = bid / (gridDim.x * gridDim.y);
-    const int k0 = bx * WG_T;
-    const int n0 = by * WG_T;
-    int rows_per = (p.M + p.splits - 1) / p.splits;
-    rows_per = (rows_per + WG_T - 1) / WG_T * WG_T;
-    const int m_begin = bz * rows_per;
-    const int m_end = min(p.M, m_begin + rows_per);
-    if (m_begin >= m_end) return;
-    const int nsteps = (m_end - m_begin + MS - 1) / MS;
-
-    // ---- DMA role: instruction i of this wave fills rows (wave + 4i)*4 + (lane>>4), LDS slot lane&15 of the row; the
-    // 16-B chunk that belongs there is slot ^ ((row & 7) << 1), and row & 7 = 4*(wave&1) + (lane>>4) for every i ----
-    const int rsub = lane >> 4;
-    const int row7 = ((wave & 1) << 2) + rsub;
-    const int cg = (lane & 15) ^ (row7 << 1);      // global 8-column chunk of this lane, 0..15
-    const int OHW = p.OH * p.OW;
-    const int yn = n0 + cg * 8;
-    const bool yvalid = yn < p.N_ld;
-    const int xk = k0 + cg * 8;
-    const bool xvalid = xk < p.K;
-    const int xtap = xvalid ? xk / p.C : 0;
-    const int xc = xvalid ? xk - xtap * p.C : 0;
-    const int xkh = xtap / p.KW, xkw = xtap - xkh * p.KW;
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dY), 0, (int)((size_t)p.M * p.ldy * 2),
-                                                                        CRIS_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.X), 0, (int)((size_t)p.Bn * p.H * p.W * p.ldx * 2), CRIS_BUF_FLAGS);
-    const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;      // pixel index == row index
-    // (b, oh, ow) of this lane's first row of the NEXT step to issue, advanced without divisions
-    int rb, roh, row_;
-    {
-        const int m = m_begin + wave * 4 + rsub;
-        rb = m / OHW;
-        const int r = m - rb * OHW;
-        roh = r / p.OW;
-        row_ = r - roh * p.OW;
-    }
-    int m_issue = m_begin;                         // first pixel row of the next step to issue
-    const int d16b = 16 / OHW, d16q = (16 - d16b * OHW) / p.OW, d16r = (16 - d16b * OHW) - d16q * p.OW;
-    const int dMSb = MS / OHW, dMSq = (MS - dMSb * OHW) / p.OW, dMSr = (MS - dMSb * OHW) - dMSq * p.OW;
-    auto issue_step = [&](int buf) {
-        unsigned char* sy = smem + buf * STAGE_BYTES + wave * 1024;               // wave-uniform LDS base of DMA i: + i*4096
-        unsigned char* sx = sy + IMG_BYTES;
-        int b = rb, oh = roh, ow = row_;
-#pragma unroll
-        for (int i = 0; i < ND; ++i) {
-            const int m = m_issue + (wave + 4 * i) * 4 + rsub;
-            const bool mv = m < m_end;
-            const unsigned yo = ((unsigned)m * (unsigned)p.ldy + (unsigned)(p.y_coff + yn)) * 2u;
-            unsigned xo;
-            bool xv = mv && xvalid;
-            if (lin) {
-                xo = ((unsigned)m * (unsigned)p.ldx + (unsigned)(p.x_coff + xc)) * 2u;
-            } else {
-                const int ih = oh * p.stride - p.pad + xkh, iw = ow * p.stride - p.pad + xkw;
-                xv = xv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                xo = ((unsigned)((b * p.H + ih) * p.W + iw) * (unsigned)p.ldx + (unsigned)(p.x_coff + xc)) * 2u;
-                // this lane's next row is 16 pixels further: 16 = d16b images + d16q rows + d16r pixels, each carry at most 1
-                b += d16b; oh += d16q; ow += d16r;
-                if (ow >= p.OW) { ow -= p.OW; ++oh; }
-                if (oh >= p.OH) { oh -= p.OH; ++b; }
-            }
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(sy + i * 4096), 16, (mv && yvalid) ? yo : CRIS_OOB, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_t*)(sx + i * 4096), 16, xv ? xo : CRIS_OOB, 0, 0, 0);
-        }
-        m_issue += MS;
-        if (!lin) {                                                              // first row of the following step
-            rb += dMSb; roh += dMSq; row_ += dMSr;
-            if (row_ >= p.OW) { row_ -= p.OW; ++roh; }
-            if (roh >= p.OH) { roh -= p.OH; ++rb; }
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // ---- fragment addressing: lane l, read q (= reduction elements 4q..4q+3 of the lane's 8): row 8*(l>>5) + 4q + ((l&15)>>2)
-    // of the slice, columns col0 + 16*((l>>4)&1) + 4*(l&3) .. +3; (row & 7) = 4q + ((l&15)>>2) whatever the slice ----
-    const int wr = wave >> 1, wc = wave & 1;
-    const int fr = lane & 31, fh = lane >> 5;
-    int offY[2][2], offX[2][2];
-    {
-        const int tl = lane & 15, gb = (lane >> 4) & 1;
-#pragma unroll
-        for (int f = 0; f < 2; ++f)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int r7 = 4 * q + (tl >> 2);
-                const int row = 8 * fh + r7;
-                const int cy = wr * 64 + f * 32 + 16 * gb + 4 * (tl & 3);
-                const int cx = wc * 64 + f * 32 + 16 * gb + 4 * (tl & 3);
-                offY[f][q] = row * 256 + ((((cy >> 3) ^ (r7 << 1)) & 15) << 4) + (cy & 7) * 2;
-                offX[f][q] = row * 256 + ((((cx >> 3) ^ (r7 << 1)) & 15) << 4) + (cx & 7) * 2;
-            }
-    }
-    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;               // LDS byte address of the ring
-    const bool do_bias = p.dbias != nullptr && bx == 0;
-    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // columns 8*bcg .. +7 of dY over this thread's rows
-    const int bcg = (t & 15) ^ ((((t >> 4) & 7) << 1) & 15);
-
-#pragma unroll
-    for (int s_ = 0; s_ < STAGES - 1; ++s_) issue_step(s_);
-    int buf = 0;
-    for (int st = 0; st < nsteps; ++st) {
-        CRIS_VMCNT((STAGES - 2) * 2 * ND);          // this wave's share of step st has landed ...
-        __builtin_amdgcn_s_barrier();               // ... and everyone's; everyone is also done reading step st-1
-        {
-            int nb = buf + STAGES - 1;
-            if (nb >= STAGES) nb -= STAGES;
-            issue_step(nb);                         // steps beyond the split's range read zeros (uniform DMA count)
-        }
-        const unsigned char* sy = smem + buf * STAGE_BYTES;
-        {
-            const unsigned sbase = lds_base + (unsigned)(buf * STAGE_BYTES);
-            unsigned ay[2][2], ax[2][2];
-#pragma unroll
-            for (int f = 0; f < 2; ++f)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    ay[f][q] = sbase + (unsigned)offY[f][q];
-                    ax[f][q] = sbase + (unsigned)(IMG_BYTES + offX[f][q]);
-                }
-            wg_frags cur;
-            wg_read_slice<0>(cur, ay, ax);
-            wg_wait_lds(cur);
-            wg_slices<0, KSL>(acc, cur, ay, ax);
-        }
-        if (do_bias) {                              // block-uniform: only the blocks of the first k-tile
-            // thread t owns LDS slot t&15 of rows (t>>4) + 16j: row & 7 is the same for all of them, so the slot always holds
-            // the same global 8-column chunk (bcg) - MS/16 16-byte reads per step instead of one 2-byte read per row
-#pragma unroll
-            for (int j = 0; j < MS / 16; ++j) {
-                float f[8];
-                unpack8(*reinterpret_cast<const uint4*>(sy + ((t >> 4) + 16 * j) * 256 + (t & 15) * 16), f);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) bsum[e] += f[e];
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (++buf == STAGES) buf = 0;
-    }
-    CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before LDS is reused / the block retires
-
-    if (do_bias) {                                   // block-wide column sums: [16 row groups][128 n] through LDS
-        __syncthreads();
-        float* red = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) red[(t >> 4) * 128 + bcg * 8 + e] = bsum[e];
-        __syncthreads();
-        if (t < 128 && n0 + t < p.N) {
-            float sacc = 0.f;
-#pragma unroll
-            for (int g = 0; g < 16; ++g) sacc += red[g * 128 + t];
-            atomicAdd(p.dbias + n0 + t, sacc);
-        }
-    }
-    const bool single = p.splits == 1;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {                       // C/D: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
-            const int n = n0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (n >= p.N) continue;
-            float* row = p.dW + (size_t)n * p.ldw;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int k = k0 + wc * 64 + j * 32 + fr;
-                if (k >= p.K) continue;
-                if (single) row[k] = acc[i][j][r];
-                else atomicAdd(row + k, acc[i][j][r]);
-            }
-        }
-    }
-}
-
-typedef void (*wgrad_tr_fn)(const cris_wgrad_params);
-
-extern "C" int cris_conv_wgrad(const cris_wgrad_params* pp, void* stream) {
-    const cris_wgrad_params& p = *pp;
-    CRIS_CHECK_ARG(p.dY && p.X && p.dW, "null operand");
-    CRIS_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0 && p.splits > 0, "empty problem");
-    CRIS_CHECK_ARG((p.C & 7) == 0 && (p.ldx & 7) == 0 && (p.x_coff & 7) == 0, "X channels/ld/offset must be multiples of 8");
-    CRIS_CHECK_ARG((p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && (p.N_ld & 7) == 0 && p.N_ld >= p.N, "dY ld/offset/N_ld");
-    CRIS_CHECK_ARG(p.K == p.KH * p.KW * p.C && p.M == p.Bn * p.OH * p.OW, "geometry");
-    CRIS_CHECK_ARG(p.ldw >= p.K, "ldw < K");
-    CRIS_CHECK_ARG((size_t)p.M * p.ldy * 2 < (1UL << 31) && (size_t)p.Bn * p.H * p.W * p.ldx * 2 < (1UL << 31),
-                   "operand extent must stay below 2 GiB (32-bit buffer offsets)");
-    dim3 grid(cris_cdiv(p.K, WG_T), cris_cdiv(p.N, WG_T), p.splits);
-    // experimental transposing-read formulation: 1 = 64-row steps x 2 stages (64 KB), 2 = 32 x 3 (48 KB), 3 = 32 x 4 (64 KB)
-    static const int tr_mode = cris_env_int("CRIS_WGRAD_TR", 0);
-    if (tr_mode >= 1 && tr_mode <= 3) {
-        static const wgrad_tr_fn tr_k[3] = {conv_wgrad_tr_kernel<64, 2>, conv_wgrad_tr_kernel<32, 3>, conv_wgrad_tr_kernel<32, 4>};
-        static const int tr_lds[3] = {2 * 2 * 64 * 256, 3 * 2 * 32 * 256, 4 * 2 * 32 * 256};
-        static const int tr_ready = set_lds((const void*)tr_k[0], tr_lds[0]) | set_lds((const void*)tr_k[1], tr_lds[1]) |
-                                    set_lds((const void*)tr_k[2], tr_lds[2]);
-        if (tr_ready != 0) {
-            cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, tr_ready);
-            return tr_ready;
-        }
-        hipLaunchKernelGGL(tr_k[tr_mode - 1], grid, dim3(256), tr_lds[tr_mode - 1], (hipStream_t)stream, p);
-        CRIS_LAUNCH_CHECK();
-        return 0;
-    }
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -98,6 +98,14 @@ class TorchDistComm:
         self._slot += 1
         return lambda: self.p2p.allreduce_sum(t, slot, gen_dev=self._gen_dev)
 
+    def broadcast(self, t, src=0):
+        dist.broadcast(t, src)
+
+    def all_gather_object(self, obj):
+        out = [None] * self.world
+        dist.all_gather_object(out, obj)
+        return out
+
     # SyncBN exchanges run inline on the compute stream (they sit on the critical path by construction)
     def allreduce_sum(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -76,6 +76,12 @@ class Comm:
     def begin_step(self):
         """Called once per scheduled training step before the first exchange (exchange numbering restarts)."""
 
+    def broadcast(self, t, src=0):  # pragma: no cover - single GPU default
+        return
+
+    def all_gather_object(self, obj):
+        return [obj]
+
     def allreduce_sum_op(self, t):
         """The exchange of `t` as a callable bound NOW (schedule time) - what ops.torch_op runs and a command list replays."""
         return lambda: self.allreduce_sum(t)
@@ -95,11 +101,8 @@ class Engine:
         # the text encoder (12 layers of M = B*L ~ 136-row GEMMs: latency-bound, ~16 workgroups each) is independent of
         # the visual encoder until the neck: it runs on a second HIP stream, forward and backward, underneath the convs
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
-        # weight gradients only feed the gradient arena (read by the exchange / optimizer at the end): they run on a third
-        # stream behind the dgrad + BatchNorm chain of the launch stream, filling the CUs those mid-size kernels leave idle
-        self.wstream = (torch.cuda.Stream(device=device)
-                        if torch.device(device).type == "cuda" and os.environ.get("CRIS_WGRAD_STREAM", "0") == "1" else None)
-        self._keepalive = []
+        # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue)
+        self._wq = ops.WgradQueue()
         # Folding a BatchNorm's backward reduction into its consumer conv's input-gradient GEMM epilogue is implemented and
         # parity-tested, but MEASURED SLOWER (21.0 -> 22.0 ms/step at R50/416/B=8: the per-element y reads and extra
         # arithmetic lengthen every block's epilogue by more than the separate reduction pass costs): off by default.
@@ -270,18 +273,6 @@ class Engine:
         t = (self.zeros if zero else self.empty)(Bn * H * W, ld, dtype=dtype)
         return Act(t, Bn, H, W, C, ld)
 
-    def wgrad_async(self, fn, *keep):
-        """run `fn` (weight-gradient launches) on the wgrad stream after everything issued so far on the current stream;
-        `keep`: temporaries it reads, kept alive until backward() joins the streams"""
-        if self.wstream is None:
-            fn()
-            return
-        cur = torch.cuda.current_stream()
-        ops.torch_op(lambda: self.wstream.wait_stream(cur))
-        with torch.cuda.stream(self.wstream):
-            fn()
-        self._keepalive.extend(keep)
-
     def drop(self, layer, site):
         p = self.head.dropout if self.training else 0.0
         return Drop(p, self.seed, layer * 8 + site, self.seed_dev) if p > 0 else NO_DROP
@@ -327,15 +318,13 @@ class Engine:
                 gy_ld, gy_coff = pad8(N), 0
             else:
                 gy, gy_ld, gy_coff = out.g, out.ld, out.coff
-            def wg():
-                if w_transposed:
-                    # parameter stored [in, out] (used as x @ P): dP = x^T dY - same kernel with the operand roles swapped
-                    ops.conv_wgrad(x.t, gy, Geom.linear(out.M, pad8(N)), x.C, Gw, ldy=x.ld, y_coff=x.coff, N_ld=x.C, ldx=gy_ld,
-                                   x_coff=gy_coff)
-                else:
-                    ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff,
-                                   dbias=None if bias is None else self.G[bias][n0:n0 + N])
-            self.wgrad_async(wg, gy)
+            if w_transposed:
+                # parameter stored [in, out] (used as x @ P): dP = x^T dY - same kernel with the operand roles swapped
+                ops.conv_wgrad(x.t, gy, Geom.linear(out.M, pad8(N)), x.C, Gw, ldy=x.ld, y_coff=x.coff, N_ld=x.C, ldx=gy_ld,
+                               x_coff=gy_coff, queue=self._wq)
+            else:
+                ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff,
+                               dbias=None if bias is None else self.G[bias][n0:n0 + N], queue=self._wq)
             if no_dgrad:
                 return
             assert N % 8 == 0, "dgrad path needs N % 8 == 0 (pad the gradient buffer otherwise)"
@@ -833,8 +822,8 @@ class Engine:
                 dwb = self._dwb                                        # fp32 [B, ld] filled by dynconv_bwd
                 gy = self.empty(state.M, wb.ld)
                 ops.cast_f32_bf16(dwb, gy)
-                self.wgrad_async(lambda: ops.conv_wgrad(gy, state.t, g, nwb, self.G[p + ".weight"], ldy=wb.ld, N_ld=wb.ld,
-                                                        ldx=state.ld, x_coff=state.coff, dbias=self.G[p + ".bias"]), gy)
+                ops.conv_wgrad(gy, state.t, g, nwb, self.G[p + ".weight"], ldy=wb.ld, N_ld=wb.ld, ldx=state.ld, x_coff=state.coff,
+                               dbias=self.G[p + ".bias"], queue=self._wq)
                 gx, acc = state.grad_target()
                 gD = Geom.linear(state.M, wb.ld)
                 ops.conv_gemm(gy, self.WD[p + ".weight"], gD, state.C, lda=wb.ld, out=gx, ldc=state.ld, c_coff=state.coff,
@@ -847,6 +836,7 @@ class Engine:
     def forward(self, img, word, mask=None, training=True, seed=0, taps: Optional[dict] = None):
         self.training, self.seed = training, int(seed) & 0xFFFFFFFF
         self.tape = []
+        self._wq = ops.WgradQueue()                      # (drops problems of a forward whose backward never ran)
         self._dgrad_outT = None
         self._stage_marks = {}
         Act._engine = self
@@ -856,7 +846,16 @@ class Engine:
             ops.zero_(self.grad_arena)
         if not self.packs_current:
             self.repack_weights()
+        # token ids index the embedding table and the key-padding mask as int64 (torch.nn.Embedding would raise on anything
+        # else); the expression may not be longer than the text positional table (reference model/clip.py:441)
+        if word.dtype != torch.int64:
+            if word.is_floating_point():
+                raise TypeError("word must hold integer token ids, got %s" % word.dtype)
+            word = word.to(torch.int64)
         word = word.contiguous()
+        if word.shape[1] > self.P["backbone.positional_embedding"].shape[0]:
+            raise ValueError("expression length %d exceeds the text context length %d"
+                             % (word.shape[1], self.P["backbone.positional_embedding"].shape[0]))
         main = torch.cuda.current_stream()
         self._text_tape_start = 0
         self._vis_stage_start = {}
@@ -919,20 +918,17 @@ class Engine:
         marks = dict(self._stage_marks)                 # tape index at which a stage's closures START
         (t0, t1), (v0, v1) = self._ranges["text"], self._ranges["visual"]
         head_start = max(t1, v1)                        # neck / decoder / projector closures: main stream
-        def join_wgrads():
-            if self.wstream is not None:
-                cur = torch.cuda.current_stream()
-                ops.torch_op(lambda: cur.wait_stream(self.wstream))
-
         def fire(i):
-            if on_stage_done is not None and i in marks:
-                join_wgrads()
-                for st in marks[i]:
-                    on_stage_done(st)
+            if i in marks:
+                self._wq.flush()                         # the stage's queued weight gradients (current stream)
+                if on_stage_done is not None:
+                    for st in marks[i]:
+                        on_stage_done(st)
 
         for i in range(len(self.tape) - 1, head_start - 1, -1):
             self.tape[i]()
             fire(i)
+        self._wq.flush()
         # the two encoders' backward passes are independent: text on the side stream, visual on the launch stream
         main = torch.cuda.current_stream()
         if self.side is not None:
@@ -940,20 +936,21 @@ class Engine:
             with torch.cuda.stream(self.side):
                 for i in range(t1 - 1, t0 - 1, -1):
                     self.tape[i]()
+                self._wq.flush()
                 if on_stage_done is not None:
                     on_stage_done(4)                     # issued from the side stream: the exchange waits for it only
         else:
             for i in range(t1 - 1, t0 - 1, -1):
                 self.tape[i]()
+            self._wq.flush()
             if on_stage_done is not None:
                 on_stage_done(4)
         for i in range(v1 - 1, v0 - 1, -1):
             self.tape[i]()
             fire(i)                                      # visual stages 3, 2, 1, 0 as their layer groups finish
+        self._wq.flush()
         if self.side is not None:
             ops.torch_op(lambda: main.wait_stream(self.side))
-        join_wgrads()
-        self._keepalive = []
         self._zneed_last = max(self._zneed_last, self._zneed)
         Act._engine = None
         self.tape = []

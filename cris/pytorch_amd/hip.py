@@ -41,7 +41,14 @@ class WgradParams(C.Structure):
                 ("OH", I), ("OW", I), ("KH", I), ("KW", I), ("stride", I), ("pad", I),
                 ("M", I), ("N", I), ("K", I),
                 ("ldw", I), ("splits", I),
-                ("dbias", P)]
+                ("dbias", P), ("ws", P)]
+
+
+WGRAD_GROUP_MAX = 24
+
+
+class WgradGroup(C.Structure):
+    _fields_ = [("n", I), ("block_start", I * (WGRAD_GROUP_MAX + 1)), ("prob", WgradParams * WGRAD_GROUP_MAX)]
 
 
 class PackDesc(C.Structure):
@@ -148,7 +155,7 @@ class P2PParams(C.Structure):
 
 
 STRUCTS = {
-    "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_pack_desc": PackDesc,
+    "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_wgrad_group": WgradGroup, "cris_pack_desc": PackDesc,
     "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
     "cris_ln_bwd_params": LnBwdParams, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams,
 }
@@ -161,6 +168,9 @@ _SIGS = {
     "cris_echo_conv_gemm": (L, [P]),
     "cris_conv_gemm": (I, [P, P]),
     "cris_conv_wgrad": (I, [P, P]),
+    "cris_conv_wgrad_group": (I, [P, P]),
+    "cris_wgrad_reduce": (I, [P, P]),
+    "cris_wgrad_ws_floats": (L, [I, I, I, I]),
     "cris_pack_weights": (I, [P, I, I, P]),
     "cris_pack_blocks": (I, [P]),
     "cris_pack_block_elems": (I, []),

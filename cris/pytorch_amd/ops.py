@@ -172,19 +172,21 @@ class KernelTimer:
 KERNEL_TIMER = None
 
 
-_WGRAD_BLOCKS = int(os.environ.get("CRIS_WGRAD_BLOCKS", "512"))      # launch-geometry knob (never changes results)
+_WGRAD_BLOCKS = int(os.environ.get("CRIS_WGRAD_BLOCKS", "512"))      # launch-geometry knobs (never change results)
+_WGRAD_GROUP_M = int(os.environ.get("CRIS_WGRAD_GROUP_M", "8192"))    # problems up to this many pixel rows are queued
+_WGRAD_FLUSH_BLOCKS = int(os.environ.get("CRIS_WGRAD_FLUSH_BLOCKS", "3072"))
 
 
 def wgrad_splits(M: int, N: int, K: int) -> int:
     """split the pixel reduction only as far as needed to put ~2 blocks on each of the 256 CUs; every split costs a
-    128x128 tile of fp32 atomics, so long reductions per block win"""
+    128x128 partial tile written to and read back from the workspace, so long reductions per block win"""
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     steps = (M + 127) // 128
     want = max(1, (_WGRAD_BLOCKS + tiles // 2) // tiles)
     return max(1, min(want, (steps + 3) // 4, 512))
 
 
-def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, ldw=None, splits=None, dbias=None):
+def _wgrad_params(dY, X, g: Geom, N: int, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, splits, dbias):
     p = hip.WgradParams()
     p.dY, p.X, p.dW = ptr(dY), ptr(X), ptr(dW)
     p.ldy = ldy if ldy is not None else dY.shape[-1]
@@ -197,10 +199,61 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
     p.M, p.N, p.K = g.M, N, g.K
     p.ldw = ldw if ldw is not None else dW.shape[-1]
     p.dbias = ptr(dbias)
-    p.splits = splits if splits is not None else wgrad_splits(g.M, N, g.K)
+    p.splits = splits
+    return p
+
+
+class WgradQueue:
+    """Weight-gradient problems of the mid-size layers, launched together (cris_conv_wgrad_group): such a layer has 16-600
+    output tiles of 128x128 - alone it would have to split its pixel reduction 4-11 ways to occupy 256 CUs.  The engine
+    queues them while backward walks an arena stage and flushes at the stage boundary (or when enough blocks are waiting),
+    longest reductions first.  Operand tensors are kept alive until their launch has been issued."""
+
+    def __init__(self):
+        self.items = []
+        self.blocks = 0
+
+    def add(self, p, keep, flops, nbytes):
+        self.items.append((p, keep, flops, nbytes))
+        self.blocks += ((p.N + 127) // 128) * ((p.K + 127) // 128)
+        if self.blocks >= _WGRAD_FLUSH_BLOCKS:
+            self.flush()
+
+    def flush(self):
+        items, self.items, self.blocks = self.items, [], 0
+        if not items:
+            return
+        items.sort(key=lambda it: -it[0].M)                    # stable: longest pixel reductions are dispatched first
+        for i in range(0, len(items), hip.WGRAD_GROUP_MAX):
+            chunk = items[i:i + hip.WGRAD_GROUP_MAX]
+            grp = hip.WgradGroup()
+            grp.n = len(chunk)
+            for j, it in enumerate(chunk):
+                grp.prob[j] = it[0]
+            if KERNEL_TIMER is not None:
+                KERNEL_TIMER.launch("conv_wgrad", sum(it[2] for it in chunk), sum(it[3] for it in chunk), "cris_conv_wgrad_group",
+                                    C.byref(grp), tag="group of %d (M %d..%d)" % (len(chunk), chunk[-1][0].M, chunk[0][0].M))
+            else:
+                hip.call("cris_conv_wgrad_group", C.byref(grp), _stream())
+
+
+def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, ldw=None, splits=None, dbias=None,
+               queue: Optional[WgradQueue] = None):
+    """dW[N][K] = dY^T X_im2col (GEMM layout), dbias = column sums of dY.  With a `queue`, problems of up to
+    CRIS_WGRAD_GROUP_M pixel rows are deferred to the queue's next grouped launch (unsplit); larger ones (and every call
+    without a queue) launch now, their pixel range split over blocks with a deterministic workspace reduction."""
+    flops, nbytes = 2.0 * g.M * N * g.K, 2.0 * (g.M * N + g.M * g.C) + 4.0 * N * g.K
+    if queue is not None and splits is None and g.M <= _WGRAD_GROUP_M:
+        p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, 1, dbias)
+        queue.add(p, (dY, X, dW, dbias), flops, nbytes)
+        return
+    p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, splits if splits is not None else wgrad_splits(g.M, N, g.K),
+                      dbias)
+    nws = hip.load().cris_wgrad_ws_floats(p.M, p.N, p.ldw, p.splits)
+    ws = torch.empty(nws, dtype=torch.float32, device=dW.device) if nws else None
+    p.ws = ptr(ws)
     if KERNEL_TIMER is not None:
-        KERNEL_TIMER.launch("conv_wgrad", 2.0 * g.M * N * g.K, 2.0 * (g.M * N + g.M * g.C) + 4.0 * N * g.K, "cris_conv_wgrad", C.byref(p),
-                            tag="M%d N%d K%d k%d s%d" % (g.M, N, g.K, g.KH, p.splits))
+        KERNEL_TIMER.launch("conv_wgrad", flops, nbytes, "cris_conv_wgrad", C.byref(p), tag="M%d N%d K%d k%d s%d" % (g.M, N, g.K, g.KH, p.splits))
         return
     hip.call("cris_conv_wgrad", C.byref(p), _stream())
 

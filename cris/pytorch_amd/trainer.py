@@ -55,6 +55,12 @@ class NativeTrainer:
         self.engine = Engine(clip, head, params, buffers, device, comm=comm, sync_bn=sync_bn)
         self.comm = self.engine.comm
         e = self.engine
+        if self.comm.world > 1:
+            # DistributedDataParallel broadcasts rank 0's parameters and buffers when it wraps the module (train.py:100-102);
+            # the single-exchange SyncBN takes its moments about the running mean, which must be bit-identical on every rank
+            for t in list(e.P.values()) + list(e.Bf.values()):
+                self.comm.broadcast(t, 0)
+        self._checked_batch = None
         # `build_segmenter` groups: backbone (w/o positional embeddings) vs the rest.  torch's Adam is built with
         # lr=base_lr and groups that only carry `initial_lr`, so BOTH groups start at base_lr.
         names = [n for n in e.grad_order if n != "backbone.logit_scale"]          # never receives a gradient (unused)
@@ -165,9 +171,11 @@ class NativeTrainer:
         """One optimizer step.  Returns (loss 0-dim device tensor, metric [IoU%, Pr@50%] device tensor); both are
         overwritten by the next call."""
         if not self.use_graph or seed is not None or ops.KERNEL_TIMER is not None:
+            self._check_equal_batch(img.shape[0])
             loss, _, _ = self._step_body(img, word, mask, seed)
             return loss, self.metric
         key = (tuple(img.shape), tuple(word.shape), tuple(mask.shape))
+        self._check_equal_batch(img.shape[0])
         if self._static is not None and self._static[0] != key:
             self._graph, self._cmds, self._static, self._eager_steps = None, None, None, 0      # new shapes: new schedule
         if self._graph is None and self._cmds is None:
@@ -201,6 +209,15 @@ class NativeTrainer:
         else:
             self._cmds.replay()
         return self._loss, self.metric
+
+    def _check_equal_batch(self, b):
+        """SyncBN's global count is local count x world: every rank must feed the same per-rank batch (the reference's
+        DistributedSampler + fixed DataLoader batch size guarantee it; checked once per batch size, not per step)."""
+        if self.comm.world > 1 and self._checked_batch != b:
+            sizes = self.comm.all_gather_object(int(b))
+            if any(x != sizes[0] for x in sizes):
+                raise ValueError("per-rank batch sizes differ across ranks (%s): SyncBN statistics assume equal shards" % (sizes,))
+            self._checked_batch = b
 
     def _capture(self):
         _, s_img, s_word, s_mask = self._static

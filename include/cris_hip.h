@@ -76,24 +76,40 @@ int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
 /* rows per BatchNorm-statistics partial written for this problem (depends on the tile variant chosen; host only) */
 int cris_conv_gemm_stat_rows(const cris_conv_gemm_params* p);
 
-/* Weight gradient in the GEMM layout: dW[n][tap*C + c] (+)= sum_m dY[m, n] * X_im2col[m, tap*C + c]
- * (splits == 1: plain store of the whole reduction; splits > 1: fp32 atomics into a zeroed buffer).
- * Replaces convolution_backward(weight) / addmm backward for every Conv2d / Linear above.  cris_adam_step reads this
- * layout directly; cris_unpack_grads converts it to the parameter layout [n][c][tap]. */
+/* Weight gradient in the GEMM layout: dW[n][tap*C + c] = sum_m dY[m, n] * X_im2col[m, tap*C + c]  (csrc/wgrad.hip).
+ * Deterministic, no atomics: splits == 1 stores the whole reduction; splits > 1 stores one partial tile per split into the
+ * workspace `ws` (cris_wgrad_ws_floats floats) and sums the slabs in split order (cris_wgrad_reduce, launched by
+ * cris_conv_wgrad itself).  Replaces convolution_backward(weight) / addmm backward for every Conv2d / Linear above.
+ * cris_adam_step reads this layout directly; cris_unpack_grads converts it to the parameter layout [n][c][tap]. */
 typedef struct {
     const cris_bf16* dY;     /* [M][ldy] (+y_coff) */
     const cris_bf16* X;      /* NHWC input of the forward conv */
-    float* dW;               /* fp32 [N][ldw], k = tap*C + c contiguous */
+    float* dW;               /* fp32 [N][ldw], k = tap*C + c contiguous; overwritten */
     int ldy, y_coff, N_ld;   /* N_ld: columns of dY that may be read (multiple of 8, >= N) */
     int ldx, x_coff;
     int Bn, H, W, C;
     int OH, OW, KH, KW, stride, pad;
     int M, N, K;
     int ldw;                 /* row stride of dW (>= K) */
-    int splits;              /* grid.z; each split covers ceil(M/splits) rows rounded up to 128 */
-    float* dbias;            /* optional [N]: += column sums of dY (bias gradient), fp32 atomics; or NULL */
+    int splits;              /* requested split of the pixel range (each split covers ceil(M/splits) rows rounded up to 128;
+                                the launcher drops splits that would be empty) */
+    float* dbias;            /* optional [N]: = column sums of dY (bias gradient); or NULL */
+    float* ws;               /* splits > 1: workspace of cris_wgrad_ws_floats(M, N, ldw, splits) floats, 16-byte aligned */
 } cris_wgrad_params;
 int cris_conv_wgrad(const cris_wgrad_params* p, void* stream);
+long cris_wgrad_ws_floats(int M, int N, int ldw, int splits);
+int cris_wgrad_reduce(const cris_wgrad_params* p, void* stream);
+
+/* Up to CRIS_WGRAD_GROUP_MAX weight-gradient problems in ONE launch (problem table passed by value in the kernel
+ * arguments): the mid-size layers have too few 128x128 output tiles to fill the chip alone; the engine queues them per
+ * gradient-arena stage and launches them together, longest pixel reductions first.  block_start is filled by the launcher. */
+#define CRIS_WGRAD_GROUP_MAX 24
+typedef struct {
+    int n;                                           /* problems in prob[] */
+    int block_start[CRIS_WGRAD_GROUP_MAX + 1];       /* (out) first block of each problem */
+    cris_wgrad_params prob[CRIS_WGRAD_GROUP_MAX];
+} cris_wgrad_group;
+int cris_conv_wgrad_group(const cris_wgrad_group* g, void* stream);
 
 /* Batched weight packing (fp32 parameter layout -> bf16 GEMM layouts), one launch for a table of tensors.
  *   F layout: Wf[n][tap][Cpad]        (forward, k = tap*Cpad + c, zero padded)

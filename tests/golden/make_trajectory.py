@@ -25,7 +25,7 @@ from cris.pytorch_amd import arch, synth  # noqa: E402
 from oracle import cris_oracle as O  # noqa: E402
 
 
-def main(spec="tiny", B=4, S=64, steps=100, dropout=0.1, lr=1e-4, emul=False, threads=6):
+def main(spec="tiny", B=4, S=64, steps=100, dropout=0.1, lr=1e-4, emul=False, threads=4):
     torch.set_num_threads(threads)
     clip, head = arch.specs_by_name(spec)
     head = dataclasses.replace(head, dropout=dropout)

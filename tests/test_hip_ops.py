@@ -146,15 +146,18 @@ def test_conv_gemm_transposed_store(L, B):
     assert float(got[..., L:].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("case", [
+WGRAD_CASES = [
     dict(B=2, H=12, W=12, C=64, N=128, k=1),
     dict(B=2, H=12, W=12, C=64, N=64, k=3),
     dict(B=1, H=20, W=20, C=32, N=32, k=3),
     dict(B=2, H=9, W=9, C=136, N=72, k=3, C_real=130),
     dict(B=8, H=1, W=1, C=1024, N=2305, k=1),
     dict(B=1500, H=1, W=1, C=40, N=24, k=1),
-])
-def test_conv_wgrad(case):
+    dict(B=2, H=26, W=26, C=128, N=256, k=3),          # M=1352: many tiles, long pixel loop with image-border carries
+]
+
+
+def _wgrad_problem(case):
     B, H, W, C_, N, k = case["B"], case["H"], case["W"], case["C"], case["N"], case["k"]
     C_real = case.get("C_real", C_)
     pad = k // 2
@@ -166,18 +169,63 @@ def test_conv_wgrad(case):
     dy = torch.zeros(g.M, Nld)
     dy[:, :N] = rnd(g.M, N, seed=5)
     dy = dy.to(BF).float()
-    for splits in (None, 1):                                  # atomics path (split reduction) and plain-store path
-        dWg = torch.zeros(N, k * k * C_, device=DEV)           # GEMM layout [n][tap][c]
-        dbias = torch.zeros(N, device=DEV)
+    # reference: autograd of conv2d wrt weight
+    wt = torch.zeros(N, C_real, k, k, requires_grad=True)
+    y = F.conv2d(x[..., :C_real].permute(0, 3, 1, 2), wt, padding=pad)
+    y.backward(dy[:, :N].reshape(B, g.OH, g.OW, N).permute(0, 3, 1, 2))
+    return x, dy, g, wt.grad, C_real
+
+
+def _wgrad_check(case, dWg, dbias, dy, ref, C_real, what):
+    C_, N, k = case["C"], case["N"], case["k"]
+    check(dbias, dy[:, :N].sum(0), 1e-5, "bias gradient fused into wgrad %s %s" % (case, what))
+    dW = dWg.view(N, k * k, C_)[:, :, :C_real].permute(0, 2, 1).reshape(N, C_real, k, k)
+    check(dW, ref, 3e-3, "wgrad %s %s" % (case, what))
+    assert float(dWg.view(N, k * k, C_)[:, :, C_real:].abs().max() if C_real < C_ else 0.0) == 0.0
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv_wgrad(case):
+    """one problem per launch: unsplit (plain stores) and split pixel ranges (workspace slabs + ordered reduction); the
+    result is deterministic (no atomics): a second run of the same launch is bit-identical."""
+    x, dy, g, ref, C_real = _wgrad_problem(case)
+    N, k, C_ = case["N"], case["k"], case["C"]
+    outs = {}
+    for splits in (None, 1, 3, 3):
+        dWg = torch.full((N, k * k * C_), float("nan"), device=DEV)      # GEMM layout [n][tap][c]; every element is overwritten
+        dbias = torch.full((N,), float("nan"), device=DEV)
         ops.conv_wgrad(bf(dy), bf(x), g, N, dWg, splits=splits, dbias=dbias)
-        check(dbias, dy[:, :N].sum(0), 1e-5, "bias gradient fused into wgrad %s" % case)
-        dW = dWg.view(N, k * k, C_)[:, :, :C_real].permute(0, 2, 1).reshape(N, C_real, k, k)
-        # reference: autograd of conv2d wrt weight
-        wt = torch.zeros(N, C_real, k, k, requires_grad=True)
-        y = F.conv2d(x[..., :C_real].permute(0, 3, 1, 2), wt, padding=pad)
-        y.backward(dy[:, :N].reshape(B, g.OH, g.OW, N).permute(0, 3, 1, 2))
-        check(dW, wt.grad, 3e-3, "wgrad %s splits=%s" % (case, splits))
-        assert float(dWg.view(N, k * k, C_)[:, :, C_real:].abs().max() if C_real < C_ else 0.0) == 0.0
+        _wgrad_check(case, dWg, dbias, dy, ref, C_real, "splits=%s" % splits)
+        if splits in outs:
+            assert torch.equal(outs[splits][0], dWg) and torch.equal(outs[splits][1], dbias), "split reduction is not deterministic"
+        outs[splits] = (dWg, dbias)
+
+
+def test_conv_wgrad_group():
+    """the queued form: all cases (twice over, so that the queue has to cut the list into more than one launch of
+    CRIS_WGRAD_GROUP_MAX problems) in grouped launches; each result equals its own single-problem launch bit for bit."""
+    from cris.pytorch_amd import hip
+    q = ops.WgradQueue()
+    jobs = []
+    cases = WGRAD_CASES * 4
+    assert len(cases) > hip.WGRAD_GROUP_MAX
+    for case in cases:
+        x, dy, g, ref, C_real = _wgrad_problem(case)
+        N, k, C_ = case["N"], case["k"], case["C"]
+        dWg = torch.full((N, k * k * C_), float("nan"), device=DEV)
+        dbias = torch.full((N,), float("nan"), device=DEV)
+        dyb, xb = bf(dy), bf(x)
+        ops.conv_wgrad(dyb, xb, g, N, dWg, dbias=dbias, queue=q)
+        jobs.append((case, dWg, dbias, dy, ref, C_real, dyb, xb, g))
+    assert q.items, "nothing was queued"
+    q.flush()
+    assert not q.items
+    for case, dWg, dbias, dy, ref, C_real, dyb, xb, g in jobs:
+        _wgrad_check(case, dWg, dbias, dy, ref, C_real, "grouped")
+        one = torch.empty_like(dWg)
+        ob = torch.empty_like(dbias)
+        ops.conv_wgrad(dyb, xb, g, case["N"], one, splits=1, dbias=ob)
+        assert torch.equal(one, dWg) and torch.equal(ob, dbias)
 
 
 def test_pack_weights():

@@ -1,4 +1,4 @@
-"""Index arithmetic of the experimental transposing-read weight-gradient kernel (gemm.hip: conv_wgrad_tr_kernel), emulated on
+"""Index arithmetic of the transposing-read weight-gradient kernel (csrc/wgrad.hip: wgrad_tile), emulated on
 the CPU against the lane mapping of ds_read_b64_tr_b16 that was MEASURED on an MI355X (profiles/r01_ds_read_tr_probe.txt):
 the DMA role (which 16-byte chunk each lane puts where, source-side swizzle), the fragment addresses of every lane and the
 32x32x16 MFMA operand layout must together produce dW[n][k] = sum_m dY[m][n] * X[m][k] for a 128x128 tile."""
@@ -9,7 +9,7 @@ import numpy as np
 
 from conftest import ROOT
 
-MS = 64                                     # pixel rows per stage (the <64, 2> instantiation)
+MS = 32                                     # pixel rows per pipeline step (WG_MS of csrc/wgrad.hip)
 
 
 def _measured_tr_semantics():
