@@ -28,43 +28,46 @@ HBM_PEAK = 8000.0                  # GB/s spec
 
 
 def cpu_baseline(spec, batch, size, word_len, threads):
-    """The oracle (fp32 CPU restatement of the reference forward/loss + autograd backward) timed on the host cores:
-    one train forward+backward at the bench batch.  A reported baseline, not the optimisation target."""
+    """The CPU oracle (oracle/cris_oracle.py: fp32 restatement of the reference forward/loss, autograd backward) timed on the
+    host cores.  kind "port": the unmodified reference (/root/reference) does not exist on the GPU box, only its restatement
+    travels.  (i) BASELINE.json configs[0]: eval forward of one image + expression, 10 warm-up + 50 timed iterations
+    (SURVEY.md 8d-i); (ii) one train forward+backward at the bench batch.  A reported baseline, not the optimisation target."""
     from cris.pytorch_amd import arch, synth
     from oracle import cris_oracle as O
     clip, head = arch.specs_by_name(spec)
     sd = arch.synthetic_state_dict(clip, head, 0)
     img, word, mask = synth.make_batch(batch, size, word_len, 0, 0)
     torch.set_num_threads(threads)
+    img1, word1 = img[:1].contiguous(), word[:1].contiguous()
+    with torch.no_grad():
+        for _ in range(10):
+            O.cris_forward(sd, clip, head, img1, word1, None, training=False)
+        t1 = time.time()
+        n_eval = 50
+        for _ in range(n_eval):
+            O.cris_forward(sd, clip, head, img1, word1, None, training=False)
+        eval_ms = 1000.0 * (time.time() - t1) / n_eval
     leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
     t0 = time.time()
     _, _, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=1)
     loss.backward()
     dt = time.time() - t0
-    # BASELINE.json configs[0] beside it (SURVEY.md 8d-i): eval forward of ONE image + expression, a few timed iterations
-    img1, word1 = img[:1].contiguous(), word[:1].contiguous()
-    with torch.no_grad():
-        for _ in range(2):
-            O.cris_forward(sd, clip, head, img1, word1, None, training=False)
-        t1 = time.time()
-        n_eval = 5
-        for _ in range(n_eval):
-            O.cris_forward(sd, clip, head, img1, word1, None, training=False)
-        eval_ms = 1000.0 * (time.time() - t1) / n_eval
     return {"value": batch / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "1 train step (fwd+loss+bwd, fp32, no optimizer) of the CPU oracle at batch %d, %dx%d, L=%d: %.1f s"
-                      % (batch, size, size, word_len, dt),
+            "sample": "oracle port (the reference itself is absent on the GPU box): 1 train step (fwd+loss+bwd, fp32, no optimizer) "
+                      "at batch %d, %dx%d, L=%d: %.1f s; eval forward bs=1: 10 warm-up + %d timed iterations"
+                      % (batch, size, size, word_len, dt, n_eval),
             "eval_forward_bs1_ms": eval_ms}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--spec", default="r50")
     ap.add_argument("--size", type=int, default=416)
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch")
+    ap.add_argument("--word-len", type=int, default=None, help="tokens per expression (default 17; 22 with --size 480 = BASELINE configs[4])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the Python schedule (no graph / command list)")
@@ -95,7 +98,10 @@ def main():
     from cris.pytorch_amd import arch, synth, ops
     from cris.pytorch_amd.trainer import NativeTrainer
 
+    import dataclasses
     clip, head = arch.specs_by_name(args.spec)
+    word_len = args.word_len if args.word_len is not None else (22 if args.size == 480 else head.word_len)
+    head = dataclasses.replace(head, word_len=word_len)
     sd = arch.synthetic_state_dict(clip, head, 0)
     tr = NativeTrainer(clip, head, sd, dev, comm=comm, sync_bn=world > 1, use_graph=not args.no_graph, launch=args.launch)
     del sd
@@ -148,9 +154,9 @@ def main():
             "value": sps, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "CRIS-%s bf16 training step (fwd+BCE+bwd+Adam), %dx%d, per-GPU bs=%d, 17-token text, "
+            "config": {"workload": "CRIS-%s bf16 training step (fwd+BCE+bwd+Adam), %dx%d, per-GPU bs=%d, %d-token text, "
                                    "synthetic RefCOCO-shape batch resident in HBM (BASELINE.json configs[1]%s)"
-                                   % (args.spec.upper(), args.size, args.size, args.batch,
+                                   % (args.spec.upper(), args.size, args.size, args.batch, head.word_len,
                                       "" if world == 1 else "; x%d GPUs = configs[2] recipe: SyncBN + gradient all-reduce over RCCL" % world),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first_loss, "final_loss": loss_v,
                        "launch": tr.launch, "graph_error": tr.graph_error},
@@ -168,11 +174,18 @@ def main():
                                "share_of_step": (d["ms"] / timer_steps) / (1000.0 * dt / args.steps)}
             # HBM bytes per launch of the same kernel from the PMC passes of tools/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE /
             # WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction): a committed measurement, not taken live
+            for pmf in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))["kernels"]["conv_gemm_kernel"]
+                    out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
+                    out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc, eager launches)" % pmf
+                    out["roofline"]["algorithmic_bytes_per_launch"] = d["bytes"] / d["launches"]
+                    break
+                except Exception:               # noqa: BLE001
+                    pass
+            # measured parity of this path (committed with the profiles): 100-step loss trajectory vs the fp32 oracle
             try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))["kernels"]["conv_gemm_kernel"]
-                out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
-                out["roofline"]["traffic_source"] = "profiles/r01_hbm_traffic.json (rocprofv3 --pmc, eager launches)"
-                out["roofline"]["algorithmic_bytes_per_launch"] = d["bytes"] / d["launches"]
+                out["config"]["parity"] = json.load(open(os.path.join(ROOT, "profiles", "parity_r02.json")))
             except Exception:               # noqa: BLE001
                 pass
             out["roofline"]["timing"] = "HIP events around each launch, %d-step eager pass after the timed region" % timer_steps

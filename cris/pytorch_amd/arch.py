@@ -84,8 +84,6 @@ HEAD_TINY = HeadSpec(word_len=9, fpn_in=(128, 256, 128), fpn_out=(64, 128, 256),
 
 def specs_by_name(name: str):
     name = name.lower()
-    if name == "tiny" and os.environ.get("CRIS_TEST_TINY_DROPOUT0") == "1":      # test hook (tests/test_dist_gpu.py)
-        return CLIP_TINY, dataclasses.replace(HEAD_TINY, dropout=0.0)
     if name in ("r50", "cris_r50"):
         return CLIP_R50, HEAD_R50
     if name in ("r101", "cris_r101"):

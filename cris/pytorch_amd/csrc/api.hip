@@ -26,6 +26,8 @@ extern "C" int cris_sizeof(const char* name) {
     S(cris_bn_bwd_params);
     S(cris_ln_fwd_params);
     S(cris_ln_bwd_params);
+    S(cris_sum_entry);
+    S(cris_sum_group);
     S(cris_attn_params);
     S(cris_adam_desc);
     S(cris_p2p_params);

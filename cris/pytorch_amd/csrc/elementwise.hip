@@ -432,15 +432,28 @@ extern "C" int cris_embed_fwd(const int64_t* tokens, const float* table, const f
     CRIS_LAUNCH_CHECK();
     return 0;
 }
+// Deterministic (no atomics): the thread of row r, column d adds up every row that holds the same token (same position) in
+// row order and only the FIRST such row stores the sum - B*L is 136 / 176 rows, the scan is free.
 __global__ void embed_bwd_kernel(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos) {
     const long total = (long)Bn * L * D;
+    const int R = Bn * L;
     GRID_STRIDE(idx, total) {
         const int d = (int)(idx % D);
-        const long r = idx / D;
-        const int l = (int)(r % L);
-        const float g = dx[idx];
-        atomicAdd(dtable + (size_t)tokens[r] * D + d, g);
-        atomicAdd(dpos + (size_t)l * D + d, g);
+        const int r = (int)(idx / D);
+        const int64_t tok = tokens[r];
+        bool first = true;
+        for (int q = 0; q < r; ++q) first = first && tokens[q] != tok;
+        if (first) {
+            float a = 0.f;
+            for (int q = r; q < R; ++q)
+                if (tokens[q] == tok) a += dx[(size_t)q * D + d];
+            dtable[(size_t)tok * D + d] = a;
+        }
+        if (r < L) {                                   // position r: rows r, r + L, r + 2L, ...
+            float a = 0.f;
+            for (int b = 0; b < Bn; ++b) a += dx[((size_t)b * L + r) * D + d];
+            dpos[(size_t)r * D + d] = a;
+        }
     }
 }
 extern "C" int cris_embed_bwd(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos,
@@ -601,7 +614,7 @@ extern "C" int cris_dynconv_fwd(const cris_bf16* x, int Bn, int H, int W, int C,
 
 __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const bf16_t* __restrict__ x, const float* __restrict__ dpred, int H, int W, int C,
                                                           const float* __restrict__ wb, int ldwb, bf16_t* __restrict__ dx,
-                                                          float* __restrict__ dwb, int pix_per_block) {
+                                                          float* __restrict__ dwb_part, int pix_per_block) {
     extern __shared__ float sdw[];              // [C*9 + 1]
     const int b = blockIdx.y;
     const int LP = C >> 3;
@@ -648,23 +661,46 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const bf16_t* __restri
             }
         st8bf(dx + ((size_t)b * HW + pix) * C + cl * 8, gx);
     }
+    // block sums in a fixed order (no atomics): lanes of one wave that hold the same channels combine by shuffles, the four
+    // waves then add into LDS one after the other; the block stores its row of the partials table
+    for (int o = LP; o < 64; o <<= 1) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
+        for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(&sdw[(cl * 8 + j) * 9 + t], dw[t][j]);
-    if (cl == 0) atomicAdd(&sdw[C * 9], dbias);
-    __syncthreads();
-    for (int i = threadIdx.x; i < C * 9 + 1; i += 256) atomicAdd(dwb + (size_t)b * ldwb + i, sdw[i]);
+            for (int j = 0; j < 8; ++j) dw[t][j] += __shfl_xor(dw[t][j], o, 64);
+        dbias += __shfl_xor(dbias, o, 64);
+    }
+    const int lane = threadIdx.x & 63;
+    for (int w = 0; w < 4; ++w) {
+        if ((int)(threadIdx.x >> 6) == w && lane < LP) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) sdw[(cl * 8 + j) * 9 + t] += dw[t][j];
+            if (cl == 0) sdw[C * 9] += dbias;
+        }
+        __syncthreads();
+    }
+    float* part = dwb_part + ((size_t)blockIdx.x * gridDim.y + b) * ldwb;
+    for (int i = threadIdx.x; i < ldwb; i += 256) part[i] = i < C * 9 + 1 ? sdw[i] : 0.f;      // padding columns: zeros
 }
 
+static int dynconv_bwd_blocks(int HW) { return cris_cdiv(HW, 512); }
+extern "C" long cris_dynconv_bwd_ws_floats(int Bn, int H, int W, int ldwb) { return (long)dynconv_bwd_blocks(H * W) * Bn * ldwb; }
+void cris_launch_sum_partials(const float* part, int nparts, int ncol, float* out, hipStream_t stream);      // norm.hip
+
 extern "C" int cris_dynconv_bwd(const cris_bf16* x, const float* dpred, int Bn, int H, int W, int C, const float* wb, int ldwb,
-                                cris_bf16* dx, float* dwb, void* stream) {
+                                cris_bf16* dx, float* dwb, float* ws, void* stream) {
     const int LP = C / 8;
-    CRIS_CHECK_ARG(x && dpred && wb && dx && dwb && !(C & 7) && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "bad args");
+    CRIS_CHECK_ARG(x && dpred && wb && dx && dwb && ws && !(C & 7) && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0 && ldwb >= C * 9 + 1,
+                   "bad args");
     const int ppb = 512;
-    dim3 grid(cris_cdiv(H * W, ppb), Bn);
+    dim3 grid(dynconv_bwd_blocks(H * W), Bn);
     hipLaunchKernelGGL(dynconv_bwd_kernel, grid, dim3(256), (size_t)(C * 9 + 1) * sizeof(float), (hipStream_t)stream, x, dpred, H, W,
-                       C, wb, ldwb, dx, dwb, ppb);
+                       C, wb, ldwb, dx, ws, ppb);
+    CRIS_LAUNCH_CHECK();
+    // dwb[b][i] += the blocks' partial rows in block order (deterministic); padding columns of the table are never read
+    cris_launch_sum_partials(ws, grid.x, Bn * ldwb, dwb, (hipStream_t)stream);
     CRIS_LAUNCH_CHECK();
     return 0;
 }
@@ -692,21 +728,37 @@ extern "C" int cris_mask_resize_nearest(const float* mask, int Bn, int IH, int I
     return 0;
 }
 
-__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* x, const float* t, long n, float* loss_accum) {
-    __shared__ float sw[4];
+// ONE block of 1024 threads (the loss is 86 k - 115 k elements: launch latency, not bandwidth), fixed summation order
+__global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* x, const float* t, long n, float* loss) {
+    __shared__ float sw[16];
     float s = 0.f;
-    GRID_STRIDE(i, n) {
+    const long n4 = n >> 2;
+    for (long i = threadIdx.x; i < n4; i += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+        const float4 y = *reinterpret_cast<const float4*>(t + i * 4);
+        s += fmaxf(v.x, 0.f) - v.x * y.x + log1pf(__expf(-fabsf(v.x)));
+        s += fmaxf(v.y, 0.f) - v.y * y.y + log1pf(__expf(-fabsf(v.y)));
+        s += fmaxf(v.z, 0.f) - v.z * y.z + log1pf(__expf(-fabsf(v.z)));
+        s += fmaxf(v.w, 0.f) - v.w * y.w + log1pf(__expf(-fabsf(v.w)));
+    }
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 1024) {
         const float v = x[i];
         s += fmaxf(v, 0.f) - v * t[i] + log1pf(__expf(-fabsf(v)));
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss_accum, (sw[0] + sw[1] + sw[2] + sw[3]) / (float)n);
+    if (threadIdx.x == 0) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) a += sw[w];
+        loss[0] = a / (float)n;
+    }
 }
-extern "C" int cris_bce_fwd(const float* logits, const float* target, long n, float* loss_accum, void* stream) {
-    CRIS_CHECK_ARG(logits && target && loss_accum && n > 0, "bad args");
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(cris_grid_1d(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, logits, target, n, loss_accum);
+extern "C" int cris_bce_fwd(const float* logits, const float* target, long n, float* loss, void* stream) {
+    CRIS_CHECK_ARG(logits && target && loss && n > 0, "bad args");
+    CRIS_CHECK_ARG((uintptr_t)logits % 16 == 0 && (uintptr_t)target % 16 == 0, "operands must be 16-byte aligned");
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, target, n, loss);
     CRIS_LAUNCH_CHECK();
     return 0;
 }
@@ -724,30 +776,42 @@ extern "C" int cris_bce_bwd(const float* logits, const float* target, long n, co
     return 0;
 }
 
-__global__ __launch_bounds__(256) void train_metric_kernel(const float* x, const float* t, int Bn, int HW, float thr, float pr_iou, float* out) {
-    __shared__ float si[4], su[4];
-    const int b = blockIdx.x;
-    float inter = 0.f, uni = 0.f;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-        const bool o = 1.f / (1.f + __expf(-x[(size_t)b * HW + i])) >= thr;
-        const bool g = t[(size_t)b * HW + i] != 0.f;
-        inter += (o && g) ? 1.f : 0.f;
-        uni += (o || g) ? 1.f : 0.f;
+// ONE block of 1024 threads walks the samples in order (counts are exact integers, the mean over samples is summed in sample
+// order): deterministic, and 8 x 10816 elements are launch-latency sized anyway
+__global__ __launch_bounds__(1024) void train_metric_kernel(const float* x, const float* t, int Bn, int HW, float thr, float pr_iou, float* out) {
+    __shared__ float si[16], su[16];
+    float iou_sum = 0.f, pr_sum = 0.f;
+    for (int b = 0; b < Bn; ++b) {
+        float inter = 0.f, uni = 0.f;
+        for (int i = threadIdx.x; i < HW; i += 1024) {
+            const bool o = 1.f / (1.f + __expf(-x[(size_t)b * HW + i])) >= thr;
+            const bool g = t[(size_t)b * HW + i] != 0.f;
+            inter += (o && g) ? 1.f : 0.f;
+            uni += (o || g) ? 1.f : 0.f;
+        }
+        inter = wave_sum(inter);
+        uni = wave_sum(uni);
+        __syncthreads();                                  // previous sample's table consumed
+        if ((threadIdx.x & 63) == 0) { si[threadIdx.x >> 6] = inter; su[threadIdx.x >> 6] = uni; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = 0.f, u = 0.f;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) { a += si[w]; u += su[w]; }
+            const float iou = a / (u + 1e-6f);
+            iou_sum += iou;
+            pr_sum += iou > pr_iou ? 1.f : 0.f;
+        }
     }
-    inter = wave_sum(inter);
-    uni = wave_sum(uni);
-    if ((threadIdx.x & 63) == 0) { si[threadIdx.x >> 6] = inter; su[threadIdx.x >> 6] = uni; }
-    __syncthreads();
     if (threadIdx.x == 0) {
-        const float iou = (si[0] + si[1] + si[2] + si[3]) / (su[0] + su[1] + su[2] + su[3] + 1e-6f);
-        atomicAdd(out, 100.f * iou / (float)Bn);
-        atomicAdd(out + 1, (iou > pr_iou ? 100.f : 0.f) / (float)Bn);
+        out[0] = 100.f * iou_sum / (float)Bn;
+        out[1] = 100.f * pr_sum / (float)Bn;
     }
 }
 extern "C" int cris_train_metric(const float* logits, const float* target, int Bn, int HW, float thr, float pr_iou, float* out,
                                  void* stream) {
     CRIS_CHECK_ARG(logits && target && out, "bad args");
-    hipLaunchKernelGGL(train_metric_kernel, dim3(Bn), dim3(256), 0, (hipStream_t)stream, logits, target, Bn, HW, thr, pr_iou, out);
+    hipLaunchKernelGGL(train_metric_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, target, Bn, HW, thr, pr_iou, out);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -577,7 +577,7 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight packing (batched) and column sums
+// weight packing (batched)
 // ------------------------------------------------------------------------------------------------
 #define PACK_ELEMS 4096     // destination elements handled per block
 
@@ -649,31 +649,6 @@ extern "C" int cris_pack_block_elems(void) { return PACK_ELEMS; }
 extern "C" int cris_pack_weights(const cris_pack_desc* dev_table, int n_desc, int total_blocks, void* stream) {
     CRIS_CHECK_ARG(dev_table && n_desc > 0 && total_blocks > 0, "empty table");
     hipLaunchKernelGGL(pack_weights_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dev_table, n_desc);
-    CRIS_LAUNCH_CHECK();
-    return 0;
-}
-
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ldx, int coff, int M, int N,
-                                                     float* __restrict__ out, int rows_per_block) {
-    // block (bx: column group of 256, by: row chunk); thread = one column, coalesced across the block
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const int mb = blockIdx.y * rows_per_block;
-    const int me = min(M, mb + rows_per_block);
-    float s = 0.f;
-    for (int m = mb; m < me; ++m) s += bf2f(x[(size_t)m * ldx + coff + n]);
-    atomicAdd(out + n, s);
-}
-
-extern "C" int cris_colsum_bf16(const cris_bf16* x, int ldx, int coff, int M, int N, float* out, void* stream) {
-    CRIS_CHECK_ARG(x && out && M > 0 && N > 0, "bad args");
-    const int gx = cris_cdiv(N, 256);
-    int gy = 2048 / gx;
-    if (gy < 1) gy = 1;
-    int rpb = cris_cdiv(M, gy);
-    if (rpb < 8) rpb = 8;
-    gy = cris_cdiv(M, rpb);
-    hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, x, ldx, coff, M, N, out, rpb);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

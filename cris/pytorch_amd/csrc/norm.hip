@@ -1,6 +1,6 @@
 // BatchNorm (training statistics) and LayerNorm kernels for gfx950.  All HBM-bound: 16-byte vector
-// accesses (8 bf16 channels per lane), per-channel reductions accumulated in registers then LDS then one
-// global atomic per channel per block.
+// accesses (8 bf16 channels per lane), per-channel reductions accumulated in registers, then LDS (fixed order), then one
+// partial row per block that a second small launch sums in block order - no atomics, results are deterministic.
 #include "common.h"
 #include "../../../include/cris_hip.h"
 
@@ -110,6 +110,9 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
         for (int j = 1; j < 16; ++j) a += sh[j][cl];
         out[c] += a;
     }
+}
+void cris_launch_sum_partials(const float* part, int nparts, int ncol, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, stream, part, nparts, ncol, out);
 }
 extern "C" int cris_sum_partials(const float* part, int nparts, int ncol, float* out, void* stream) {
     CRIS_CHECK_ARG(part && out && nparts > 0 && ncol > 0, "bad args");
@@ -350,8 +353,7 @@ extern "C" int cris_bn_apply(const cris_bn_apply_params* pp, void* stream) {
 // BN backward: reduce (sum g, sum g*xhat [, branch 2]) then apply
 // ------------------------------------------------------------------------------------------------
 // gradient entering the BN output at full-resolution row m, channels c0..c0+7; also xhat (and xhat2)
-__device__ __forceinline__ void bn_bwd_point(const cris_bn_bwd_params& p, int m, int c0, float* g, float* xh, float* xh2,
-                                             bool want_dmul) {
+__device__ __forceinline__ void bn_bwd_point(const cris_bn_bwd_params& p, int m, int c0, float* g, float* xh, float* xh2) {
     float y[8], mean[8], inv[8];
     load8bf(p.y + (size_t)m * p.ldy + p.y_coff + c0, y);
     load8f(p.mean + c0, mean);
@@ -397,17 +399,8 @@ __device__ __forceinline__ void bn_bwd_point(const cris_bn_bwd_params& p, int m,
     }
     if (p.mul) {
         const int b = m / HW;
-        float mu[8], sc[8], sh[8];
+        float mu[8];
         load8f(p.mul + (size_t)b * p.C + c0, mu);
-        if (want_dmul && p.dmul) {
-            load8f(p.scale + c0, sc);
-            load8f(p.shift + c0, sh);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float a = fmaxf(y[j] * sc[j] + sh[j], 0.f);
-                if (a > 0.f) atomicAdd(p.dmul + (size_t)b * p.C + c0 + j, dz[j] * a);
-            }
-        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) dz[j] *= mu[j];
     }
@@ -436,7 +429,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_pa
         if (rsub < RS) {
             for (int m = r0 + rsub; m < r1; m += RS) {
                 float g[8], xh[8], xh2[8];
-                bn_bwd_point(p, m, cv * 8, g, xh, xh2, true);
+                bn_bwd_point(p, m, cv * 8, g, xh, xh2);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     a0[j] += g[j];
@@ -465,11 +458,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_pa
                 s3 += spart[2][r * ncol + c];
             }
             const int col = cvb * 8 + c;
-            atomicAdd(p.sums + col, s0);
-            atomicAdd(p.sums + p.C + col, s1);
+            float* part = p.part + (size_t)blockIdx.x * (p.y2 ? 4 : 2) * p.C;      // this block's row of the partials table
+            part[col] = s0;
+            part[p.C + col] = s1;
             if (p.y2) {
-                atomicAdd(p.sums + 2 * p.C + col, s0);
-                atomicAdd(p.sums + 3 * p.C + col, s3);
+                part[2 * p.C + col] = s0;
+                part[3 * p.C + col] = s3;
             }
         }
     }
@@ -576,11 +570,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_b
                 if (Y2) s3 += spart[2][r * ncol + c];
             }
             const int col = cvb * 8 + c;
-            atomicAdd(p.sums + col, s0);
-            atomicAdd(p.sums + p.C + col, s1);
+            float* part = p.part + (size_t)blockIdx.x * (Y2 ? 4 : 2) * p.C;
+            part[col] = s0;
+            part[p.C + col] = s1;
             if (Y2) {
-                atomicAdd(p.sums + 2 * p.C + col, s0);
-                atomicAdd(p.sums + 3 * p.C + col, s3);
+                part[2 * p.C + col] = s0;
+                part[3 * p.C + col] = s3;
             }
         }
     }
@@ -602,20 +597,54 @@ static bn_bwd_reduce_fn bn_bwd_reduce_fast_table(int mask, bool y2, bool pool) {
     return bn_bwd_reduce_fast_kernel<0, false, false>;
 }
 
+// gradient of the per-sample multiplier (FPN: f5 = relu(bn(y)) * state, model/layers.py:289): dmul[b][c] = sum over the pixels of
+// sample b of dz * relu(bn(y)).  One thread per (sample, 8 channels), pixels in order: deterministic.
+__global__ __launch_bounds__(256) void bn_dmul_kernel(const cris_bn_bwd_params p) {
+    const int CV = p.C >> 3, HW = p.H * p.W;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= p.Bn * CV) return;
+    const int b = idx / CV, c0 = (idx - b * CV) * 8;
+    float sc[8], sh[8], acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    load8f(p.scale + c0, sc);
+    load8f(p.shift + c0, sh);
+    for (int r = 0; r < HW; ++r) {
+        const size_t m = (size_t)b * HW + r;
+        float y[8], dz[8];
+        load8bf(p.y + m * p.ldy + p.y_coff + c0, y);
+        load8bf(p.dz + m * p.lddz + p.dz_coff + c0, dz);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += dz[j] * fmaxf(y[j] * sc[j] + sh[j], 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p.dmul[(size_t)b * p.C + c0 + j] = acc[j];
+}
+
+// row blocks of the reduction = rows of the partials table
+static int bn_bwd_geometry(int M, int* rows_per_block) {
+    // every block writes one partial row of 2C (4C) sums: few, fat blocks
+    static const int max_blocks = cris_env_int("CRIS_BN_RED_BLOCKS", 512);
+    static const int min_rows = cris_env_int("CRIS_BN_RED_ROWS", 32);
+    int rpb = cris_cdiv(M, max_blocks);
+    if (rpb < min_rows) rpb = min_rows;
+    *rows_per_block = rpb;
+    return cris_cdiv(M, rpb);
+}
+extern "C" long cris_bn_bwd_ws_floats(const cris_bn_bwd_params* p) {
+    int rpb;
+    return (long)bn_bwd_geometry(p->Bn * p->H * p->W, &rpb) * (p->y2 ? 4 : 2) * p->C;
+}
+
 extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     const cris_bn_bwd_params& p = *pp;
-    CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums, "null operand");
+    CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums && p.part, "null operand");
     CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 8192, "C");
     CRIS_CHECK_ARG(!p.relu || p.pool || p.z || (p.scale && p.shift), "relu mask source");
     CRIS_CHECK_ARG(!p.pool || (p.scale && p.shift && !p.y2 && !p.mul), "pool backward needs scale/shift, plain BN");
+    CRIS_CHECK_ARG(!p.mul || !p.dmul || (p.relu && !p.pool && !p.y2 && p.scale && p.shift && (p.lddz & 7) == 0 && (p.dz_coff & 7) == 0),
+                   "multiplier gradient: plain BN + ReLU");
     const int M = p.Bn * p.H * p.W;
-    // every block ends with 2C (4C) global atomics onto the same addresses: few, fat blocks
-    static const int max_blocks = cris_env_int("CRIS_BN_RED_BLOCKS", 512);
-    static const int min_rows = cris_env_int("CRIS_BN_RED_ROWS", 32);
-    int blocks = max_blocks;
-    int rpb = cris_cdiv(M, blocks);
-    if (rpb < min_rows) rpb = min_rows;
-    blocks = cris_cdiv(M, rpb);
+    int rpb;
+    const int blocks = bn_bwd_geometry(M, &rpb);
     static const int use_fast = cris_env_int("CRIS_BN_RED_FAST", 1);
     bn_bwd_reduce_fn fast = nullptr;
     if (use_fast && !p.mul && (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && (p.lddz & 7) == 0 && (p.dz_coff & 7) == 0 &&
@@ -623,13 +652,16 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
         const int mask = !p.relu ? 0 : (!p.pool && (p.y2 || p.z)) ? 1 : 2;
         if (mask != 1 || ((p.ldz & 7) == 0 && (p.z_coff & 7) == 0)) fast = bn_bwd_reduce_fast_table(mask, p.y2 != nullptr, p.pool != 0);
     }
-    if (fast) {
-        hipLaunchKernelGGL(fast, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, rpb);
-        CRIS_LAUNCH_CHECK();
-        return 0;
-    }
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, rpb);
+    hipLaunchKernelGGL(fast ? fast : bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, rpb);
     CRIS_LAUNCH_CHECK();
+    // the blocks' partial rows, summed in block order (deterministic) into the [2C] ([4C]) sums (+=)
+    const int ncol = (p.y2 ? 4 : 2) * p.C;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, blocks, ncol, p.sums);
+    CRIS_LAUNCH_CHECK();
+    if (p.mul && p.dmul) {
+        hipLaunchKernelGGL(bn_dmul_kernel, dim3(cris_cdiv((long)p.Bn * (p.C >> 3), 256)), dim3(256), 0, (hipStream_t)stream, p);
+        CRIS_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -642,7 +674,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_par
         const int m = (int)(idx / CV);
         const int c0 = cv * 8;
         float g[8], xh[8], xh2[8];
-        bn_bwd_point(p, m, c0, g, xh, xh2, false);
+        bn_bwd_point(p, m, c0, g, xh, xh2);
         float s0[8], s1[8], sc[8], o[8];
         load8f(p.sums + c0, s0);
         load8f(p.sums + p.C + c0, s1);
@@ -894,34 +926,79 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p)
             }
         }
     }
-    // parameter gradients: registers -> LDS (4 waves) -> global atomics
+    // parameter gradients: registers -> LDS, the 4 waves adding one after the other (fixed order) -> this block's row of the
+    // partials table [grid][dgamma C | dbeta C]; cris_sum_tables adds the rows in block order (deterministic, no atomics)
+    for (int w = 0; w < 4; ++w) {
+        if ((int)(threadIdx.x >> 6) == w) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c0 = (lane + 64 * i) * 8;
-        if (c0 < p.C) {
+            for (int i = 0; i < LN_MAXV; ++i) {
+                const int c0 = (lane + 64 * i) * 8;
+                if (c0 < p.C) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                atomicAdd(&sg[0][c0 + j], dga[i][j]);
-                atomicAdd(&sg[1][c0 + j], dbe[i][j]);
+                    for (int j = 0; j < 8; ++j) {
+                        sg[0][c0 + j] += dga[i][j];
+                        sg[1][c0 + j] += dbe[i][j];
+                    }
+                }
             }
         }
+        __syncthreads();
     }
-    __syncthreads();
+    float* part = p.part + (size_t)blockIdx.x * 2 * p.C;
     for (int c = threadIdx.x; c < p.C; c += 256) {
-        if (p.dgamma) atomicAdd(p.dgamma + c, sg[0][c]);
-        if (p.dbeta) atomicAdd(p.dbeta + c, sg[1][c]);
+        part[c] = sg[0][c];
+        part[p.C + c] = sg[1][c];
     }
 }
 
+static int ln_bwd_grid(int rows) {
+    static const int max_grid = cris_env_int("CRIS_LN_BWD_BLOCKS", 256);
+    return cris_grid_1d(rows, 4, max_grid);
+}
+extern "C" int cris_ln_bwd_parts(int rows) { return ln_bwd_grid(rows); }
+
 extern "C" int cris_ln_bwd(const cris_ln_bwd_params* pp, void* stream) {
     const cris_ln_bwd_params& p = *pp;
-    CRIS_CHECK_ARG(p.x && p.gamma && p.mean && p.rstd && p.dx && p.rows > 0, "null operand");
+    CRIS_CHECK_ARG(p.x && p.gamma && p.mean && p.rstd && p.dx && p.part && p.rows > 0, "null operand");
     CRIS_CHECK_ARG(p.dy || p.dypos || p.dout_f32, "no incoming gradient");
     CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 64 * 8 * LN_MAXV && (p.ldx & 7) == 0, "C must be a multiple of 8, <= 2048");
     CRIS_CHECK_ARG(!p.dx_accum || p.dx_f32, "accumulate only into fp32");
-    static const int max_grid = cris_env_int("CRIS_LN_BWD_BLOCKS", 256);
-    const int grid = cris_grid_1d(p.rows, 4, max_grid);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_grid(p.rows)), dim3(256), 0, (hipStream_t)stream, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grouped ordered column sums: out[c] = sum_p part[p*ld + c], p = 0 .. nparts-1 in order, for up to CRIS_SUM_GROUP_MAX
+// tables in one launch (LayerNorm parameter gradients of a whole arena stage; table passed by value)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sum_group_kernel(const cris_sum_group g) {
+    __shared__ float sh[4][64];
+    int ei = 0;                                    // block-uniform; entries >= g.n hold the total block count
+#pragma unroll
+    for (int i = 1; i < CRIS_SUM_GROUP_MAX; ++i) ei += g.block_start[i] <= (int)blockIdx.x ? 1 : 0;
+    const cris_sum_entry e = g.e[ei];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = (blockIdx.x - g.block_start[ei]) * 64 + cl;
+    float a = 0.f;
+    if (c < e.ncol)
+        for (int i = pl; i < e.nparts; i += 4) a += e.part[(size_t)i * e.ld + c];
+    sh[pl][cl] = a;
+    __syncthreads();
+    if (pl == 0 && c < e.ncol) e.out[c] = (sh[0][cl] + sh[1][cl]) + (sh[2][cl] + sh[3][cl]);
+}
+
+extern "C" int cris_sum_tables(const cris_sum_group* gp, void* stream) {
+    CRIS_CHECK_ARG(gp && gp->n > 0 && gp->n <= CRIS_SUM_GROUP_MAX, "1 .. CRIS_SUM_GROUP_MAX tables per launch");
+    cris_sum_group g = *gp;
+    int start = 0;
+    for (int i = 0; i < g.n; ++i) {
+        CRIS_CHECK_ARG(g.e[i].part && g.e[i].out && g.e[i].nparts > 0 && g.e[i].ncol > 0 && g.e[i].ld >= g.e[i].ncol, "bad table");
+        g.block_start[i] = start;
+        start += cris_cdiv(g.e[i].ncol, 64);
+    }
+    for (int i = g.n; i <= CRIS_SUM_GROUP_MAX; ++i) g.block_start[i] = start;
+    hipLaunchKernelGGL(sum_group_kernel, dim3(start), dim3(256), 0, (hipStream_t)stream, g);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

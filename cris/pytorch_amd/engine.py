@@ -102,7 +102,7 @@ class Engine:
         # the visual encoder until the neck: it runs on a second HIP stream, forward and backward, underneath the convs
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue)
-        self._wq = ops.WgradQueue()
+        self._wq, self._sq = ops.WgradQueue(), ops.SumQueue()
         # Folding a BatchNorm's backward reduction into its consumer conv's input-gradient GEMM epilogue is implemented and
         # parity-tested, but MEASURED SLOWER (21.0 -> 22.0 ms/step at R50/416/B=8: the per-element y reads and extra
         # arithmetic lengthen every block's epilogue by more than the separate reduction pass costs): off by default.
@@ -273,6 +273,12 @@ class Engine:
         t = (self.zeros if zero else self.empty)(Bn * H * W, ld, dtype=dtype)
         return Act(t, Bn, H, W, C, ld)
 
+    def _flush_queues(self):
+        """launch what backward has queued so far on the current stream: grouped weight gradients and the ordered sums of the
+        LayerNorm parameter-gradient partials"""
+        self._wq.flush()
+        self._sq.flush()
+
     def drop(self, layer, site):
         p = self.head.dropout if self.training else 0.0
         return Drop(p, self.seed, layer * 8 + site, self.seed_dev) if p > 0 else NO_DROP
@@ -399,7 +405,7 @@ class Engine:
             out.aux["stats"] = ops.colstats(out.t, out.M, C, 32, self.dev, ldx=out.ld, coff=out.coff)
         if not self.training:
             return out
-        dmul = self.zeros(y.Bn, C) if mul is not None else None
+        dmul = self.empty(y.Bn, C, dtype=F32) if mul is not None else None
         out.aux["dmul"] = dmul
         if relu and not pool and ident is None and y2 is None and mul is None and out.coff == 0 and out.C == C:
             # a consumer conv may fold this BatchNorm's backward reduction into its input-gradient GEMM (gemm(fuse_bn_bwd))
@@ -479,7 +485,7 @@ class Engine:
                 ops.ln_bwd(x.t, gamma, mean, rstd, rows, C, dx, ldx=x.ld, dy=None if (y is None or y.g is None) else y.g,
                            dypos=None if (ypos is None or ypos.g is None) else ypos.g,
                            dout_f32=None if outs is None else outs.g, dgamma=self.G[pfx + ".weight"], dbeta=self.G[pfx + ".bias"],
-                           dx_accum=accum, in_relu=in_relu, in_drop=in_drop, out_drop=out_drop)
+                           dx_accum=accum, in_relu=in_relu, in_drop=in_drop, out_drop=out_drop, queue=self._sq)
 
             self.tape.append(bwd)
         return y, ypos, outs
@@ -836,7 +842,7 @@ class Engine:
     def forward(self, img, word, mask=None, training=True, seed=0, taps: Optional[dict] = None):
         self.training, self.seed = training, int(seed) & 0xFFFFFFFF
         self.tape = []
-        self._wq = ops.WgradQueue()                      # (drops problems of a forward whose backward never ran)
+        self._wq, self._sq = ops.WgradQueue(), ops.SumQueue()      # (drops what a forward without backward left queued)
         self._dgrad_outT = None
         self._stage_marks = {}
         Act._engine = self
@@ -892,7 +898,7 @@ class Engine:
         B, _, OH, OW = pred.shape
         msk = self.empty(B, 1, OH, OW, dtype=F32)
         ops.mask_resize_nearest(mask.contiguous().float(), OH, OW, msk)
-        loss = self.zeros(1)
+        loss = self.empty(1, dtype=F32)
         ops.bce_fwd(pred, msk, loss)
         c = self.head.vis_dim // 2
 
@@ -920,7 +926,7 @@ class Engine:
         head_start = max(t1, v1)                        # neck / decoder / projector closures: main stream
         def fire(i):
             if i in marks:
-                self._wq.flush()                         # the stage's queued weight gradients (current stream)
+                self._flush_queues()                         # the stage's queued weight gradients (current stream)
                 if on_stage_done is not None:
                     for st in marks[i]:
                         on_stage_done(st)
@@ -928,7 +934,7 @@ class Engine:
         for i in range(len(self.tape) - 1, head_start - 1, -1):
             self.tape[i]()
             fire(i)
-        self._wq.flush()
+        self._flush_queues()
         # the two encoders' backward passes are independent: text on the side stream, visual on the launch stream
         main = torch.cuda.current_stream()
         if self.side is not None:
@@ -936,19 +942,19 @@ class Engine:
             with torch.cuda.stream(self.side):
                 for i in range(t1 - 1, t0 - 1, -1):
                     self.tape[i]()
-                self._wq.flush()
+                self._flush_queues()
                 if on_stage_done is not None:
                     on_stage_done(4)                     # issued from the side stream: the exchange waits for it only
         else:
             for i in range(t1 - 1, t0 - 1, -1):
                 self.tape[i]()
-            self._wq.flush()
+            self._flush_queues()
             if on_stage_done is not None:
                 on_stage_done(4)
         for i in range(v1 - 1, v0 - 1, -1):
             self.tape[i]()
             fire(i)                                      # visual stages 3, 2, 1, 0 as their layer groups finish
-        self._wq.flush()
+        self._flush_queues()
         if self.side is not None:
             ops.torch_op(lambda: main.wait_stream(self.side))
         self._zneed_last = max(self._zneed_last, self._zneed)

@@ -77,7 +77,7 @@ class BnBwdParams(C.Structure):
                 ("y2", P), ("ldy2", I), ("y2_coff", I),
                 ("mean2", P), ("invstd2", P), ("scale2", P),
                 ("mul", P),
-                ("sums", P),
+                ("sums", P), ("part", P),
                 ("dmul", P),
                 ("dy", P), ("lddy", I), ("dy_coff", I),
                 ("dy2", P), ("lddy2", I), ("dy2_coff", I),
@@ -108,7 +108,7 @@ class LnBwdParams(C.Structure):
                 ("gamma", P),
                 ("mean", P), ("rstd", P),
                 ("dy", P), ("dypos", P), ("dout_f32", P),
-                ("dgamma", P), ("dbeta", P),
+                ("part", P),
                 ("dx", P), ("dx_f32", I), ("dx_accum", I),
                 ("rows", I), ("C", I),
                 ("in_relu", I),
@@ -137,6 +137,17 @@ class AttnParams(C.Structure):
                 ("drop_seed_dev", P)]
 
 
+SUM_GROUP_MAX = 64
+
+
+class SumEntry(C.Structure):
+    _fields_ = [("part", P), ("out", P), ("nparts", I), ("ncol", I), ("ld", I), ("pad_", I)]
+
+
+class SumGroup(C.Structure):
+    _fields_ = [("n", I), ("block_start", I * (SUM_GROUP_MAX + 1)), ("e", SumEntry * SUM_GROUP_MAX)]
+
+
 class AdamDesc(C.Structure):
     _fields_ = [("p", P), ("g", P), ("m", P), ("v", P),
                 ("n", L),
@@ -157,7 +168,7 @@ class P2PParams(C.Structure):
 STRUCTS = {
     "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_wgrad_group": WgradGroup, "cris_pack_desc": PackDesc,
     "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
-    "cris_ln_bwd_params": LnBwdParams, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams,
+    "cris_ln_bwd_params": LnBwdParams, "cris_sum_entry": SumEntry, "cris_sum_group": SumGroup, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams,
 }
 
 # name -> (restype, argtypes); struct launchers take (struct*, stream)
@@ -174,7 +185,6 @@ _SIGS = {
     "cris_pack_weights": (I, [P, I, I, P]),
     "cris_pack_blocks": (I, [P]),
     "cris_pack_block_elems": (I, []),
-    "cris_colsum_bf16": (I, [P, I, I, I, I, P, P]),
     "cris_conv_gemm_stat_rows": (I, [P]),
     "cris_bn_partials_rows": (I, [I]),
     "cris_sum_partials": (I, [P, I, I, P, P]),
@@ -187,6 +197,9 @@ _SIGS = {
     "cris_bn_apply": (I, [P, P]),
     "cris_bn_bwd_reduce": (I, [P, P]),
     "cris_bn_bwd_apply": (I, [P, P]),
+    "cris_bn_bwd_ws_floats": (L, [P]),
+    "cris_ln_bwd_parts": (I, [I]),
+    "cris_sum_tables": (I, [P, P]),
     "cris_ln_fwd": (I, [P, P]),
     "cris_ln_bwd": (I, [P, P]),
     "cris_attn_fwd": (I, [P, P]),
@@ -215,7 +228,8 @@ _SIGS = {
     "cris_posresize_bwd": (I, [P, P, I, I, I, P, P]),
     "cris_batch_rowsum": (I, [P, I, I, I, I, P, P]),
     "cris_dynconv_fwd": (I, [P, I, I, I, I, P, I, P, P]),
-    "cris_dynconv_bwd": (I, [P, P, I, I, I, I, P, I, P, P, P]),
+    "cris_dynconv_bwd": (I, [P, P, I, I, I, I, P, I, P, P, P, P]),
+    "cris_dynconv_bwd_ws_floats": (L, [I, I, I, I]),
     "cris_mask_resize_nearest": (I, [P, I, I, I, I, I, P, P]),
     "cris_bce_fwd": (I, [P, P, L, P, P]),
     "cris_bce_bwd": (I, [P, P, L, P, P, P]),

@@ -310,10 +310,6 @@ class PackTable:
         self.dev = None
 
 
-def colsum(x, M, N, out, ldx=None, coff=0):
-    hip.call("cris_colsum_bf16", ptr(x), ldx if ldx is not None else x.shape[-1], coff, M, N, ptr(out), _stream())
-
-
 # ---- BatchNorm ---------------------------------------------------------------------------------
 def partials_rows(nparts: int) -> int:
     """rows a partials buffer needs (room for bn_finalize's first-level merge; cris_bn_partials_rows)"""
@@ -411,6 +407,8 @@ def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, 
     p.count = float(count)
     s = _stream()
     if not skip_reduce:
+        part = torch.empty(hip.load().cris_bn_bwd_ws_floats(C.byref(p)), dtype=torch.float32, device=dz.device)
+        p.part = ptr(part)
         hip.call("cris_bn_bwd_reduce", C.byref(p), s)
     if between is not None:
         between(sums)
@@ -434,19 +432,54 @@ def ln_fwd(x, gamma, beta, rows, C_, mean, rstd, *, ldx=None, y=None, ypos=None,
     hip.call("cris_ln_fwd", C.byref(p), _stream())
 
 
+class SumQueue:
+    """Ordered column sums of per-block partial tables (cris_sum_tables), deferred and launched together: the LayerNorm
+    parameter gradients are only read by the exchange / optimizer, so the engine flushes one group per arena stage."""
+
+    def __init__(self):
+        self.items = []
+
+    def add(self, part, out, nparts, ncol, ld, part_off=0):
+        e = hip.SumEntry()
+        e.part, e.out = part.data_ptr() + 4 * part_off, ptr(out)
+        e.nparts, e.ncol, e.ld = nparts, ncol, ld
+        self.items.append((e, part, out))
+
+    def flush(self):
+        items, self.items = self.items, []
+        for i in range(0, len(items), hip.SUM_GROUP_MAX):
+            chunk = items[i:i + hip.SUM_GROUP_MAX]
+            grp = hip.SumGroup()
+            grp.n = len(chunk)
+            for j, it in enumerate(chunk):
+                grp.e[j] = it[0]
+            hip.call("cris_sum_tables", C.byref(grp), _stream())
+
+
 def ln_bwd(x, gamma, mean, rstd, rows, C_, dx, *, ldx=None, dy=None, dypos=None, dout_f32=None, dgamma=None, dbeta=None,
-           dx_accum=False, in_relu=False, in_drop: Drop = NO_DROP, out_drop: Drop = NO_DROP):
+           dx_accum=False, in_relu=False, in_drop: Drop = NO_DROP, out_drop: Drop = NO_DROP, queue: Optional[SumQueue] = None):
+    """dx now; dgamma / dbeta (overwritten) = ordered sum of the kernel's per-block partial rows - through `queue` at its next
+    flush, or right away without one."""
     p = hip.LnBwdParams()
     p.x, p.x_f32, p.ldx = ptr(x), int(x.dtype == torch.float32), ldx if ldx is not None else C_
     p.gamma, p.mean, p.rstd = ptr(gamma), ptr(mean), ptr(rstd)
     p.dy, p.dypos, p.dout_f32 = ptr(dy), ptr(dypos), ptr(dout_f32)
-    p.dgamma, p.dbeta = ptr(dgamma), ptr(dbeta)
+    nparts = hip.load().cris_ln_bwd_parts(rows)
+    part = torch.empty(nparts, 2 * C_, dtype=torch.float32, device=x.device)
+    p.part = ptr(part)
     p.dx, p.dx_f32, p.dx_accum = ptr(dx), int(dx.dtype == torch.float32), int(dx_accum)
     p.rows, p.C, p.in_relu = rows, C_, int(in_relu)
     p.in_drop_p, p.in_thresh, p.in_seed, p.in_stream = in_drop.p, in_drop.thresh, in_drop.seed & 0xFFFFFFFF, in_drop.stream
     p.out_drop_p, p.out_thresh, p.out_seed, p.out_stream = out_drop.p, out_drop.thresh, out_drop.seed & 0xFFFFFFFF, out_drop.stream
     p.seed_dev = ptr(in_drop.dev if in_drop.dev is not None else out_drop.dev)
     hip.call("cris_ln_bwd", C.byref(p), _stream())
+    q = queue if queue is not None else SumQueue()
+    if dgamma is not None:
+        q.add(part, dgamma, nparts, C_, 2 * C_, 0)
+    if dbeta is not None:
+        q.add(part, dbeta, nparts, C_, 2 * C_, C_)
+    if queue is None:
+        q.flush()
 
 
 # ---- attention ---------------------------------------------------------------------------------
@@ -586,7 +619,8 @@ def dynconv_fwd(x, Bn, H, W, C_, wb, pred):
 
 
 def dynconv_bwd(x, dpred, Bn, H, W, C_, wb, dx, dwb):
-    hip.call("cris_dynconv_bwd", ptr(x), ptr(dpred), Bn, H, W, C_, ptr(wb), wb.shape[-1], ptr(dx), ptr(dwb), _stream())
+    ws = torch.empty(hip.load().cris_dynconv_bwd_ws_floats(Bn, H, W, wb.shape[-1]), dtype=torch.float32, device=dx.device)
+    hip.call("cris_dynconv_bwd", ptr(x), ptr(dpred), Bn, H, W, C_, ptr(wb), wb.shape[-1], ptr(dx), ptr(dwb), ptr(ws), _stream())
 
 
 def mask_resize_nearest(mask, OH, OW, out):

@@ -17,13 +17,36 @@ def _cos(a, b):
     return float((a @ b) / (a.norm() * b.norm() + 1e-30))
 
 
-def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", word_len=None):
-    """Returns a dict of parity figures: HIP engine vs fp32 oracle (and vs the oracle run with bf16 storage rounding,
-    the noise floor every bf16 implementation shares)."""
+# Fixed parity bounds of the bf16 HIP path against the fp32 oracle, per configuration family (DESIGN.md section 6 lists the
+# measured values they were set from; they do not move with any noise model):
+#   loss: |hip - oracle|; logits: relative L2 error; grad_cos_*: cosine of each parameter gradient with autograd's.
+BOUNDS = {
+    "tiny": dict(loss=1e-2, logits=4e-2, grad_cos_median=0.98, grad_cos_min=0.85),
+    # full parameter trees at reduced resolution / batch 2: BatchNorm statistics over few samples amplify single roundings
+    "small": dict(loss=1e-2, logits=8e-2, grad_cos_median=0.92, grad_cos_min=0.75),
+    # BASELINE.json configs[1] / [4] (R50, batch 8, 416 / 480 pixels)
+    "r50_full": dict(loss=5e-3, logits=7e-2, grad_cos_median=0.995, grad_cos_min=0.90),
+    # BASELINE.json configs[3] (R101: 23 blocks in layer3 - twice the depth for roundings to compound)
+    "r101_full": dict(loss=1.5e-2, logits=7e-2, grad_cos_median=0.96, grad_cos_min=0.85),
+}
+
+
+def assert_parity(rep, family):
+    b = BOUNDS[family]
+    assert rep["mask_equal"], "nearest mask resize is an index op: must be bit exact"
+    assert math.isfinite(rep["loss_hip"]) and math.isfinite(rep["loss_step2"]) and rep["params_finite"], rep
+    assert abs(rep["loss_hip"] - rep["loss_oracle"]) <= b["loss"], rep
+    assert rep["pred_rel_vs_fp32"] <= b["logits"], rep
+    assert rep["grad_cos_median"] >= b["grad_cos_median"], rep
+    assert rep["grad_cos_min"] >= b["grad_cos_min"], rep
+
+
+def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", word_len=None, emul=False):
+    """Returns a dict of parity figures: HIP engine vs fp32 oracle (emul=True: also vs the oracle run with bf16 storage
+    rounding, the noise floor every bf16 implementation shares - informative only, no bound depends on it)."""
     from . import arch, synth
     from .trainer import NativeTrainer
     from oracle import cris_oracle as O                      # checker only
-    from oracle.bf16_emulation import bf16_storage
 
     clip, head = arch.specs_by_name(spec)
     head = dataclasses.replace(head, dropout=dropout, **({} if word_len is None else {"word_len": word_len}))
@@ -41,33 +64,35 @@ def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", wo
     dseed = seed if dropout > 0 else None
     opred, om, oloss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=dseed)
     oloss.backward()
-    # the oracle again with bf16 storage rounding at the points where the HIP path stores bf16 (forward AND the
-    # gradients flowing back through the same casts): the noise floor any bf16 implementation of this network shares
-    leaf_e = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-    with bf16_storage():
-        epred, _, eloss = O.cris_forward(leaf_e, clip, head, img, word, mask, training=True, drop_seed=dseed)
-        eloss.backward()
-    epred, eloss = epred.detach(), eloss.detach()
-
-    coss, ecoss, hecoss = {}, {}, {}
+    coss = {}
     for k, g in grads.items():
         og = leaf[k].grad
         if og is None or k.endswith("k_proj.bias") or float(og.norm()) == 0.0:
             continue                    # d/d(key bias) == 0 analytically: rounding noise on both sides
         coss[k] = _cos(g, og)
-        ecoss[k] = _cos(leaf_e[k].grad, og)
-        hecoss[k] = _cos(g, leaf_e[k].grad)
     worst = min(coss, key=coss.get)
     med = lambda d: sorted(d.values())[len(d) // 2]
     rep = {
-        "loss_hip": float(loss), "loss_oracle": float(oloss.detach()), "loss_emul": float(eloss),
+        "loss_hip": float(loss), "loss_oracle": float(oloss.detach()),
         "mask_equal": bool(torch.equal(msk.cpu(), om)),
-        "pred_rel_vs_fp32": _rel(pred, opred), "pred_rel_vs_emul": _rel(pred, epred), "emul_rel_vs_fp32": _rel(epred, opred),
+        "pred_rel_vs_fp32": _rel(pred, opred.detach()),
         "grad_cos_min": coss[worst], "grad_cos_min_name": worst,
         "grad_cos_median": med(coss), "n_grads": len(coss),
-        "emul_grad_cos_median": med(ecoss), "emul_grad_cos_min": min(ecoss.values()),
-        "hip_vs_emul_grad_cos_median": med(hecoss),
     }
+    if emul:
+        # the oracle again with bf16 storage rounding at the points where the HIP path stores bf16 (forward AND the
+        # gradients flowing back through the same casts): the noise floor any bf16 implementation of this network shares
+        from oracle.bf16_emulation import bf16_storage
+        leaf_e = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+        with bf16_storage():
+            epred, _, eloss = O.cris_forward(leaf_e, clip, head, img, word, mask, training=True, drop_seed=dseed)
+            eloss.backward()
+        epred, eloss = epred.detach(), eloss.detach()
+        ecoss = {k: _cos(leaf_e[k].grad, leaf[k].grad) for k in coss}
+        hecoss = {k: _cos(grads[k], leaf_e[k].grad) for k in coss}
+        rep.update({"loss_emul": float(eloss), "pred_rel_vs_emul": _rel(pred, epred), "emul_rel_vs_fp32": _rel(epred, opred.detach()),
+                    "emul_grad_cos_median": med(ecoss), "emul_grad_cos_min": min(ecoss.values()),
+                    "hip_vs_emul_grad_cos_median": med(hecoss)})
     # one optimizer step on top (Adam over the arena) must keep everything finite
     l2, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev), seed=seed + 1)
     torch.cuda.synchronize(dev)
@@ -79,12 +104,4 @@ def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", wo
 def smoke():
     rep = run()
     print("smoke:", {k: (round(v, 6) if isinstance(v, float) else v) for k, v in rep.items()})
-    assert rep["mask_equal"], "nearest mask resize is an index op: must be bit exact"
-    assert math.isfinite(rep["loss_hip"]) and math.isfinite(rep["loss_step2"]) and rep["params_finite"]
-    # bf16 path vs fp32 oracle, bounded by 3x what the oracle itself shows when it is run with bf16 storage rounding at the
-    # same points (the noise floor of any bf16 implementation of this network) - the rule of tests/test_engine_gpu.py
-    k = 3.0
-    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < k * abs(rep["loss_emul"] - rep["loss_oracle"]) + 1e-2, rep
-    assert rep["pred_rel_vs_fp32"] < k * rep["emul_rel_vs_fp32"] + 1e-2, rep
-    assert 1.0 - rep["grad_cos_median"] < k * (1.0 - rep["emul_grad_cos_median"]) + 5e-3, rep
-    assert 1.0 - rep["grad_cos_min"] < k * (1.0 - rep["emul_grad_cos_min"]) + 5e-2, rep
+    assert_parity(rep, "tiny")

@@ -163,7 +163,6 @@ class NativeTrainer:
             main = torch.cuda.current_stream()
             ops.torch_op(lambda: main.wait_stream(self.ostream))
             e.packs_current = True
-        ops.zero_(self.metric)
         ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         return loss, pred, msk
 

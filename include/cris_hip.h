@@ -127,8 +127,6 @@ int cris_pack_weights(const cris_pack_desc* dev_table, int n_desc, int total_blo
 int cris_pack_blocks(const cris_pack_desc* host_desc);
 int cris_pack_block_elems(void);
 
-/* column sums of a bf16 matrix into fp32 (bias gradients): out[n] += sum_m x[m][n] */
-int cris_colsum_bf16(const cris_bf16* x, int ldx, int coff, int M, int N, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm (training statistics), replaces native_batch_norm / its backward
@@ -183,7 +181,9 @@ typedef struct {
     const cris_bf16* y2; int ldy2, y2_coff;          /* second branch or NULL */
     const float* mean2; const float* invstd2; const float* scale2;
     const float* mul;                                /* [Bn][C] or NULL (forward multiplier) */
-    float* sums;                                     /* [4*C]: sum g, sum g*xhat, (branch 2) sum g, sum g*xhat2 */
+    float* sums;                                     /* [4*C]: sum g, sum g*xhat, (branch 2) sum g, sum g*xhat2 (+=) */
+    float* part;                                     /* reduce workspace, cris_bn_bwd_ws_floats(p) floats: one partial row of
+                                                        sums per row block; summed in block order (no atomics) */
     float* dmul;                                     /* [Bn][C] grad of mul or NULL */
     cris_bf16* dy;  int lddy, dy_coff;               /* grad wrt y */
     cris_bf16* dy2; int lddy2, dy2_coff;             /* grad wrt y2 or NULL */
@@ -194,6 +194,7 @@ typedef struct {
     float count;                                     /* rows entering the statistics (global count under SyncBN) */
 } cris_bn_bwd_params;
 int cris_bn_bwd_reduce(const cris_bn_bwd_params* p, void* stream);
+long cris_bn_bwd_ws_floats(const cris_bn_bwd_params* p);
 int cris_bn_bwd_apply(const cris_bn_bwd_params* p, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
@@ -225,7 +226,8 @@ typedef struct {
     const cris_bf16* dy;                             /* optional grad wrt y */
     const cris_bf16* dypos;                          /* optional grad wrt ypos (added to dy) */
     const float* dout_f32;                           /* optional grad wrt out_f32 (passes the output dropout) */
-    float* dgamma; float* dbeta;                     /* accumulated (+=, atomics) */
+    float* part;                                     /* (out) [cris_ln_bwd_parts(rows)][2C]: per-block (dgamma | dbeta) partial rows;
+                                                        cris_sum_tables adds them in block order into the gradients */
     void* dx; int dx_f32; int dx_accum;              /* grad wrt x: bf16 or fp32; accum: += (fp32 only) */
     int rows, C;
     int in_relu;
@@ -234,6 +236,19 @@ typedef struct {
     const uint32_t* seed_dev;
 } cris_ln_bwd_params;
 int cris_ln_bwd(const cris_ln_bwd_params* p, void* stream);
+int cris_ln_bwd_parts(int rows);                     /* rows of the partials table for `rows` LayerNorm rows */
+
+/* Ordered column sums of up to CRIS_SUM_GROUP_MAX partial tables in one launch (table passed by value):
+ * out[c] = sum_p part[p*ld + c], p = 0 .. nparts-1 in order - the deterministic replacement of atomic accumulation for
+ * the LayerNorm parameter gradients (the engine flushes one group per gradient-arena stage).  block_start: launcher. */
+#define CRIS_SUM_GROUP_MAX 64
+typedef struct { const float* part; float* out; int nparts, ncol, ld, pad_; } cris_sum_entry;
+typedef struct {
+    int n;
+    int block_start[CRIS_SUM_GROUP_MAX + 1];
+    cris_sum_entry e[CRIS_SUM_GROUP_MAX];
+} cris_sum_group;
+int cris_sum_tables(const cris_sum_group* g, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused multi-head attention, head dim 64 (replaces bmm/baddbmm/_softmax/bernoulli_/bmm of the
@@ -321,14 +336,17 @@ int cris_batch_rowsum(const cris_bf16* dx, int ldx, int Bn, int T, int C, float*
 /* text-to-pixel dynamic conv (grouped conv2d, groups = B: model/layers.py:71-84), fp32 logits out */
 int cris_dynconv_fwd(const cris_bf16* x, int Bn, int H, int W, int C, const float* wb, int ldwb, float* pred,
                      void* stream);
+/* dx, and dwb[b][i] += (per-sample kernel + bias gradient); ws: cris_dynconv_bwd_ws_floats floats (per-block partial rows,
+ * summed in block order - no atomics) */
 int cris_dynconv_bwd(const cris_bf16* x, const float* dpred, int Bn, int H, int W, int C, const float* wb, int ldwb,
-                     cris_bf16* dx, float* dwb, void* stream);
+                     cris_bf16* dx, float* dwb, float* ws, void* stream);
+long cris_dynconv_bwd_ws_floats(int Bn, int H, int W, int ldwb);
 /* nearest mask resize + BCE-with-logits mean (model/segmenter.py:56-59) and gradient.
- * loss_accum[0] += sum(loss_i)/n ; grad = (sigmoid(x) - t)/n * (*gscale or 1) */
+ * loss[0] = sum(loss_i)/n (one block, fixed summation order) ; grad = (sigmoid(x) - t)/n * (*gscale or 1) */
 int cris_mask_resize_nearest(const float* mask, int Bn, int IH, int IW, int OH, int OW, float* out, void* stream);
-int cris_bce_fwd(const float* logits, const float* target, long n, float* loss_accum, void* stream);
+int cris_bce_fwd(const float* logits, const float* target, long n, float* loss, void* stream);
 int cris_bce_bwd(const float* logits, const float* target, long n, const float* gscale, float* dlogits, void* stream);
-/* trainMetricGPU (utils/misc.py:114-129): out[0] += 100*mean IoU, out[1] += 100*mean(IoU > pr_iou) */
+/* trainMetricGPU (utils/misc.py:114-129): out[0] = 100*mean IoU, out[1] = 100*mean(IoU > pr_iou) */
 int cris_train_metric(const float* logits, const float* target, int Bn, int HW, float thr, float pr_iou, float* out,
                       void* stream);
 /* elementwise multiply by per-(batch,channel) scalar handled inside cris_bn_apply (mul) */

@@ -1,15 +1,15 @@
 """GPU parity of the whole hot path (forward + BCE loss + backward + Adam) through the C-ABI library vs the CPU oracle
 on the same seeded inputs.
 
-Tolerances (bf16 activations / MFMA operands, fp32 accumulation, statistics and residual streams; stated per check):
+Tolerances are FIXED numbers per configuration family (cris/pytorch_amd/selfcheck.py BOUNDS; bf16 activations / MFMA
+operands, fp32 accumulation, statistics and residual streams), set once from the values measured on an MI355X
+(DESIGN.md section 6):
   * nearest-resized mask, dropout keep decisions: bit exact (index ops);
-  * loss: |hip - oracle_fp32| <= 2e-2 on an O(0.7) mean BCE (measured: see profiles/parity_r01.md);
-  * logits: relative L2 error vs the fp32 oracle <= 3x the error of the oracle itself when run with bf16 storage
-    rounding at the same points (the noise floor any bf16 implementation shares) + 5e-2;
-  * gradients: cosine vs fp32 autograd of the oracle - median > 0.98, worst parameter > 0.5 (tiny BN layers with
-    8-50 samples amplify single bf16 roundings; the k-projection biases have an analytically zero gradient and are
-    skipped);
-  * loss trajectory over optimizer steps vs the oracle driven by torch.optim.Adam: max |diff| reported, bound 3e-2.
+  * loss |hip - oracle_fp32|, logits relative L2, per-parameter gradient cosine (median and worst parameter; the
+    k-projection biases have an analytically zero gradient and are skipped);
+  * BASELINE.json configs[1] (R50 416x416 batch 8), configs[3] (R101) and configs[4] (480x480, 22 tokens) are checked at
+    their FULL size: logits and every parameter gradient, not only the loss;
+  * loss trajectories over 100 optimizer steps vs the oracle driven by torch.optim.Adam at the reference's lr 1e-4.
 """
 import dataclasses
 import json
@@ -30,53 +30,86 @@ from cris.pytorch_amd.trainer import NativeTrainer  # noqa: E402
 from oracle import cris_oracle as O  # noqa: E402
 
 
-def _assert_parity(rep, k=3.0):
-    """HIP-vs-fp32 errors are bounded by k x the errors the ORACLE ITSELF shows when it is run with bf16 storage rounding at
-    the same points (oracle/bf16_emulation.py): the noise floor of any bf16 implementation of this network."""
-    assert rep["mask_equal"]
-    assert math.isfinite(rep["loss_hip"]) and rep["params_finite"]
-    assert abs(rep["loss_hip"] - rep["loss_oracle"]) < k * abs(rep["loss_emul"] - rep["loss_oracle"]) + 1e-2, rep
-    assert rep["pred_rel_vs_fp32"] < k * rep["emul_rel_vs_fp32"] + 1e-2, rep
-    assert 1.0 - rep["grad_cos_median"] < k * (1.0 - rep["emul_grad_cos_median"]) + 5e-3, rep
-    assert 1.0 - rep["grad_cos_min"] < k * (1.0 - rep["emul_grad_cos_min"]) + 5e-2, rep
-
-
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_tiny_step_matches_oracle(dropout):
     rep = selfcheck.run("tiny", batch=8, size=64, dropout=dropout, seed=11)
     print(rep)
-    _assert_parity(rep)
+    selfcheck.assert_parity(rep, "tiny")
 
 
 def test_tiny_ragged_shapes():
     """odd batch, 96 px (24/12/6/3 feature maps: every tile tail path), random text lengths."""
     rep = selfcheck.run("tiny", batch=3, size=96, dropout=0.0, seed=5)
     print(rep)
-    _assert_parity(rep)
+    selfcheck.assert_parity(rep, "tiny")
 
 
 def test_r50_small_step_matches_oracle():
     """Full CRIS-R50 parameter tree (146.8 M parameters) at 160x160, batch 2 - the golden-fixture case."""
     rep = selfcheck.run("r50", batch=2, size=160, dropout=0.0, seed=3)
     print(rep)
-    _assert_parity(rep)
+    selfcheck.assert_parity(rep, "small")
     g = np.load(os.path.join(GOLDEN, "r50_b2_s160.npz"))          # the reference's own loss on the same inputs
     assert abs(rep["loss_oracle"] - float(g["loss"])) < 2e-4
 
 
 def test_r101_step_matches_oracle():
-    """BASELINE.json configs[3]: the deeper visual encoder (layer3 x23, embed_dim 512, fpn_in [512,1024,512]), 160x160, batch 2."""
+    """The R101 tree (layer3 x23, embed_dim 512, fpn_in [512,1024,512]) at 160x160, batch 2."""
     rep = selfcheck.run("r101", batch=2, size=160, dropout=0.0, seed=7)
     print(rep)
-    _assert_parity(rep)
+    selfcheck.assert_parity(rep, "small")
 
 
-def test_r50_480_long_text_step_matches_oracle():
-    """BASELINE.json configs[4] shape family: 480-pixel-style geometry (odd feature maps: 240 -> 60/30/15/8... here 224 with
-    L = 22 tokens: 56/28/14/7 maps) and G-Ref-length expressions (word_len 22)."""
+def test_r50_long_text_small_step_matches_oracle():
+    """22-token expressions with dropout on, 224x224 (56/28/14/7 maps), batch 2."""
     rep = selfcheck.run("r50", batch=2, size=224, dropout=0.1, seed=9, word_len=22)
     print(rep)
-    _assert_parity(rep)
+    selfcheck.assert_parity(rep, "small")
+
+
+# ---- the BASELINE.json configurations at their full size: logits + every parameter gradient -------------------------
+def test_config1_r50_416_batch8_step_matches_oracle():
+    """BASELINE.json configs[1]: CRIS-R50, 416x416, per-GPU batch 8, 17 tokens - the benchmarked shape (128x128 / 64x128
+    GEMM tiles, 676-token decoder attention, split weight gradients all run here)."""
+    rep = selfcheck.run("r50", batch=8, size=416, dropout=0.0, seed=3)
+    print(rep)
+    selfcheck.assert_parity(rep, "r50_full")
+
+
+def test_config3_r101_416_batch8_step_matches_oracle():
+    """BASELINE.json configs[3]: CRIS-R101, 416x416, batch 8."""
+    rep = selfcheck.run("r101", batch=8, size=416, dropout=0.0, seed=3)
+    print(rep)
+    selfcheck.assert_parity(rep, "r101_full")
+
+
+def test_config4_r50_480_22_tokens_step_matches_oracle():
+    """BASELINE.json configs[4]: CRIS-R50, 480x480 (120/60/30/15 maps, 900-token decoder attention), 22-token text, batch 8."""
+    rep = selfcheck.run("r50", batch=8, size=480, dropout=0.0, seed=3, word_len=22)
+    print(rep)
+    selfcheck.assert_parity(rep, "r50_full")
+
+
+def test_training_step_is_deterministic():
+    """No atomics anywhere on the path: the same batch from the same state gives bit-identical losses, gradients and updated
+    parameters - three times over (eager schedule and HIP-graph replay)."""
+    clip, head = arch.specs_by_name("tiny")
+    dev = torch.device("cuda:0")
+    outs = []
+    for rep in range(3):
+        sd = arch.synthetic_state_dict(clip, head, 0)
+        tr = NativeTrainer(clip, head, sd, dev)
+        losses = []
+        for t in range(4):
+            img, word, mask = synth.make_batch(4, 64, head.word_len, 0, t)
+            loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        outs.append((losses, tr.engine.grad_arena.clone(), {k: v.clone() for k, v in tr.engine.P.items()}))
+    for losses, arena, params in outs[1:]:
+        assert losses == outs[0][0], (losses, outs[0][0])
+        assert torch.equal(arena, outs[0][1])
+        assert all(torch.equal(params[k], outs[0][2][k]) for k in params)
 
 
 def test_stage_isolated_parity():
@@ -109,7 +142,7 @@ def test_eval_forward_matches_oracle():
         ref = O.cris_forward(sd, clip, head, img, word, training=False)
     assert pred.shape == ref.shape
     err = float((pred.cpu() - ref).norm() / ref.norm())
-    assert err < 0.1, err
+    assert err < 3e-2, err
 
 
 def _trajectory(name, max_steps=None):
@@ -131,28 +164,33 @@ def _trajectory(name, max_steps=None):
 
 def test_loss_trajectory_tiny_100_steps():
     """100 optimizer steps with dropout 0.1 (shared counter-hash masks) and the reference's Adam(lr 1e-4) vs the fixture made
-    by the CPU oracle + torch.optim.Adam (tests/golden/make_trajectory.py).  Run-to-run the HIP curve itself moves (fp32
-    atomics order feeding Adam's sign-like steps): over 14 runs max |dloss| was 1.5e-2 ... 2.3e-2 (once above 3e-2), mean
-    |dloss| 3.5e-3 ... 4.5e-3.  Bounds: mean <= 1e-2, max <= 6e-2."""
+    by the CPU oracle (fp32) + torch.optim.Adam (tests/golden/make_trajectory.py).  The HIP path is deterministic, so the
+    measured figures are reproducible: see DESIGN.md section 6.  Bounds: mean |dloss| <= 1e-2, max <= 4e-2."""
     losses, ref, diffs = _trajectory("traj_tiny_b4_s64_d0.1_lr0.0001.json")
     print("tiny trajectory: max |d| %.3e mean |d| %.3e, final hip %.4f oracle %.4f" % (max(diffs), sum(diffs) / len(diffs), losses[-1], ref[-1]))
-    assert sum(diffs) / len(diffs) < 1e-2 and max(diffs) < 6e-2, diffs
+    assert sum(diffs) / len(diffs) < 1e-2 and max(diffs) < 4e-2, diffs
     assert losses[-1] < 0.5 * losses[0]            # and it actually trains
 
 
-def test_loss_trajectory_r50_full_size():
-    """BASELINE.json configs[1] shape (R50, 416x416, batch 8, L=17, dropout 0.1, Adam lr 2e-6 - see make_trajectory.py).
-    Contract: the trajectory of the oracle run with bf16 storage rounding at the HIP path's storage points
-    (traj_*_bf16emul.json), max |dloss| <= 1.5e-2 over its 12 steps.  The fp32 oracle's trajectory is printed beside it:
-    Adam's sign-like first steps turn bf16 rounding of near-zero gradient elements into a visible loss difference after
-    the first update (fp32 0.7177, bf16-emulated oracle 0.3634, HIP 0.3577), which then decays."""
-    emul, fp32 = "traj_r50_b8_s416_d0.1_lr2e-06_bf16emul.json", "traj_r50_b8_s416_d0.1_lr2e-06.json"
-    if not os.path.exists(os.path.join(GOLDEN, emul)):
-        pytest.skip("fixture not generated")
-    losses, ref, diffs = _trajectory(emul)
-    ref32 = json.load(open(os.path.join(GOLDEN, fp32)))["loss"][:len(losses)]
-    print("r50 trajectory hip / bf16-emulated oracle / fp32 oracle:",
-          ["%.4f/%.4f/%.4f" % (a, b, c) for a, b, c in zip(losses, ref, ref32)])
-    assert max(diffs) < 1.5e-2, diffs
-    # the first step, before any update, also matches the fp32 oracle
-    assert abs(losses[0] - ref32[0]) < 2e-3
+# fixed bounds on |loss_hip - loss_fp32_oracle| over the 100 steps (mean, max), from the measured curves (DESIGN.md section 6)
+TRAJ_BOUNDS = {"mean": 3e-2, "max": 1.5e-1}
+
+
+def test_loss_trajectory_r50_full_size_100_steps():
+    """BASELINE.json configs[1] (R50, 416x416, batch 8, L=17, dropout 0.1) for 100 optimizer steps at the REFERENCE's learning
+    rate (Adam lr 1e-4, config/refcoco/cris_r50.yaml) against the fp32 CPU oracle + torch.optim.Adam
+    (tests/golden/traj_r50_b8_s416_d0.1_lr0.0001.json, made by tests/golden/make_trajectory.py).  The untrained head makes the
+    first steps violent for ANY implementation (fp32: 0.90, 1.80, 1.46, 0.78, 1.11, 2.17, ...); the bound is a constant.
+    The oracle run with bf16 storage rounding (…_bf16emul.json) is printed beside it for orientation only."""
+    fp32, emul = "traj_r50_b8_s416_d0.1_lr0.0001.json", "traj_r50_b8_s416_d0.1_lr0.0001_bf16emul.json"
+    losses, ref, diffs = _trajectory(fp32)
+    n = len(losses)
+    assert n >= 100, "fixture must hold 100 steps"
+    ref_e = json.load(open(os.path.join(GOLDEN, emul)))["loss"][:n] if os.path.exists(os.path.join(GOLDEN, emul)) else [float("nan")] * n
+    print("r50 trajectory hip / fp32 oracle / bf16-emulated oracle:",
+          ["%.4f/%.4f/%.4f" % (a, b, c) for a, b, c in zip(losses, ref, ref_e)])
+    de = [abs(a - b) for a, b in zip(ref_e, ref)]
+    print("max |hip-fp32| %.3e mean %.3e ; bf16-emulated oracle vs fp32: max %.3e mean %.3e"
+          % (max(diffs), sum(diffs) / n, max(de), sum(de) / n))
+    assert abs(losses[0] - ref[0]) < 5e-3                      # before any update
+    assert sum(diffs) / n <= TRAJ_BOUNDS["mean"] and max(diffs) <= TRAJ_BOUNDS["max"], (max(diffs), sum(diffs) / n)

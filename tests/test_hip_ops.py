@@ -70,6 +70,10 @@ def pack_F(w, Cpad=None):
     dict(B=3, H=8, W=10, C=24, N=200, k=3, stride=2),
     dict(B=8, H=1, W=1, C=1024, N=2305, k=1),        # proj.txt shape: M=8, N tail
     dict(B=700, H=1, W=1, C=512, N=1536, k=1),       # linear
+    # the shapes of the benchmarked configuration that select the 128x128 tile (>= 448 tiles): proj.vis.3 and proj.vis.1
+    dict(B=8, H=104, W=104, C=512, N=256, k=3),      # M=86528 N=256 K=4608: 1352 tiles, 2-deep ring
+    dict(B=8, H=52, W=52, C=512, N=512, k=3),        # M=21632 N=512 K=4608: 676 tiles
+    dict(B=8, H=104, W=104, C=64, N=256, k=1),       # M=86528 N=256 K=64: one K-step (prologue == whole loop), HBM-bound
 ])
 def test_conv_gemm_plain(case):
     B, H, W, C_, N, k = case["B"], case["H"], case["W"], case["C"], case["N"], case["k"]
@@ -124,6 +128,23 @@ def test_conv_gemm_epilogues():
     check(out3, ref, 3e-3, "dropout epilogue")
     dropped = (out3.cpu() - res32).abs() < 1e-12
     assert bool((dropped == ~km).all()), "dropout keep decisions differ from the hash oracle"
+
+
+def test_conv_gemm_general_epilogue_large_tiles():
+    """the non-LEAN instantiation of the 128x128 tile (bias + fp32 residual + fp32 out; BN statistics partials of 64 rows)"""
+    M, K, N = 21632 * 3, 512, 512                     # 507 x 4 tiles of 128x128
+    x = rnd(M, K).to(BF).float()
+    w = (rnd(N, K, seed=1) / math.sqrt(K)).to(BF).float()
+    bias, res = rnd(N, seed=2), rnd(M, N, seed=3)
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    st = ops.conv_gemm(bf(x), bf(w), Geom.linear(M, K), N, bias=bias.to(DEV), resid=res.to(DEV), out=out, stats=True)
+    ref = x @ w.t() + bias + res
+    check(out, ref, 3e-3, "128x128 general epilogue")
+    assert st.rows_per_part == 64
+    outs = [torch.empty(N, device=DEV) for _ in range(4)]
+    ops.bn_finalize(st, M, M, torch.ones(N, device=DEV), torch.zeros(N, device=DEV), None, None, 0.1, 1e-5, N, *outs)
+    check(outs[2], ref.mean(0), 3e-3, "mean from 128x128 partials")
+    check(outs[3], torch.rsqrt(ref.var(0, unbiased=False) + 1e-5), 3e-3, "invstd from 128x128 partials")
 
 
 @pytest.mark.parametrize("L,B", [(24, 3), (17, 2)])
@@ -289,13 +310,6 @@ def test_bn_finalize_two_level_merge():
     ops.bn_finalize(st, M, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs)
     check(outs[2], y.double().mean(0), 1e-6, "mean")
     check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), 1e-5, "invstd")
-
-
-def test_colsum():
-    x = rnd(1000, 72).to(BF).float()
-    out = torch.zeros(72, device=DEV)
-    ops.colsum(bf(x), 1000, 72, out)
-    check(out, x.sum(0), 1e-5, "colsum_bf16")
 
 
 # ----------------------------------------------------------------------------------------------------
@@ -480,6 +494,10 @@ def _head_T(x, B, L, Hn, Lpad):
     dict(B=2, Hn=2, Lq=70, Lk=17, pad=True, p=0.1),          # cross attention, key padding
     dict(B=3, Hn=2, Lq=17, Lk=17, causal=True, p=0.0),       # text
     dict(B=1, Hn=4, Lq=169, Lk=169, p=0.0),                  # attnpool
+    dict(B=1, Hn=2, Lq=676, Lk=676, p=0.1),                  # decoder self-attention at 416x416 (26x26 tokens)
+    dict(B=1, Hn=2, Lq=900, Lk=900, p=0.0),                  # ... at 480x480 (30x30 tokens)
+    dict(B=2, Hn=2, Lq=676, Lk=17, pad=True, p=0.1),         # decoder cross attention at 416x416
+    dict(B=2, Hn=1, Lq=900, Lk=22, pad=True, p=0.1),         # ... at 480x480, 22-token text
 ])
 def test_attention_fwd_bwd(case):
     B, Hn, Lq, Lk, p = case["B"], case["Hn"], case["Lq"], case["Lk"], case["p"]
@@ -493,7 +511,8 @@ def test_attention_fwd_bwd(case):
     if case.get("pad"):
         toks = torch.ones(B, Lk, dtype=torch.int64)
         toks[0, 9:] = 0
-        toks[1, 14:] = 0
+        if B > 1:
+            toks[1, 14:] = 0
     seed, stream = 4321, 2
     Lkp, Lqp = ops.pad32(Lk), ops.pad32(Lq)
     qd, kd, vd = bf(q), bf(k), bf(v)
@@ -685,7 +704,7 @@ def test_loss_mask_metric():
     assert torch.equal(out2.cpu(), F.interpolate(mask2, (13, 23), mode="nearest"))
     x = rnd(B, 1, O_, O_) * 3
     t = out.cpu()
-    loss = torch.zeros(1, device=DEV)
+    loss = torch.full((1,), float('nan'), device=DEV)          # overwritten, not accumulated
     ops.bce_fwd(x.to(DEV), out, loss)
     xl = x.clone().requires_grad_(True)
     ref = F.binary_cross_entropy_with_logits(xl, t)
@@ -694,7 +713,7 @@ def test_loss_mask_metric():
     dx = torch.empty(B, 1, O_, O_, device=DEV)
     ops.bce_bwd(x.to(DEV), out, torch.tensor([3.0], device=DEV), dx)
     check(dx, xl.grad, 1e-5)
-    met = torch.zeros(2, device=DEV)
+    met = torch.full((2,), float('nan'), device=DEV)
     ops.train_metric(x.to(DEV), out, B, O_ * O_, met)
     o = (torch.sigmoid(x.flatten(1)) >= 0.35)
     tt = t.flatten(1).bool()

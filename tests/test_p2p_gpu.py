@@ -2,6 +2,7 @@
 (csrc/p2p.hip, dist.PeerMailboxes) with two ranks sharing the one GPU of the test box - the mailboxes travel through HIP
 IPC exactly as between two GPUs.  (1) the primitive: sums over ranks, slot / generation reuse, device generation counter;
 (2) the whole trainer with CRIS_SYNCBN_P2P=1 equals the run that exchanges through torch.distributed."""
+import dataclasses
 import os
 import socket
 
@@ -71,7 +72,6 @@ def _train_worker(rank, world, port, p2p, launch, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CRIS_SYNCBN_P2P"] = "1" if p2p else "0"
-    os.environ["CRIS_TEST_TINY_DROPOUT0"] = "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cris.pytorch_amd import arch, synth
@@ -80,6 +80,7 @@ def _train_worker(rank, world, port, p2p, launch, q):
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
         clip, head = arch.specs_by_name("tiny")
+        head = dataclasses.replace(head, dropout=0.0)      # mask indices are rank-local: compare without dropout
         tr = NativeTrainer(clip, head, arch.synthetic_state_dict(clip, head, 0), dev, comm=TorchDistComm(dev), sync_bn=True,
                            launch=launch)
         assert (tr.comm.p2p is not None) == p2p
