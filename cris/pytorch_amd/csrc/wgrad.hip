@@ -316,24 +316,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const cris_wgrad_
     wgrad_tile<WG_MS, WG_STAGES>(p, bx, by, bz, smem);
 }
 
-// dW (and dbias) = sum over the splits' workspace slabs, in split order (deterministic)
+// dW (and dbias) = sum over the splits' workspace slabs (deterministic: a fixed tree - 16 split lanes each add their splits
+// in order, then the lanes are added in lane order).  Block = 16 float4 columns x 16 split lanes.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int splits, long slab, float* __restrict__ dW,
                                                           long n_dw, float* __restrict__ dbias, int N) {
+    __shared__ float4 sh[16][17];
     const long n4 = n_dw >> 2;                     // n_dw = N * ldw is a multiple of 4 (checked by the launcher)
-    const long total = n4 + (dbias ? N : 0);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long nb4 = dbias ? (N + 3) >> 2 : 0;     // the bias part of a slab is padded to 8 floats
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const long i = (long)blockIdx.x * 16 + cl;     // float4 index over [dW | dbias]
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4 + nb4) {
+        const float* src = ws + (i < n4 ? i * 4 : n_dw + (i - n4) * 4);
+        for (int s = pl; s < splits; s += 16) {
+            const float4 b = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    }
+    sh[pl][cl] = a;
+    __syncthreads();
+    if (pl == 0 && i < n4 + nb4) {
+#pragma unroll
+        for (int j = 1; j < 16; ++j) {
+            const float4 b = sh[j][cl];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
         if (i < n4) {
-            float4 a = *reinterpret_cast<const float4*>(ws + i * 4);
-            for (int s = 1; s < splits; ++s) {
-                const float4 b = *reinterpret_cast<const float4*>(ws + (size_t)s * slab + i * 4);
-                a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            }
             *reinterpret_cast<float4*>(dW + i * 4) = a;
         } else {
-            const long n = i - n4;
-            float a = ws[n_dw + n];
-            for (int s = 1; s < splits; ++s) a += ws[(size_t)s * slab + n_dw + n];
-            dbias[n] = a;
+            const long n = (i - n4) * 4;
+            const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < N) dbias[n + j] = v[j];
         }
     }
 }
@@ -386,7 +401,8 @@ extern "C" int cris_wgrad_reduce(const cris_wgrad_params* pp, void* stream) {
     if (p.splits == 1) return 0;
     if (wgrad_check(p, __func__)) return -1;
     const long n_dw = (long)p.N * p.ldw;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cris_grid_1d(n_dw / 4 + p.N, 256, 2048)), dim3(256), 0, (hipStream_t)stream, p.ws, p.splits,
+    const long cols4 = n_dw / 4 + (p.dbias ? (p.N + 3) / 4 : 0);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cris_cdiv(cols4, 16)), dim3(256), 0, (hipStream_t)stream, p.ws, p.splits,
                        wg_slab_floats(p.N, p.ldw), p.dW, n_dw, p.dbias, p.N);
     CRIS_LAUNCH_CHECK();
     return 0;

@@ -183,7 +183,7 @@ def wgrad_splits(M: int, N: int, K: int) -> int:
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     steps = (M + 127) // 128
     want = max(1, (_WGRAD_BLOCKS + tiles // 2) // tiles)
-    return max(1, min(want, (steps + 3) // 4, 512))
+    return max(1, min(want, (steps + 7) // 8, 256))
 
 
 def _wgrad_params(dY, X, g: Geom, N: int, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, splits, dbias):

@@ -74,6 +74,7 @@ class Ctx:
         e = self.eng
         for fn in reversed(e.tape):
             fn()
+        e._flush_queues()                    # queued weight gradients / LayerNorm parameter-gradient sums
         e.tape = []
         torch.cuda.synchronize()
         out = []
