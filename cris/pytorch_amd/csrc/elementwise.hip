@@ -820,8 +820,78 @@ extern "C" int cris_train_metric(const float* logits, const float* target, int B
 // fused multi-tensor Adam (torch.optim.Adam, non-amsgrad)
 // ------------------------------------------------------------------------------------------------
 #define ADAM_ELEMS 8192
+#define AP_T 64                                   // packed tensors: a block owns 64 output rows x 64 input channels x all taps
+#define AP_LROW(PT) (AP_T * (PT) + 2)             // bf16 elements per LDS tile row (+1 dword: conflict-free column reads)
+
+struct adam_coef {
+    float beta1, beta2, eps, wd, bc1, rsb2, gscale;
+};
+// torch.optim.Adam (non-amsgrad): step_size = lr / bias_correction1, denom = sqrt(v) / sqrt(bias_correction2) + eps
+__device__ __forceinline__ void adam_update(const adam_coef& k, float lr, float g, float& p, float& m, float& v) {
+    g *= k.gscale;
+    if (k.wd != 0.f) g += k.wd * p;
+    m = k.beta1 * m + (1.f - k.beta1) * g;
+    v = k.beta2 * v + (1.f - k.beta2) * g * g;
+    p = p - (lr / k.bc1) * m / (sqrtf(v) * k.rsb2 + k.eps);
+}
+
+// One tile of a GEMM weight: Adam on the fp32 master values AND the bf16 operand copies the next step's kernels read -
+// F [n][tap][Cpad] (forward) and D [c][taps-1-tap][Npad] (input gradient) - written from the freshly updated values through an
+// LDS tile, so the fp32 weights are not read a second time by a separate packing pass (1.8 GB / step at CRIS-R50).
+template <int PT>
+__device__ __forceinline__ void adam_pack_tile(const cris_adam_desc& d, int lb, const adam_coef& k, bf16_t* tile) {
+    constexpr int LROW = AP_LROW(PT);
+    const int tiles_c = (d.cin + AP_T - 1) / AP_T;
+    const int tn = lb / tiles_c, tc = lb - tn * tiles_c;
+    const int n0 = tn * AP_T, c0 = tc * AP_T;
+    const int rows = min(AP_T, d.N - n0), cw = min(AP_T, d.cin - c0);
+    if (!d.transposed) {
+        // parameter layout [n][c][tap]: for one n the tile's (c, tap) range is contiguous
+        for (int i = threadIdx.x; i < rows * AP_T * PT; i += 256) {
+            const int n_l = i / (AP_T * PT), e = i - n_l * (AP_T * PT);
+            const int c_l = e / PT, tap = e - c_l * PT;
+            if (c_l >= cw) continue;
+            const long pi = ((long)(n0 + n_l) * d.cin + c0) * PT + e;
+            const long gi = d.taps > 0 ? ((long)(n0 + n_l) * PT + tap) * d.cpad + c0 + c_l : pi;
+            float p = d.p[pi], m = d.m[pi], v = d.v[pi];
+            adam_update(k, d.lr, d.g[gi], p, m, v);
+            d.p[pi] = p; d.m[pi] = m; d.v[pi] = v;
+            tile[n_l * LROW + e] = f2bf(p);
+        }
+    } else {
+        // parameter stored [c][n] (used as x @ P), one tap: contiguous along n
+        for (int i = threadIdx.x; i < cw * AP_T; i += 256) {
+            const int c_l = i / AP_T, n_l = i - c_l * AP_T;
+            if (n_l >= rows) continue;
+            const long pi = (long)(c0 + c_l) * d.N + n0 + n_l;
+            float p = d.p[pi], m = d.m[pi], v = d.v[pi];
+            adam_update(k, d.lr, d.g[pi], p, m, v);
+            d.p[pi] = p; d.m[pi] = m; d.v[pi] = v;
+            tile[n_l * LROW + c_l * PT] = f2bf(p);
+        }
+    }
+    __syncthreads();
+    if (d.dstF) {                                  // F[(n*PT + tap)*Cpad + c]: consecutive threads = consecutive channels
+        const int cpadF = d.cpad;
+        for (int i = threadIdx.x; i < rows * PT * AP_T; i += 256) {
+            const int c_l = i & (AP_T - 1), r = i >> 6;
+            const int n_l = r / PT, tap = r - n_l * PT;
+            if (c_l < cw) d.dstF[((long)(n0 + n_l) * PT + tap) * cpadF + c0 + c_l] = tile[n_l * LROW + c_l * PT + tap];
+        }
+    }
+    if (d.dstD) {                                  // D[(c*PT + PT-1-tap)*Npad + n]: consecutive threads = consecutive rows n
+        for (int i = threadIdx.x; i < cw * PT * AP_T; i += 256) {
+            const int n_l = i & (AP_T - 1), r = i >> 6;
+            const int c_l = r / PT, tapf = r - c_l * PT;
+            if (n_l < rows) d.dstD[((long)(c0 + c_l) * PT + tapf) * d.npad + n0 + n_l] = tile[n_l * LROW + c_l * PT + (PT - 1 - tapf)];
+        }
+    }
+}
+
+template <int PT>
 __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restrict__ tab, int n_desc, float beta1, float beta2, float eps,
                                                    float wd, float bc1, float bc2, float gscale, const int* __restrict__ step_dev) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char adam_smem[];
     if (step_dev) {                       // step count lives on the device (HIP-graph replay): bias corrections from it,
         __shared__ float s_bc[2];         // in double precision like torch.optim.Adam's host arithmetic (1 - beta**t)
         if (threadIdx.x == 0) {
@@ -840,9 +910,13 @@ __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restr
         if (tab[mid].block_start <= bid) lo = mid; else hi = mid - 1;
     }
     const cris_adam_desc d = tab[lo];
+    adam_coef k;
+    k.beta1 = beta1; k.beta2 = beta2; k.eps = eps; k.wd = wd; k.bc1 = bc1; k.rsb2 = rsqrtf(bc2); k.gscale = gscale;
+    if (d.dstF || d.dstD) {               // block-uniform
+        adam_pack_tile<PT>(d, bid - d.block_start, k, reinterpret_cast<bf16_t*>(adam_smem));
+        return;
+    }
     const long base = (long)(bid - d.block_start) * ADAM_ELEMS;
-    const float step = d.lr / bc1;
-    const float rsb2 = rsqrtf(bc2);
     for (int e = threadIdx.x; e < ADAM_ELEMS; e += 256) {
         const long i = base + e;
         if (i >= d.n) break;
@@ -854,15 +928,15 @@ __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restr
             const int c = r / d.taps, tap = r - c * d.taps;
             gi = (n * d.taps + tap) * d.cpad + c;
         }
-        float g = d.g[gi] * gscale;
-        float p = d.p[i];
-        if (wd != 0.f) g += wd * p;
-        const float m = beta1 * d.m[i] + (1.f - beta1) * g;
-        const float v = beta2 * d.v[i] + (1.f - beta2) * g * g;
-        d.m[i] = m;
-        d.v[i] = v;
-        d.p[i] = p - step * m / (sqrtf(v) * rsb2 + eps);
+        float p = d.p[i], m = d.m[i], v = d.v[i];
+        adam_update(k, d.lr, d.g[gi], p, m, v);
+        d.p[i] = p; d.m[i] = m; d.v[i] = v;
     }
+}
+// blocks a descriptor needs (host): tiles for tensors whose bf16 packs are refreshed by the update, else 8192-element chunks
+extern "C" int cris_adam_blocks(const cris_adam_desc* d) {
+    if (d->dstF || d->dstD) return cris_cdiv(d->N, AP_T) * cris_cdiv(d->cin, AP_T);
+    return cris_cdiv(d->n, ADAM_ELEMS);
 }
 extern "C" int cris_adam_block_elems(void) { return ADAM_ELEMS; }
 
@@ -899,10 +973,19 @@ extern "C" int cris_unpack_grads(const cris_adam_desc* dev_table, int n_desc, in
 }
 extern "C" int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
                               float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
-                              void* stream) {
+                              int pack_taps, void* stream) {
     CRIS_CHECK_ARG(dev_table && n_desc > 0 && total_blocks > 0, "empty table");
-    hipLaunchKernelGGL(adam_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, dev_table, n_desc, beta1, beta2, eps,
-                       weight_decay, bias_corr1, bias_corr2, grad_scale, step_dev);
+    CRIS_CHECK_ARG(pack_taps == 1 || pack_taps == 9, "a table holds tensors packed with 1 tap (and unpacked ones) or with 9 taps");
+    typedef void (*adam_fn)(const cris_adam_desc*, int, float, float, float, float, float, float, float, const int*);
+    const adam_fn k9 = adam_kernel<9>, k1 = adam_kernel<1>;
+    constexpr int LDS9 = AP_T * AP_LROW(9) * 2, LDS1 = AP_T * AP_LROW(1) * 2;
+    static const int ready = (int)hipFuncSetAttribute((const void*)k9, hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
+    if (ready != 0) {
+        cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, ready);
+        return ready;
+    }
+    hipLaunchKernelGGL(pack_taps == 9 ? k9 : k1, dim3(total_blocks), dim3(256), pack_taps == 9 ? LDS9 : LDS1, (hipStream_t)stream, dev_table,
+                       n_desc, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale, step_dev);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

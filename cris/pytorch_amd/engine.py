@@ -207,15 +207,18 @@ class Engine:
 
     def _add_pack(self, name, N, Cin, taps, Cpad=None, want_D=True, transposed=False):
         src = self.P[name]
-        f, d = self.packs[self.stage_of(name)].add(src, N, Cin, taps, Cpad=Cpad, want_D=want_D, src_transposed=transposed)
+        tab = self.packs[self.stage_of(name)]
+        f, d = tab.add(src, N, Cin, taps, Cpad=Cpad, want_D=want_D, src_transposed=transposed)
         self.WF[name], self.WD[name] = f, d
+        self.pack_info[name] = tab.info[-1]
 
     def _build_packs(self):
-        # one pack table per arena stage: the trainer re-packs a stage right behind that stage's optimizer update, on the
-        # optimizer stream, underneath the rest of backward (packs_current); a forward that finds them stale re-packs all
+        # bf16 GEMM-operand copies of the weights (F: forward, D: input gradient).  The native trainer's Adam rewrites them
+        # from the updated values (packs_current stays True); a forward that finds them stale - first step, or parameters
+        # changed by someone else (the drop-in module under a torch optimizer) - re-packs all with one launch per stage
         self.packs = {st: ops.PackTable() for st in range(8)}
         self.packs_current = False
-        self.WF, self.WD = {}, {}
+        self.WF, self.WD, self.pack_info = {}, {}, {}
         for name, p in self.P.items():
             if p.dim() == 4:
                 N, Cin, taps, Cpad = self.gemm_layout(name)

@@ -153,7 +153,10 @@ class AdamDesc(C.Structure):
                 ("n", L),
                 ("lr", F), ("pad_", F),
                 ("block_start", I), ("taps", I),
-                ("cin", I), ("cpad", I)]
+                ("cin", I), ("cpad", I),
+                ("dstF", P), ("dstD", P),
+                ("N", I), ("npad", I),
+                ("transposed", I), ("pad2_", I)]
 
 
 class P2PParams(C.Structure):
@@ -236,7 +239,8 @@ _SIGS = {
     "cris_train_metric": (I, [P, P, I, I, F, F, P, P]),
     "cris_memset_f32": (I, [P, F, L, P]),
     "cris_zero_bytes": (I, [P, C.c_size_t, P]),
-    "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, P]),
+    "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, I, P]),
+    "cris_adam_blocks": (I, [P]),
     "cris_adam_block_elems": (I, []),
     "cris_unpack_grads": (I, [P, I, I, P]),
     "cris_p2p_mailbox_bytes": (C.c_size_t, [I, I, I]),

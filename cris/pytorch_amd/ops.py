@@ -264,6 +264,7 @@ class PackTable:
 
     def __init__(self):
         self.descs = []
+        self.info = []       # per tensor: (dstF, dstD, N, Cin, taps, Cpad, Npad, transposed) - what AdamTable(packs=) takes
         self.keep = []       # tensors referenced by the table
         self.dev = None
         self.total_blocks = 0
@@ -278,6 +279,7 @@ class PackTable:
         d.N, d.Cin, d.taps, d.Cpad, d.Npad, d.src_transposed = N, Cin, taps, Cpad, Npad, int(src_transposed)
         self.descs.append(d)
         self.keep.append((src, dstF, dstD))
+        self.info.append((dstF, dstD, N, Cin, taps, Cpad, Npad, bool(src_transposed)))
         self.dev = None
         return dstF, dstD
 
@@ -667,56 +669,82 @@ def memset_f32(t, v=0.0):
     hip.call("cris_memset_f32", ptr(t), float(v), t.numel(), _stream())
 
 
+class _AdamDeviceTable:
+    def __init__(self, arr, n, total_blocks, device):
+        self.arr, self.n, self.total_blocks = arr, n, total_blocks
+        self.dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device) if n else None
+
+    def upload(self, device):
+        if self.n:
+            self.dev = torch.frombuffer(bytearray(bytes(self.arr)), dtype=torch.uint8).to(device)
+
+
 class AdamTable:
-    """Device table of {p, g, m, v, n, lr}: one launch = torch.optim.Adam.step() over every tensor."""
+    """Device tables of {p, g, m, v, n, lr [, bf16 packs]}: torch.optim.Adam.step() over every tensor in two launches - the
+    3x3 convolution weights whose bf16 operand copies are refreshed by the update (9-tap tiles: 74 KB of LDS per block) and
+    everything else (1-tap packed weights and plain tensors)."""
 
-    def __init__(self, params, grads, lrs, layouts=None, share_state_of=None, names=None):
+    def __init__(self, params, grads, lrs, layouts=None, packs=None):
         """layouts[i]: None (gradient in the parameter layout) or (N, Cin, taps, Cpad) (GEMM layout, see cris_conv_wgrad).
-        share_state_of / names=(all_names, my_names): a table over a SUBSET of another table's tensors that uses that
-        table's m / v buffers (per-stage optimizer tables of trainer.py)."""
+        packs[i]: None or (dstF, dstD, N, Cin, taps, Cpad, Npad, transposed) - the bf16 GEMM-operand copies of tensor i
+        (PackTable layouts) that the update rewrites from the new values."""
         lib = hip.load()
-        be = lib.cris_adam_block_elems()
-        if share_state_of is not None:
-            idx = {n: i for i, n in enumerate(names[0])}
-            self.m = [share_state_of.m[idx[n]] for n in names[1]]
-            self.v = [share_state_of.v[idx[n]] for n in names[1]]
-        else:
-            self.m = [torch.zeros_like(p) for p in params]
-            self.v = [torch.zeros_like(p) for p in params]
+        self.m = [torch.zeros_like(p) for p in params]
+        self.v = [torch.zeros_like(p) for p in params]
         self.params, self.grads, self.lrs = list(params), list(grads), list(lrs)
-        n = len(self.params)
-        self.arr = (hip.AdamDesc * n)()
-        start = 0
-        for i, (p, g) in enumerate(zip(self.params, self.grads)):
-            d = self.arr[i]
-            d.p, d.g, d.m, d.v, d.n, d.lr = ptr(p), ptr(g), ptr(self.m[i]), ptr(self.v[i]), p.numel(), self.lrs[i]
-            lay = layouts[i] if layouts is not None else None
-            if lay is not None and not (lay[2] == 1 and lay[3] == lay[1]):
-                d.taps, d.cin, d.cpad = lay[2], lay[1], lay[3]
-            d.block_start = start
-            start += (p.numel() + be - 1) // be
-        self.total_blocks = start
-        self.n = n
-        self.dev = None
+        self.packs = list(packs) if packs is not None else [None] * len(self.params)
+        self.device = self.params[0].device
+        groups = {9: [], 1: []}
+        for i in range(len(self.params)):
+            pk = self.packs[i]
+            groups[9 if (pk is not None and pk[4] == 9) else 1].append(i)
+        self.index = groups
+        self.tables = {}
+        for taps, idx in groups.items():
+            arr = (hip.AdamDesc * max(len(idx), 1))()
+            start = 0
+            for j, i in enumerate(idx):
+                p, g = self.params[i], self.grads[i]
+                d = arr[j]
+                d.p, d.g, d.m, d.v, d.n, d.lr = ptr(p), ptr(g), ptr(self.m[i]), ptr(self.v[i]), p.numel(), self.lrs[i]
+                lay = layouts[i] if layouts is not None else None
+                if lay is not None and not (lay[2] == 1 and lay[3] == lay[1]):
+                    d.taps, d.cin, d.cpad = lay[2], lay[1], lay[3]
+                pk = self.packs[i]
+                if pk is not None:
+                    dstF, dstD, N, Cin, ptaps, Cpad, Npad, transposed = pk
+                    assert ptaps in (1, 9), "packed weights have 1 or 9 taps"
+                    assert d.taps in (0, ptaps)
+                    d.dstF, d.dstD = ptr(dstF), ptr(dstD)
+                    d.N, d.cin, d.cpad, d.npad, d.transposed = N, Cin, Cpad, Npad, int(transposed)
+                d.block_start = start
+                start += lib.cris_adam_blocks(C.byref(d))
+            self.tables[taps] = _AdamDeviceTable(arr, len(idx), start, self.device)
+        self.keep = [pk[:2] for pk in self.packs if pk is not None]
         self.step_count = 0
-        self._upload(self.params[0].device)
-
-    def _upload(self, device):
-        self.dev = torch.frombuffer(bytearray(bytes(self.arr)), dtype=torch.uint8).to(device)
 
     def set_lrs(self, lrs):
         self.lrs = list(lrs)
-        for i, lr in enumerate(self.lrs):
-            self.arr[i].lr = lr
-        self._upload(self.params[0].device)
+        for taps, idx in self.index.items():
+            t = self.tables[taps]
+            for j, i in enumerate(idx):
+                t.arr[j].lr = self.lrs[i]
+            t.upload(self.device)
+
+    @property
+    def refreshes_packs(self):
+        return any(pk is not None for pk in self.packs)
 
     def step(self, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, step_dev=None):
         """step_dev: optional int32 device tensor holding the 1-based step count (graph replay); else a host counter"""
         self.step_count += 1
         bc1 = 1.0 - beta1 ** self.step_count
         bc2 = 1.0 - beta2 ** self.step_count
-        hip.call("cris_adam_step", ptr(self.dev), self.n, self.total_blocks, beta1, beta2, eps, weight_decay, bc1, bc2,
-                 grad_scale, ptr(step_dev), _stream())
+        for taps in (9, 1):
+            t = self.tables[taps]
+            if t.n:
+                hip.call("cris_adam_step", ptr(t.dev), t.n, t.total_blocks, beta1, beta2, eps, weight_decay, bc1, bc2,
+                         grad_scale, ptr(step_dev), taps, _stream())
 
 
 class UnpackTable:

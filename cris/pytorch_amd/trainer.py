@@ -67,12 +67,6 @@ class NativeTrainer:
         self.names = names
         self.group = {n: (0 if (n.startswith("backbone") and "positional_embedding" not in n) else 1) for n in names}
         self.base_lr, self.lr_multi, self.weight_decay = base_lr, lr_multi, weight_decay
-        # Optional (CRIS_STAGED_ADAM=1, single GPU): the optimizer update and the weight re-pack of an arena stage run on their
-        # own stream as soon as backward has finished that stage's gradients, underneath the rest of backward.  Implemented
-        # and trajectory-tested, but MEASURED SLOWER (18.8 -> 21.9 ms/step: the HBM-bound update kernels take bandwidth and
-        # cache from the GEMMs they overlap with), so the default keeps one Adam + one re-pack launch at the step boundary.
-        staged = os.environ.get("CRIS_STAGED_ADAM", "0") == "1" and torch.device(device).type == "cuda"
-        self.ostream = torch.cuda.Stream(device=device) if staged else None
         self._build_adam([base_lr] * len(names))
         self.metric = torch.zeros(2, device=device)
         # per-step device state: steps done (int32) and the dropout seed of the running step
@@ -106,13 +100,7 @@ class NativeTrainer:
         e, names = self.engine, self.names
         lr_of = dict(zip(names, lrs))
         self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [lr_of[n] for n in names],
-                                  layouts=[e.gemm_layout(n) for n in names])
-        self.adam_stage = {}
-        for st in (range(8) if self.ostream is not None else ()):
-            sn = [n for n in names if e.stage_of(n) == st]
-            if sn:
-                self.adam_stage[st] = ops.AdamTable([e.P[n] for n in sn], [e.G[n] for n in sn], [lr_of[n] for n in sn],
-                                                    layouts=[e.gemm_layout(n) for n in sn], share_state_of=self.adam, names=(names, sn))
+                                  layouts=[e.gemm_layout(n) for n in names], packs=[e.pack_info.get(n) for n in names])
 
     @property
     def step_idx(self):
@@ -121,8 +109,6 @@ class NativeTrainer:
     def set_group_lrs(self, lr_backbone, lr_head):
         lrs = [lr_backbone if self.group[n] == 0 else lr_head for n in self.names]
         self.adam.set_lrs(lrs)
-        for st, tab in self.adam_stage.items():
-            tab.set_lrs([lr for n, lr in zip(self.names, lrs) if self.engine.stage_of(n) == st])
         self._graph = self._cmds = None          # learning rates live in the device table, which was re-uploaded (new
         self._eager_steps = 0                    # address): capture / record again
 
@@ -146,23 +132,11 @@ class NativeTrainer:
                 ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))
             e.backward(on_stage_done=on_stage)
             ops.torch_op(self.comm.wait_all)
-            self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
-            e.packs_current = False
-        elif self.ostream is None:
-            e.backward()
-            self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0, step_dev=self.step_dev)
-            e.packs_current = False
         else:
-            def on_stage(st):
-                cur = torch.cuda.current_stream()
-                ops.torch_op(lambda: self.ostream.wait_stream(cur))
-                with torch.cuda.stream(self.ostream):
-                    self.adam_stage[st].step(weight_decay=self.weight_decay, grad_scale=1.0, step_dev=self.step_dev)
-                    e.repack_stage(st)
-            e.backward(on_stage_done=on_stage)
-            main = torch.cuda.current_stream()
-            ops.torch_op(lambda: main.wait_stream(self.ostream))
-            e.packs_current = True
+            e.backward()
+        # one Adam pass over every tensor; it also rewrites the bf16 operand copies of the GEMM weights from the new values
+        self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
+        e.packs_current = self.adam.refreshes_packs
         ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         return loss, pred, msk
 

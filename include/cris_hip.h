@@ -357,18 +357,25 @@ int cris_zero_bytes(void* p, size_t nbytes, void* stream);
 /* fused multi-tensor Adam (torch.optim.Adam semantics, train.py:105-107): table of {p,g,m,v,n}.
  * p/m/v are in the parameter layout; g is in the parameter layout when taps == 0, else in the GEMM layout
  * [n][tap][cpad] written by cris_conv_wgrad (element (n, c, tap) of the parameter reads g[(n*taps + tap)*cpad + c]).
+ * dstF / dstD (optional): the bf16 GEMM-operand copies of a weight (layouts of cris_pack_desc); the update then also writes
+ * them from the new values (tile by tile through LDS) - no separate packing pass re-reads the fp32 weights.  A table holds
+ * either the 9-tap (3x3) packed tensors or everything else (pack_taps of cris_adam_step: 9 / 1).
  * step_dev (optional, device int32): 1-based step count read on the device - the bias corrections are then
- * 1 - beta^step and bias_corr1/2 are ignored (lets a captured HIP graph be replayed step after step). */
+ * 1 - beta^step (in double) and bias_corr1/2 are ignored (lets a captured HIP graph be replayed step after step). */
 typedef struct {
     float* p; const float* g; float* m; float* v;
     long n;
     float lr; float pad_;
     int block_start; int taps;
     int cin; int cpad;
+    cris_bf16* dstF; cris_bf16* dstD;
+    int N; int npad;                 /* packed tensors: rows, padded rows of the D layout (cin / cpad above) */
+    int transposed; int pad2_;       /* packed: parameter stored [cin][N] (one tap) */
 } cris_adam_desc;
 int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
                    float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
-                   void* stream);
+                   int pack_taps, void* stream);
+int cris_adam_blocks(const cris_adam_desc* d);       /* blocks one descriptor occupies (host: block_start prefix sums) */
 int cris_adam_block_elems(void);
 /* dst (param layout, desc.p) <- src (GEMM layout, desc.g) for a table of tensors; block_start as for cris_adam_step */
 int cris_unpack_grads(const cris_adam_desc* dev_table, int n_desc, int total_blocks, void* stream);

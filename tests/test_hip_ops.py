@@ -788,6 +788,44 @@ def test_adam_gemm_layout_gradient_and_device_step():
     check(dev_p, rp.data, 1e-6, "adam gemm-layout")
 
 
+def test_adam_refreshes_the_bf16_packs():
+    """the optimizer update also rewrites the F / D operand copies of the GEMM weights (no separate packing pass): after a
+    step the packs written by cris_adam_step equal, bit for bit, what cris_pack_weights makes of the updated parameters -
+    3x3 conv with ragged N / Cin and a GEMM-layout gradient, a linear weight, a transposed ([in, out]) projection, next to
+    an unpacked tensor in the same table; parameters agree with torch.optim.Adam."""
+    N3, C3, Cp3 = 70, 66, 72
+    w3 = rnd(N3, C3, 3, 3).to(DEV)
+    g3 = rnd(N3, C3, 3, 3, seed=3)
+    g3g = torch.zeros(N3, 9, Cp3)
+    g3g[:, :, :C3] = g3.permute(0, 2, 3, 1).reshape(N3, 9, C3)
+    wl, gl = rnd(100, 72, seed=1).to(DEV), rnd(100, 72, seed=4)
+    wt, gt = rnd(64, 136, seed=2).to(DEV), rnd(64, 136, seed=5)          # [Cin=64][N=136], used as x @ wt
+    wb, gb = rnd(300, seed=6).to(DEV), rnd(300, seed=7)                   # a bias: no packs
+    tab = ops.PackTable()
+    tab.add(w3.view(N3, C3, 9), N3, C3, 9, Cpad=Cp3)
+    tab.add(wl.view(100, 72, 1), 100, 72, 1)
+    tab.add(wt, 136, 64, 1, src_transposed=True)
+    params = [w3, wl, wt, wb]
+    grads = [g3g.reshape(N3, 9 * Cp3).to(DEV), gl.to(DEV), gt.to(DEV), gb.to(DEV)]
+    adam = ops.AdamTable(params, grads, [1e-3] * 4, layouts=[(N3, C3, 9, Cp3), None, None, None], packs=tab.info + [None])
+    assert adam.refreshes_packs
+    ref = [torch.nn.Parameter(t.detach().cpu().clone()) for t in params]
+    opt = torch.optim.Adam(ref, lr=1e-3)
+    for step in range(2):
+        for rp, g in zip(ref, (g3, gl, gt, gb)):
+            rp.grad = g.clone()
+        opt.step()
+        adam.step()
+    for t, rp in zip(params, ref):
+        check(t, rp.data, 1e-6, "adam + packs: parameters")
+    got = [(f.clone(), None if d is None else d.clone()) for f, d, *_ in tab.info]
+    tab.run()                                                  # the reference packing of the updated parameters
+    torch.cuda.synchronize()
+    for (f, d, *_), (gf, gd) in zip(tab.info, got):
+        assert torch.equal(f, gf), "F pack written by the optimizer differs from cris_pack_weights"
+        assert torch.equal(d, gd), "D pack written by the optimizer differs from cris_pack_weights"
+
+
 def test_zero_bytes():
     for n in (1, 15, 16, 17, 4099, 1 << 20):
         t = torch.full((n + 32,), 7, dtype=torch.uint8, device=DEV)
