@@ -209,20 +209,23 @@ class WgradQueue:
     queues them while backward walks an arena stage and flushes at the stage boundary (or when enough blocks are waiting),
     longest reductions first.  Operand tensors are kept alive until their launch has been issued."""
 
-    def __init__(self):
+    def __init__(self, on_full=None):
         self.items = []
         self.blocks = 0
+        self.on_full = on_full        # called instead of flush() when enough blocks are waiting (the engine picks the stream)
 
     def add(self, p, keep, flops, nbytes):
         self.items.append((p, keep, flops, nbytes))
         self.blocks += ((p.N + 127) // 128) * ((p.K + 127) // 128)
         if self.blocks >= _WGRAD_FLUSH_BLOCKS:
-            self.flush()
+            (self.on_full or self.flush)()
 
     def flush(self):
+        """launch everything queued on the current stream; returns the operand tensors of the launched problems (a caller
+        that launches on a side stream keeps them alive until that stream has been joined)"""
         items, self.items, self.blocks = self.items, [], 0
         if not items:
-            return
+            return []
         items.sort(key=lambda it: -it[0].M)                    # stable: longest pixel reductions are dispatched first
         for i in range(0, len(items), hip.WGRAD_GROUP_MAX):
             chunk = items[i:i + hip.WGRAD_GROUP_MAX]
@@ -235,6 +238,7 @@ class WgradQueue:
                                     C.byref(grp), tag="group of %d (M %d..%d)" % (len(chunk), chunk[-1][0].M, chunk[0][0].M))
             else:
                 hip.call("cris_conv_wgrad_group", C.byref(grp), _stream())
+        return [it[1] for it in items]
 
 
 def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, ldw=None, splits=None, dbias=None,

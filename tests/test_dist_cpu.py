@@ -67,3 +67,27 @@ def test_gloo_world2_syncbn_merge_and_grad_allreduce():
         assert ok_bn, "SyncBN merge != concatenated-batch statistics on rank %d" % rank
         assert ok_ar, "staged all-reduce wrong on rank %d" % rank
         assert ok_shard
+
+
+def test_single_exchange_cancellation_bound_fp32():
+    """the SyncBN single-exchange arithmetic in fp32 with the reference d standard deviations from the batch mean (a fresh
+    BatchNorm: running mean 0): relative variance error ~ eps * (1 + d^2)  (see the GPU test of cris_bn_sync_unpack)."""
+    from cris.pytorch_amd.dist import merge_batchnorm_partials
+
+    class One:
+        world = 2
+        def __init__(self):
+            self.buf = None
+        def allreduce_sum(self, t):
+            t.mul_(2.0)                                    # two identical ranks
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2000, 32, generator=g, dtype=torch.float64) * 0.5
+    for d, tol in ((20.0, 2e-4), (100.0, 5e-3)):
+        y = x + 0.5 * d
+        s = y.sum(0).float()
+        m2 = ((y - y.mean(0)) ** 2).sum(0).float()
+        mean_g, var_g = merge_batchnorm_partials(s, m2, 2000.0, One(), ref=torch.zeros(32))
+        ref_var = y.var(0, unbiased=False)
+        assert float(((var_g.double() - ref_var) / ref_var).abs().max()) < tol, d
+        assert float((mean_g.double() - y.mean(0)).abs().max()) < 1e-4

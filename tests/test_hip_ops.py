@@ -855,3 +855,31 @@ def test_syncbn_single_exchange_kernels():
                     global_stats=g)
     check(outs[2], y.double().mean(0), 1e-6, "global mean")
     check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), 1e-5, "global invstd")
+
+
+@pytest.mark.parametrize("d,tol", [(20.0, 2e-4), (100.0, 5e-3)])
+def test_syncbn_single_exchange_far_reference(d, tol):
+    """the worst case of the single-exchange form: a FRESH BatchNorm (running mean = 0, the reference the moments are taken
+    about) whose input sits d standard deviations away from zero.  M2 = S2 - S1^2/N then cancels (1 + d^2) : 1, i.e. the
+    variance loses eps_fp32 * (1 + d^2) of relative accuracy: 2.4e-5 at d = 20, 6e-4 at d = 100 (the bounds asserted on
+    1/std are 10x that).  Post-ReLU / post-BatchNorm inputs of this network have |mean|/std of order 1; after a few steps the
+    running mean tracks the batch mean and d goes to 0."""
+    M, C_ = 4000, 64
+    y = (rnd(M, C_) * 0.5 + 0.5 * d).to(BF).float()             # std 0.5, mean d * std
+    ref = torch.zeros(C_, device=DEV)
+    packed = []
+    for half in (y[:2000], y[2000:]):
+        n = half.shape[0]
+        st = ops.colstats(bf(half), n, C_, 32, DEV)
+        merged, mean_l = torch.zeros(2 * C_, device=DEV), torch.empty(C_, device=DEV)
+        ops.bn_finalize(st, n, n, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, None, None,
+                        mean_l, None, merged=merged)
+        ops.bn_sync_pack(merged, mean_l, ref, n, C_)
+        packed.append(merged)
+    g = packed[0] + packed[1]
+    ops.bn_sync_unpack(g, ref, M, C_)
+    outs = [torch.empty(C_, device=DEV) for _ in range(4)]
+    ops.bn_finalize(None, 2000, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs,
+                    global_stats=g)
+    check(outs[2], y.double().mean(0), 1e-6, "global mean, reference %g std away" % d)
+    check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), tol, "global invstd, reference %g std away" % d)
