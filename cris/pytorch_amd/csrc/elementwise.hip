@@ -728,12 +728,14 @@ extern "C" int cris_mask_resize_nearest(const float* mask, int Bn, int IH, int I
     return 0;
 }
 
-// ONE block of 1024 threads (the loss is 86 k - 115 k elements: launch latency, not bandwidth), fixed summation order
-__global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* x, const float* t, long n, float* loss) {
-    __shared__ float sw[16];
+// BCE partial sums: one partial per block (fixed order inside the block), then one wave adds the partials in block order -
+// deterministic without atomics, and the element pass still runs on many CUs
+#define BCE_BLOCKS 128
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* x, const float* t, long n, float* part) {
+    __shared__ float sw[4];
     float s = 0.f;
     const long n4 = n >> 2;
-    for (long i = threadIdx.x; i < n4; i += 1024) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)BCE_BLOCKS * 256) {
         const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
         const float4 y = *reinterpret_cast<const float4*>(t + i * 4);
         s += fmaxf(v.x, 0.f) - v.x * y.x + log1pf(__expf(-fabsf(v.x)));
@@ -741,24 +743,27 @@ __global__ __launch_bounds__(1024) void bce_fwd_kernel(const float* x, const flo
         s += fmaxf(v.z, 0.f) - v.z * y.z + log1pf(__expf(-fabsf(v.z)));
         s += fmaxf(v.w, 0.f) - v.w * y.w + log1pf(__expf(-fabsf(v.w)));
     }
-    for (long i = n4 * 4 + threadIdx.x; i < n; i += 1024) {
-        const float v = x[i];
-        s += fmaxf(v, 0.f) - v * t[i] + log1pf(__expf(-fabsf(v)));
-    }
+    if (blockIdx.x == 0)
+        for (long i = n4 * 4 + threadIdx.x; i < n; i += 256) {
+            const float v = x[i];
+            s += fmaxf(v, 0.f) - v * t[i] + log1pf(__expf(-fabsf(v)));
+        }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sw[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = 0.f;
-#pragma unroll
-        for (int w = 0; w < 16; ++w) a += sw[w];
-        loss[0] = a / (float)n;
-    }
+    if (threadIdx.x == 0) part[blockIdx.x] = (sw[0] + sw[1]) + (sw[2] + sw[3]);
 }
-extern "C" int cris_bce_fwd(const float* logits, const float* target, long n, float* loss, void* stream) {
-    CRIS_CHECK_ARG(logits && target && loss && n > 0, "bad args");
+__global__ __launch_bounds__(64) void bce_finish_kernel(const float* part, long n, float* loss) {
+    float a = part[threadIdx.x] + part[threadIdx.x + 64];          // BCE_BLOCKS == 128
+    a = wave_sum(a);                                               // fixed butterfly order
+    if (threadIdx.x == 0) loss[0] = a / (float)n;
+}
+extern "C" int cris_bce_ws_floats(void) { return BCE_BLOCKS; }
+extern "C" int cris_bce_fwd(const float* logits, const float* target, long n, float* loss, float* ws, void* stream) {
+    CRIS_CHECK_ARG(logits && target && loss && ws && n > 0, "bad args");
     CRIS_CHECK_ARG((uintptr_t)logits % 16 == 0 && (uintptr_t)target % 16 == 0, "operands must be 16-byte aligned");
-    hipLaunchKernelGGL(bce_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, target, n, loss);
+    hipLaunchKernelGGL(bce_fwd_kernel, dim3(BCE_BLOCKS), dim3(256), 0, (hipStream_t)stream, logits, target, n, ws);
+    hipLaunchKernelGGL(bce_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, ws, n, loss);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -34,12 +34,9 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; 
 // LEAN: compile-time promise of the plain conv / dgrad case (bf16 output, optional bf16 residual, optional statistics;
 // no bias, activation, dropout, transposed copy, fp32 I/O or fused BN-backward sums) - the epilogue every block of the ~190
 // convolution GEMMs per step runs; the general form costs thousands of instructions per wave.
-// LEAN + `wsm` (this wave's private LDS region of FM*MT rows x (FN*MT*2 + 16) bytes): the bf16 tile goes through LDS and
-// leaves as 16-byte row segments (8 lanes = one full 128-byte line) instead of one 2-byte store per element - the K <= 256
-// 1x1 convolutions of layers 1-2 are bound by exactly these stores.  Needs N, ldc, c_coff multiples of 8 and no residual.
 template <bool LEAN, int MT, int FM, int FN, typename ACC>
 __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, ACC (&acc)[FM][FN], int row0, int col0, int part,
-                                              int lane, unsigned char* wsm = nullptr) {
+                                              int lane) {
     // MT = 16: v_mfma_f32_16x16x32 C/D layout  col = lane&15, row = (lane>>4)*4 + r            (r = 0..3)
     // MT = 32: v_mfma_f32_32x32x16 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (reg = 0..15)
     // both: per lane NG groups of 4 consecutive rows of one column
@@ -54,8 +51,6 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
     // residual reads and output writes go through raw buffer descriptors: an element outside the problem (row >= M,
     // column >= N) is an out-of-range offset - reads return 0, writes are dropped - so the epilogue has no per-element
     // branches and its residual loads are issued together instead of one wait per element
-    constexpr int WPITCH = FN * MT * 2 + 16;          // bytes per row of the wave's LDS tile (+16: rows 4 apart land on other banks)
-    const bool wide = LEAN && wsm != nullptr;         // block-uniform
     const bool has_res = p.resid != nullptr, has_out = p.out != nullptr;
     const bool res_f32 = !LEAN && p.resid_f32, out_f32 = !LEAN && p.out_f32;
     const int act = LEAN ? 0 : p.act;
@@ -112,10 +107,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                     bs0 += g;
                     bs1 += g * (yv - bmu) * biv;
                 }
-                if (wide) {
-                    const int lrow = i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4) + r;
-                    *reinterpret_cast<bf16_t*>(wsm + lrow * WPITCH + (j * MT + fr) * 2) = f2bf(x);
-                } else if (has_out) {
+                if (has_out) {
                     const unsigned off = valid ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(p.c_coff + col)) * out_es : CRIS_OOB;
                     if (out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(x), rsO, off, 0, 0);
@@ -183,19 +175,6 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 p.colsum[(size_t)part * p.N + col] = s1;
                 p.colsq[(size_t)part * p.N + col] = q;
             }
-        }
-    }
-    if (wide) {
-        // the wave's tile, read back as 16-byte row segments (LDS operations of one wave execute in order)
-        constexpr int CH = FN * MT / 8, RPI = 64 / CH;    // 16-byte chunks per row, rows per wave instruction
-        const int ch = lane % CH, lr0 = lane / CH;
-#pragma unroll
-        for (int it = 0; it < FM * MT / RPI; ++it) {
-            const int lrow = it * RPI + lr0;
-            const int m = row0 + lrow, col = col0 + ch * 8;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(wsm + lrow * WPITCH + ch * 16);
-            const unsigned off = (m < p.M && col < p.N) ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(p.c_coff + col)) * 2u : CRIS_OOB;
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsO, off, 0, 0);
         }
     }
 }
@@ -414,18 +393,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     }
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 
-    unsigned char* wsm = nullptr;
-    if constexpr (LEAN) {
-        // wide-store epilogue (see gemm_epilogue): each wave reuses a private slice of the operand ring once every wave
-        // has finished reading the last K-step
-        constexpr int WREG = WTM * (WTN * 2 + 16);
-        static_assert(4 * WREG <= STAGES * STAGE_BYTES, "epilogue tiles must fit the operand ring");
-        if (p.out && !p.resid && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (p.c_coff & 7) == 0) {
-            __syncthreads();
-            wsm = smem + wave * WREG;
-        }
-    }
-    gemm_epilogue<LEAN, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane, wsm);
+    gemm_epilogue<LEAN, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
 }
 
 // Skinny kernel (M <= FM*16 rows, 1x1 geometry: text encoder / per-sample vectors).  Such GEMMs are pure latency: one

@@ -8,7 +8,7 @@
 // BN coefficients
 // ------------------------------------------------------------------------------------------------
 #define BN_MERGE_SLICES 64      // first-level merge width for long partial lists (see cris_bn_partials_rows)
-#define BN_MERGE_MIN 512        // lists up to this long go straight to the (16-lane) final merge
+#define BN_MERGE_MIN 1024       // lists up to this long go straight to the (64-lane) final merge
 
 // Chan et al. pairwise update of (n, mean, M2) with a block (nb rows, sum sb, M2 mb)
 __device__ __forceinline__ void chan_add(float& n, float& mean, float& m2, float nb, float sb, float mb) {
@@ -48,20 +48,24 @@ __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__
     }
 }
 
-// final merge + coefficients: block = 16 channels x 16 part lanes (coalesced 64-B rows), LDS tree over the part lanes
+// final merge + coefficients: block = 4 channels x 64 part lanes (the kernel is pure latency - a handful of blocks on an idle
+// chip - so the part list is spread over many lanes: ceil(nparts / 64) dependent merges per lane), then the lanes are merged in
+// lane order (deterministic)
+#define BNF_CH 4
+#define BNF_PL 64
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
                                    float count, const float* gamma, const float* beta, float* rmean, float* rvar,
                                    float momentum, float eps, int C, float* scale, float* shift, float* mean_o,
                                    float* invstd_o, float* merged /* optional [2*C]: local (sum, M2) for SyncBN */,
                                    const float* global_stats /* optional [2*C]: (sum, M2 about the global mean) */) {
-    __shared__ float sh[3][16][17];
-    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ float sh[3][BNF_PL][BNF_CH + 1];
+    const int cl = threadIdx.x & (BNF_CH - 1), pl = threadIdx.x / BNF_CH;
+    const int c = blockIdx.x * BNF_CH + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (!global_stats) {
         if (c < C) {
             const int M = (int)count_local;
-            for (int i = pl; i < nparts; i += 16) {
+            for (int i = pl; i < nparts; i += BNF_PL) {
                 const int rows = min(rows_per_part, M - i * rows_per_part);
                 if (rows > 0) chan_add(n, mean, m2, (float)rows, psum[(size_t)i * C + c], pm2[(size_t)i * C + c]);
             }
@@ -69,8 +73,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, con
         sh[0][pl][cl] = n; sh[1][pl][cl] = mean; sh[2][pl][cl] = m2;
         __syncthreads();
         if (pl != 0 || c >= C) return;
-#pragma unroll
-        for (int j = 1; j < 16; ++j) chan_add(n, mean, m2, sh[0][j][cl], sh[1][j][cl] * sh[0][j][cl], sh[2][j][cl]);
+        for (int j = 1; j < BNF_PL; ++j) chan_add(n, mean, m2, sh[0][j][cl], sh[1][j][cl] * sh[0][j][cl], sh[2][j][cl]);
         if (merged) {                       // hand the local (sum, M2) to the SyncBN exchange; finalize runs again after it
             merged[c] = mean * n;
             merged[C + c] = m2;
@@ -144,7 +147,7 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
         nparts = slices;
         rows_per_part *= pps;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, BNF_CH)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
                        count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
                        merged, global_stats);
     CRIS_LAUNCH_CHECK();
@@ -598,25 +601,41 @@ static bn_bwd_reduce_fn bn_bwd_reduce_fast_table(int mask, bool y2, bool pool) {
 }
 
 // gradient of the per-sample multiplier (FPN: f5 = relu(bn(y)) * state, model/layers.py:289): dmul[b][c] = sum over the pixels of
-// sample b of dz * relu(bn(y)).  One thread per (sample, 8 channels), pixels in order: deterministic.
+// sample b of dz * relu(bn(y)).  Block = (sample, 64 channels): 8 channel vectors x 32 pixel lanes, each lane adds its pixels
+// in order, the lanes are added in lane order through LDS: deterministic.
 __global__ __launch_bounds__(256) void bn_dmul_kernel(const cris_bn_bwd_params p) {
+    __shared__ float sh[32][8][8 + 1];
     const int CV = p.C >> 3, HW = p.H * p.W;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= p.Bn * CV) return;
-    const int b = idx / CV, c0 = (idx - b * CV) * 8;
-    float sc[8], sh[8], acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    load8f(p.scale + c0, sc);
-    load8f(p.shift + c0, sh);
-    for (int r = 0; r < HW; ++r) {
-        const size_t m = (size_t)b * HW + r;
-        float y[8], dz[8];
-        load8bf(p.y + m * p.ldy + p.y_coff + c0, y);
-        load8bf(p.dz + m * p.lddz + p.dz_coff + c0, dz);
+    const int chunks = (CV + 7) / 8;
+    const int b = blockIdx.x / chunks, cvb = (blockIdx.x - b * chunks) * 8;
+    const int cvl = threadIdx.x & 7, pl = threadIdx.x >> 3;
+    const int cv = cvb + cvl;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (cv < CV) {
+        const int c0 = cv * 8;
+        float sc[8], shf[8];
+        load8f(p.scale + c0, sc);
+        load8f(p.shift + c0, shf);
+        for (int r = pl; r < HW; r += 32) {
+            const size_t m = (size_t)b * HW + r;
+            float y[8], dz[8];
+            load8bf(p.y + m * p.ldy + p.y_coff + c0, y);
+            load8bf(p.dz + m * p.lddz + p.dz_coff + c0, dz);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += dz[j] * fmaxf(y[j] * sc[j] + sh[j], 0.f);
+            for (int j = 0; j < 8; ++j) acc[j] += dz[j] * fmaxf(y[j] * sc[j] + shf[j], 0.f);
+        }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) p.dmul[(size_t)b * p.C + c0 + j] = acc[j];
+    for (int j = 0; j < 8; ++j) sh[pl][cvl][j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x >> 3, j = threadIdx.x & 7;
+        if (cvb + l < CV) {
+            float a = 0.f;
+            for (int q = 0; q < 32; ++q) a += sh[q][l][j];
+            p.dmul[(size_t)b * p.C + (cvb + l) * 8 + j] = a;
+        }
+    }
 }
 
 // row blocks of the reduction = rows of the partials table
@@ -659,7 +678,7 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, blocks, ncol, p.sums);
     CRIS_LAUNCH_CHECK();
     if (p.mul && p.dmul) {
-        hipLaunchKernelGGL(bn_dmul_kernel, dim3(cris_cdiv((long)p.Bn * (p.C >> 3), 256)), dim3(256), 0, (hipStream_t)stream, p);
+        hipLaunchKernelGGL(bn_dmul_kernel, dim3(p.Bn * cris_cdiv(p.C >> 3, 8)), dim3(256), 0, (hipStream_t)stream, p);
         CRIS_LAUNCH_CHECK();
     }
     return 0;

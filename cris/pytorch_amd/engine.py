@@ -101,12 +101,7 @@ class Engine:
         # the text encoder (12 layers of M = B*L ~ 136-row GEMMs: latency-bound, ~16 workgroups each) is independent of
         # the visual encoder until the neck: it runs on a second HIP stream, forward and backward, underneath the convs
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
-        # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue).
-        # CRIS_WGRAD_STREAM=1 (experiment): the grouped launches go to a second stream - few, large, efficient launches that
-        # only feed the gradient arena - underneath the latency-bound dgrad / BatchNorm chain of the launch stream.
-        self.wstream = (torch.cuda.Stream(device=device)
-                        if torch.device(device).type == "cuda" and os.environ.get("CRIS_WGRAD_STREAM", "0") == "1" else None)
-        self._wkeep = []
+        # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue)
         self._wq, self._sq = ops.WgradQueue(self._flush_wgrads), ops.SumQueue()
         # Folding a BatchNorm's backward reduction into its consumer conv's input-gradient GEMM epilogue is implemented and
         # parity-tested, but MEASURED SLOWER (21.0 -> 22.0 ms/step at R50/416/B=8: the per-element y reads and extra
@@ -282,27 +277,13 @@ class Engine:
         return Act(t, Bn, H, W, C, ld)
 
     def _flush_wgrads(self):
-        if self.wstream is None or not self._wq.items:
-            self._wq.flush()
-            return
-        cur = torch.cuda.current_stream()
-        ops.torch_op(lambda: self.wstream.wait_stream(cur))      # every queued operand has been produced on `cur` by now
-        with torch.cuda.stream(self.wstream):
-            self._wkeep.extend(self._wq.flush())                 # operands stay allocated until the streams are joined
+        self._wq.flush()
 
-    def _join_wgrads(self):
-        if self.wstream is not None:
-            cur = torch.cuda.current_stream()
-            ops.torch_op(lambda: cur.wait_stream(self.wstream))
-
-    def _flush_queues(self, join=False):
-        """launch what backward has queued so far: grouped weight gradients and the ordered sums of the LayerNorm
-        parameter-gradient partials.  join: the current stream then waits for the weight-gradient stream (a stage's
-        gradients are about to be read)."""
-        self._flush_wgrads()
+    def _flush_queues(self):
+        """launch what backward has queued so far on the current stream: grouped weight gradients and the ordered sums of the
+        LayerNorm parameter-gradient partials"""
+        self._wq.flush()
         self._sq.flush()
-        if join:
-            self._join_wgrads()
 
     def drop(self, layer, site):
         p = self.head.dropout if self.training else 0.0
@@ -951,7 +932,7 @@ class Engine:
         head_start = max(t1, v1)                        # neck / decoder / projector closures: main stream
         def fire(i):
             if i in marks:
-                self._flush_queues(join=on_stage_done is not None)      # the stage's queued weight gradients
+                self._flush_queues()                         # the stage's queued weight gradients (current stream)
                 if on_stage_done is not None:
                     for st in marks[i]:
                         on_stage_done(st)
@@ -967,20 +948,19 @@ class Engine:
             with torch.cuda.stream(self.side):
                 for i in range(t1 - 1, t0 - 1, -1):
                     self.tape[i]()
-                self._flush_queues(join=True)
+                self._flush_queues()
                 if on_stage_done is not None:
                     on_stage_done(4)                     # issued from the side stream: the exchange waits for it only
         else:
             for i in range(t1 - 1, t0 - 1, -1):
                 self.tape[i]()
-            self._flush_queues(join=True)
+            self._flush_queues()
             if on_stage_done is not None:
                 on_stage_done(4)
         for i in range(v1 - 1, v0 - 1, -1):
             self.tape[i]()
             fire(i)                                      # visual stages 3, 2, 1, 0 as their layer groups finish
-        self._flush_queues(join=True)
-        self._wkeep = []              # (only now: a block freed earlier could be reused by the launch stream under the side stream)
+        self._flush_queues()
         if self.side is not None:
             ops.torch_op(lambda: main.wait_stream(self.side))
         self._zneed_last = max(self._zneed_last, self._zneed)

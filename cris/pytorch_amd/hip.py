@@ -234,7 +234,8 @@ _SIGS = {
     "cris_dynconv_bwd": (I, [P, P, I, I, I, I, P, I, P, P, P, P]),
     "cris_dynconv_bwd_ws_floats": (L, [I, I, I, I]),
     "cris_mask_resize_nearest": (I, [P, I, I, I, I, I, P, P]),
-    "cris_bce_fwd": (I, [P, P, L, P, P]),
+    "cris_bce_fwd": (I, [P, P, L, P, P, P]),
+    "cris_bce_ws_floats": (I, []),
     "cris_bce_bwd": (I, [P, P, L, P, P, P]),
     "cris_train_metric": (I, [P, P, I, I, F, F, P, P]),
     "cris_memset_f32": (I, [P, F, L, P]),

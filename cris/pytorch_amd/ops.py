@@ -634,8 +634,9 @@ def mask_resize_nearest(mask, OH, OW, out):
     hip.call("cris_mask_resize_nearest", ptr(mask), Bn, IH, IW, OH, OW, ptr(out), _stream())
 
 
-def bce_fwd(logits, target, loss_accum):
-    hip.call("cris_bce_fwd", ptr(logits), ptr(target), logits.numel(), ptr(loss_accum), _stream())
+def bce_fwd(logits, target, loss):
+    ws = torch.empty(hip.load().cris_bce_ws_floats(), dtype=torch.float32, device=logits.device)
+    hip.call("cris_bce_fwd", ptr(logits), ptr(target), logits.numel(), ptr(loss), ptr(ws), _stream())
 
 
 def bce_bwd(logits, target, gscale, dlogits):

@@ -126,6 +126,15 @@ class NativeTrainer:
             ops.step_advance(self.step_dev, self.seed_dev)
             e.seed_dev, seed = None, host_seed
         pred, msk, loss = e.forward(img, word, mask, training=True, seed=seed)
+        # the train metric (utils/misc.py:114-129) only needs the logits: it runs on the text-encoder stream underneath the
+        # backward pass (backward() joins that stream before it returns)
+        if e.side is not None:
+            cur = torch.cuda.current_stream()
+            ops.torch_op(lambda: e.side.wait_stream(cur))
+            with torch.cuda.stream(e.side):
+                ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
+        else:
+            ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         if self.comm.world > 1:
             def on_stage(st):
                 lo, hi = e.stage_ranges[st]
@@ -137,7 +146,6 @@ class NativeTrainer:
         # one Adam pass over every tensor; it also rewrites the bf16 operand copies of the GEMM weights from the new values
         self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
         e.packs_current = self.adam.refreshes_packs
-        ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         return loss, pred, msk
 
     def train_step(self, img, word, mask, seed: Optional[int] = None):

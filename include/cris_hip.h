@@ -342,9 +342,11 @@ int cris_dynconv_bwd(const cris_bf16* x, const float* dpred, int Bn, int H, int 
                      cris_bf16* dx, float* dwb, float* ws, void* stream);
 long cris_dynconv_bwd_ws_floats(int Bn, int H, int W, int ldwb);
 /* nearest mask resize + BCE-with-logits mean (model/segmenter.py:56-59) and gradient.
- * loss[0] = sum(loss_i)/n (one block, fixed summation order) ; grad = (sigmoid(x) - t)/n * (*gscale or 1) */
+ * loss[0] = sum(loss_i)/n (per-block partials in ws [cris_bce_ws_floats()], added in block order: no atomics) ;
+ * grad = (sigmoid(x) - t)/n * (*gscale or 1) */
 int cris_mask_resize_nearest(const float* mask, int Bn, int IH, int IW, int OH, int OW, float* out, void* stream);
-int cris_bce_fwd(const float* logits, const float* target, long n, float* loss, void* stream);
+int cris_bce_fwd(const float* logits, const float* target, long n, float* loss, float* ws, void* stream);
+int cris_bce_ws_floats(void);
 int cris_bce_bwd(const float* logits, const float* target, long n, const float* gscale, float* dlogits, void* stream);
 /* trainMetricGPU (utils/misc.py:114-129): out[0] = 100*mean IoU, out[1] = 100*mean(IoU > pr_iou) */
 int cris_train_metric(const float* logits, const float* target, int Bn, int HW, float thr, float pr_iou, float* out,
