@@ -488,13 +488,18 @@ static int pick_variant(const cris_conv_gemm_params& p) {
     if (lin && p.M <= 16) return V_SKINNY1;
     if (lin && p.M <= SKINNY_MAX_M) return V_SKINNY9;
     if (p.N <= 64) return V_128x64;
-    // too few 128x128 tiles to occupy the chip: halve the tile (2 blocks of 72 KB LDS fit a CU)
+    // too few 128x128 tiles to occupy the chip: halve the tile (2 blocks of 72 KB LDS fit a CU).  Mid-size problems
+    // (M <= 8192 rows: layers 3-4, neck, decoder) never take the 128x128 tile even when N is wide: measured on the decoder FFN
+    // (M 5408, N 2048, K 512) 37 us with 64-row tiles against 48 us.
     static const int t128_min = cris_env_int("CRIS_GEMM_T128_MIN", 448);
-    if ((long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128) < t128_min) {
+    if (p.M <= 8192 || (long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128) < t128_min) {
         // latency-bound mid-size problems: more, smaller blocks (3 per CU at 48 KB LDS) hide each other's pipeline fill,
-        // barriers and epilogues
+        // barriers and epilogues - except for long reductions (K >= 4096) over enough rows, where the 64x64 tile's LDS read
+        // traffic (two fragment loads per MFMA) is the limit and the 64x128 tile (1.5 per MFMA) wins (measured: M 5408, N 512,
+        // K 9216: 96 us against 119 us; K 4608: 54 against 57)
         static const int t64_max = cris_env_int("CRIS_GEMM_T64_MAX", 1024);
-        if ((long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128) < t64_max) return V_64x64;
+        const bool long_k = p.K >= 4096 && p.M >= 4096 && p.N >= 256;
+        if (!long_k && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128) < t64_max) return V_64x64;
         return V_64x128;
     }
     return V_128x128;

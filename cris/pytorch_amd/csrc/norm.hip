@@ -411,17 +411,22 @@ __device__ __forceinline__ void bn_bwd_point(const cris_bn_bwd_params& p, int m,
     for (int j = 0; j < 8; ++j) g[j] = pos[j] ? dz[j] * gscale : 0.f;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_params p, int rows_per_block) {
+// Geometry shared by the reduce and apply kernels: a block owns ONE chunk of `chv` 8-channel vectors (up to 64 channels) and a
+// range of rows; its 256 threads are chv vector lanes x 256/chv row lanes.  The reduce grid is chunks x row blocks with at most
+// 64 row blocks, so a channel's partial sums form a column of <= 64 entries that the apply kernel's blocks add up themselves
+// (in order: deterministic, no atomics, no separate summation launch).
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_params p, int rows_per_block, int chv, int chunks) {
     // Each thread owns one 8-channel vector and a strided subset of the block's rows (register accumulation); the RS row
-    // lanes of a vector are then combined through a plain LDS table + a column sum (no LDS atomics: RS lanes adding to the
-    // same word serialise - measured 23 % of this kernel's wave cycles), one global atomic per column per block.
+    // lanes of a vector are then combined through a plain LDS table + a column sum in lane order.
     __shared__ float spart[3][256 * 8];            // [sum][thread-major: rsub * cvn*8 + cv_local*8 + j]
     const int CV = p.C >> 3;
     const int M = p.Bn * p.H * p.W;
-    const int r0 = blockIdx.x * rows_per_block;
+    const int chunk = blockIdx.x % chunks, rb = blockIdx.x / chunks;
+    const int r0 = rb * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
-    for (int cvb = 0; cvb < CV; cvb += 256) {
-        const int cvn = min(256, CV - cvb);
+    {
+        const int cvb = chunk * chv;
+        const int cvn = min(chv, CV - cvb);
         const int RS = 256 / cvn;
         const int cvl = (int)threadIdx.x % cvn;
         const int cv = cvb + cvl;
@@ -441,7 +446,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_pa
                 }
             }
         }
-        __syncthreads();                           // previous chunk's table fully consumed
         if (rsub < RS) {
             const int base = (rsub * cvn + cvl) * 8;
 #pragma unroll
@@ -461,7 +465,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_pa
                 s3 += spart[2][r * ncol + c];
             }
             const int col = cvb * 8 + c;
-            float* part = p.part + (size_t)blockIdx.x * (p.y2 ? 4 : 2) * p.C;      // this block's row of the partials table
+            float* part = p.part + (size_t)rb * (p.y2 ? 4 : 2) * p.C;      // this row block's row of the partials table
             part[col] = s0;
             part[p.C + col] = s1;
             if (p.y2) {
@@ -479,17 +483,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_pa
 // (rows past the block's range re-read its last row with weight 0 - an unconditional load, not a branch).
 //   MASK 0: no ReLU; 1: ReLU mask from the stored forward output z; 2: ReLU mask recomputed from scale*y + shift.
 template <int MASK, bool Y2, bool POOL>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_bwd_params p, int rows_per_block) {
+__global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_bwd_params p, int rows_per_block, int chv, int chunks) {
     constexpr int U = Y2 ? 2 : 4;
     __shared__ float spart[3][256 * 8];
     const int CV = p.C >> 3;
     const int M = p.Bn * p.H * p.W;
-    const int r0 = blockIdx.x * rows_per_block;
+    const int chunk = blockIdx.x % chunks, rb = blockIdx.x / chunks;
+    const int r0 = rb * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     const int HW = p.H * p.W, W2 = p.W >> 1, HW2 = (p.H >> 1) * W2;
     const float gscale = POOL ? 0.25f : 1.f;
-    for (int cvb = 0; cvb < CV; cvb += 256) {
-        const int cvn = min(256, CV - cvb);
+    {
+        const int cvb = chunk * chv;
+        const int cvn = min(chv, CV - cvb);
         const int RS = 256 / cvn;
         const int cvl = (int)threadIdx.x % cvn;
         const int c0 = (cvb + cvl) * 8;
@@ -553,7 +559,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_b
                 }
             }
         }
-        __syncthreads();
         if (rsub < RS) {
             const int base = (rsub * cvn + cvl) * 8;
 #pragma unroll
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_b
                 if (Y2) s3 += spart[2][r * ncol + c];
             }
             const int col = cvb * 8 + c;
-            float* part = p.part + (size_t)blockIdx.x * (Y2 ? 4 : 2) * p.C;
+            float* part = p.part + (size_t)rb * (Y2 ? 4 : 2) * p.C;
             part[col] = s0;
             part[p.C + col] = s1;
             if (Y2) {
@@ -584,7 +589,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_b
     }
 }
 
-typedef void (*bn_bwd_reduce_fn)(const cris_bn_bwd_params, int);
+typedef void (*bn_bwd_reduce_fn)(const cris_bn_bwd_params, int, int, int);
 // [MASK][Y2][POOL]; combinations the path never produces stay on the generic kernel
 static bn_bwd_reduce_fn bn_bwd_reduce_fast_table(int mask, bool y2, bool pool) {
     if (pool) {
@@ -638,19 +643,28 @@ __global__ __launch_bounds__(256) void bn_dmul_kernel(const cris_bn_bwd_params p
     }
 }
 
-// row blocks of the reduction = rows of the partials table
-static int bn_bwd_geometry(int M, int* rows_per_block) {
-    // every block writes one partial row of 2C (4C) sums: few, fat blocks
+// chunk width (8-channel vectors per block, a power of two <= 8), number of chunks, rows per row block, row blocks (<= 64)
+struct bn_bwd_geom {
+    int chv, chunks, rpb, rbs;
+};
+static bn_bwd_geom bn_bwd_geometry(int M, int C) {
     static const int max_blocks = cris_env_int("CRIS_BN_RED_BLOCKS", 512);
     static const int min_rows = cris_env_int("CRIS_BN_RED_ROWS", 32);
-    int rpb = cris_cdiv(M, max_blocks);
-    if (rpb < min_rows) rpb = min_rows;
-    *rows_per_block = rpb;
-    return cris_cdiv(M, rpb);
+    bn_bwd_geom g;
+    const int CV = C >> 3;
+    g.chv = 1;
+    while (g.chv < 8 && g.chv * 2 <= CV / 4) g.chv *= 2;       // ~C/4 channels per chunk, at most 64
+    g.chunks = cris_cdiv(CV, g.chv);
+    int rbs = max_blocks / g.chunks;
+    if (rbs > 64) rbs = 64;
+    if (rbs < 1) rbs = 1;
+    g.rpb = cris_cdiv(M, rbs);
+    if (g.rpb < min_rows) g.rpb = min_rows;
+    g.rbs = cris_cdiv(M, g.rpb);
+    return g;
 }
 extern "C" long cris_bn_bwd_ws_floats(const cris_bn_bwd_params* p) {
-    int rpb;
-    return (long)bn_bwd_geometry(p->Bn * p->H * p->W, &rpb) * (p->y2 ? 4 : 2) * p->C;
+    return (long)bn_bwd_geometry(p->Bn * p->H * p->W, p->C).rbs * (p->y2 ? 4 : 2) * p->C;
 }
 
 extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
@@ -662,8 +676,7 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     CRIS_CHECK_ARG(!p.mul || !p.dmul || (p.relu && !p.pool && !p.y2 && p.scale && p.shift && (p.lddz & 7) == 0 && (p.dz_coff & 7) == 0),
                    "multiplier gradient: plain BN + ReLU");
     const int M = p.Bn * p.H * p.W;
-    int rpb;
-    const int blocks = bn_bwd_geometry(M, &rpb);
+    const bn_bwd_geom g = bn_bwd_geometry(M, p.C);
     static const int use_fast = cris_env_int("CRIS_BN_RED_FAST", 1);
     bn_bwd_reduce_fn fast = nullptr;
     if (use_fast && !p.mul && (p.ldy & 7) == 0 && (p.y_coff & 7) == 0 && (p.lddz & 7) == 0 && (p.dz_coff & 7) == 0 &&
@@ -671,12 +684,15 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
         const int mask = !p.relu ? 0 : (!p.pool && (p.y2 || p.z)) ? 1 : 2;
         if (mask != 1 || ((p.ldz & 7) == 0 && (p.z_coff & 7) == 0)) fast = bn_bwd_reduce_fast_table(mask, p.y2 != nullptr, p.pool != 0);
     }
-    hipLaunchKernelGGL(fast ? fast : bn_bwd_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, rpb);
+    hipLaunchKernelGGL(fast ? fast : bn_bwd_reduce_kernel, dim3(g.chunks * g.rbs), dim3(256), 0, (hipStream_t)stream, p, g.rpb, g.chv, g.chunks);
     CRIS_LAUNCH_CHECK();
-    // the blocks' partial rows, summed in block order (deterministic) into the [2C] ([4C]) sums (+=)
-    const int ncol = (p.y2 ? 4 : 2) * p.C;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, blocks, ncol, p.sums);
-    CRIS_LAUNCH_CHECK();
+    if (!p.sum_in_apply) {
+        // the row blocks' partial rows, summed in block order (deterministic) into the [2C] ([4C]) sums (+=); with sum_in_apply
+        // cris_bn_bwd_apply's blocks do this themselves for their channels
+        const int ncol = (p.y2 ? 4 : 2) * p.C;
+        hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, g.rbs, ncol, p.sums);
+        CRIS_LAUNCH_CHECK();
+    }
     if (p.mul && p.dmul) {
         hipLaunchKernelGGL(bn_dmul_kernel, dim3(p.Bn * cris_cdiv(p.C >> 3, 8)), dim3(256), 0, (hipStream_t)stream, p);
         CRIS_LAUNCH_CHECK();
@@ -684,26 +700,62 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     return 0;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_params p) {
+#define BN_APPLY_ROWS 4                            // rows per thread: a block covers 4 * (256 / chv) rows of its channel chunk
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_params p, int chv, int chunks, int rbs) {
+    __shared__ float s_tot[3][64];                 // totals of this block's channels: sum g | sum g*xhat | sum g*xhat2
     const int CV = p.C >> 3;
-    const long total = (long)p.Bn * p.H * p.W * CV;
+    const int M = p.Bn * p.H * p.W;
+    const int chunk = blockIdx.x % chunks, ra = blockIdx.x / chunks;
+    const int cvb = chunk * chv;
+    const int cvn = min(chv, CV - cvb);
+    const int RS = 256 / cvn;
+    const int cvl = (int)threadIdx.x % cvn, rsub = threadIdx.x / cvn;
+    const int ncolc = cvn * 8;
+    const int ncols = (p.y2 ? 4 : 2) * p.C;
+    // totals of the chunk's channels: the reduce kernel's partial rows added in row-block order (sum_in_apply), or the sums
+    // the caller completed (SyncBN: all-reduced between the two launches)
+    for (int idx = threadIdx.x; idx < 3 * ncolc; idx += 256) {
+        const int kind = idx / ncolc, c = idx - kind * ncolc;
+        if (kind == 2 && !p.y2) continue;
+        const int col = (kind == 0 ? 0 : kind == 1 ? p.C : 3 * p.C) + cvb * 8 + c;
+        float a;
+        if (p.sum_in_apply) {
+            a = 0.f;
+            for (int r = 0; r < rbs; ++r) a += p.part[(size_t)r * ncols + col];
+            if (ra == 0) {                         // one block per chunk publishes the totals ([dbeta | dgamma] of the arena)
+                p.sums[col] = a;
+                if (kind == 0 && p.y2) p.sums[2 * p.C + cvb * 8 + c] = a;
+            }
+        } else {
+            a = p.sums[col];
+        }
+        s_tot[kind][c] = a;
+    }
+    __syncthreads();
+    if (rsub >= RS) return;
     const float invc = 1.0f / p.count;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(idx % CV);
-        const int m = (int)(idx / CV);
-        const int c0 = cv * 8;
-        float g[8], xh[8], xh2[8];
+    const int c0 = (cvb + cvl) * 8;
+    float s0[8], s1[8], s3[8], sc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        s0[j] = s_tot[0][cvl * 8 + j];
+        s1[j] = s_tot[1][cvl * 8 + j];
+        s3[j] = p.y2 ? s_tot[2][cvl * 8 + j] : 0.f;
+    }
+    load8f(p.scale + c0, sc);
+    const int mbase = ra * (RS * BN_APPLY_ROWS) + rsub;
+#pragma unroll 1
+    for (int it = 0; it < BN_APPLY_ROWS; ++it) {
+        const int m = mbase + it * RS;
+        if (m >= M) break;
+        float g[8], xh[8], xh2[8], o[8];
         bn_bwd_point(p, m, c0, g, xh, xh2);
-        float s0[8], s1[8], sc[8], o[8];
-        load8f(p.sums + c0, s0);
-        load8f(p.sums + p.C + c0, s1);
-        load8f(p.scale + c0, sc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = sc[j] * (g[j] - s0[j] * invc - xh[j] * s1[j] * invc);
         *reinterpret_cast<uint4*>(p.dy + (size_t)m * p.lddy + p.dy_coff + c0) = pack8(o);
         if (p.y2 && p.dy2) {
-            float s3[8], sc2[8];
-            load8f(p.sums + 3 * p.C + c0, s3);
+            float sc2[8];
             load8f(p.scale2 + c0, sc2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = sc2[j] * (g[j] - s0[j] * invc - xh2[j] * s3[j] * invc);
@@ -726,8 +778,12 @@ extern "C" int cris_bn_bwd_apply(const cris_bn_bwd_params* pp, void* stream) {
     const cris_bn_bwd_params& p = *pp;
     CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums && p.scale && p.dy, "null operand");
     CRIS_CHECK_ARG((p.C & 7) == 0 && (p.lddy & 7) == 0 && (p.dy_coff & 7) == 0 && p.count > 0.f, "geometry");
-    const long total = (long)p.Bn * p.H * p.W * (p.C >> 3);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
+    CRIS_CHECK_ARG(!p.sum_in_apply || p.part, "sum_in_apply needs the reduce workspace");
+    const int M = p.Bn * p.H * p.W;
+    const bn_bwd_geom g = bn_bwd_geometry(M, p.C);
+    const int rows_per_block = (256 / g.chv) * BN_APPLY_ROWS;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks * cris_cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, p, g.chv,
+                       g.chunks, g.rbs);
     CRIS_LAUNCH_CHECK();
     return 0;
 }
@@ -971,7 +1027,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p)
 }
 
 static int ln_bwd_grid(int rows) {
-    static const int max_grid = cris_env_int("CRIS_LN_BWD_BLOCKS", 256);
+    static const int max_grid = cris_env_int("CRIS_LN_BWD_BLOCKS", 512);
     return cris_grid_1d(rows, 4, max_grid);
 }
 extern "C" int cris_ln_bwd_parts(int rows) { return ln_bwd_grid(rows); }
