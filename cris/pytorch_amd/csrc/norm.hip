@@ -413,8 +413,8 @@ __device__ __forceinline__ void bn_bwd_point(const cris_bn_bwd_params& p, int m,
 
 // Geometry shared by the reduce and apply kernels: a block owns ONE chunk of `chv` 8-channel vectors (up to 64 channels) and a
 // range of rows; its 256 threads are chv vector lanes x 256/chv row lanes.  The reduce grid is chunks x row blocks with at most
-// 64 row blocks, so a channel's partial sums form a column of <= 64 entries that the apply kernel's blocks add up themselves
-// (in order: deterministic, no atomics, no separate summation launch).
+// 64 row blocks, so a channel's partial sums form a column of <= 64 entries that one small launch adds up in order
+// (deterministic, no atomics).
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const cris_bn_bwd_params p, int rows_per_block, int chv, int chunks) {
     // Each thread owns one 8-channel vector and a strided subset of the block's rows (register accumulation); the RS row
     // lanes of a vector are then combined through a plain LDS table + a column sum in lane order.
@@ -686,13 +686,10 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     }
     hipLaunchKernelGGL(fast ? fast : bn_bwd_reduce_kernel, dim3(g.chunks * g.rbs), dim3(256), 0, (hipStream_t)stream, p, g.rpb, g.chv, g.chunks);
     CRIS_LAUNCH_CHECK();
-    if (!p.sum_in_apply) {
-        // the row blocks' partial rows, summed in block order (deterministic) into the [2C] ([4C]) sums (+=); with sum_in_apply
-        // cris_bn_bwd_apply's blocks do this themselves for their channels
-        const int ncol = (p.y2 ? 4 : 2) * p.C;
-        hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, g.rbs, ncol, p.sums);
-        CRIS_LAUNCH_CHECK();
-    }
+    // the row blocks' partial rows, summed in block order (deterministic) into the [2C] ([4C]) sums (+=)
+    const int ncol = (p.y2 ? 4 : 2) * p.C;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, g.rbs, ncol, p.sums);
+    CRIS_LAUNCH_CHECK();
     if (p.mul && p.dmul) {
         hipLaunchKernelGGL(bn_dmul_kernel, dim3(p.Bn * cris_cdiv(p.C >> 3, 8)), dim3(256), 0, (hipStream_t)stream, p);
         CRIS_LAUNCH_CHECK();
@@ -702,7 +699,7 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
 
 #define BN_APPLY_ROWS 4                            // rows per thread: a block covers 4 * (256 / chv) rows of its channel chunk
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_params p, int chv, int chunks, int rbs) {
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_params p, int chv, int chunks) {
     __shared__ float s_tot[3][64];                 // totals of this block's channels: sum g | sum g*xhat | sum g*xhat2
     const int CV = p.C >> 3;
     const int M = p.Bn * p.H * p.W;
@@ -712,25 +709,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_par
     const int RS = 256 / cvn;
     const int cvl = (int)threadIdx.x % cvn, rsub = threadIdx.x / cvn;
     const int ncolc = cvn * 8;
-    const int ncols = (p.y2 ? 4 : 2) * p.C;
-    // totals of the chunk's channels: the reduce kernel's partial rows added in row-block order (sum_in_apply), or the sums
-    // the caller completed (SyncBN: all-reduced between the two launches)
+    // totals of the chunk's channels (completed by cris_bn_bwd_reduce's summation launch; under SyncBN all-reduced in between).
+    // (Letting every block add up the <= 64 partial rows of its channels itself, to save that launch, was measured: 16.0
+    // against 15.2 ms per step - the prologue is paid by every one of the hundreds of blocks.)
     for (int idx = threadIdx.x; idx < 3 * ncolc; idx += 256) {
         const int kind = idx / ncolc, c = idx - kind * ncolc;
         if (kind == 2 && !p.y2) continue;
-        const int col = (kind == 0 ? 0 : kind == 1 ? p.C : 3 * p.C) + cvb * 8 + c;
-        float a;
-        if (p.sum_in_apply) {
-            a = 0.f;
-            for (int r = 0; r < rbs; ++r) a += p.part[(size_t)r * ncols + col];
-            if (ra == 0) {                         // one block per chunk publishes the totals ([dbeta | dgamma] of the arena)
-                p.sums[col] = a;
-                if (kind == 0 && p.y2) p.sums[2 * p.C + cvb * 8 + c] = a;
-            }
-        } else {
-            a = p.sums[col];
-        }
-        s_tot[kind][c] = a;
+        s_tot[kind][c] = p.sums[(kind == 0 ? 0 : kind == 1 ? p.C : 3 * p.C) + cvb * 8 + c];
     }
     __syncthreads();
     if (rsub >= RS) return;
@@ -778,12 +763,11 @@ extern "C" int cris_bn_bwd_apply(const cris_bn_bwd_params* pp, void* stream) {
     const cris_bn_bwd_params& p = *pp;
     CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums && p.scale && p.dy, "null operand");
     CRIS_CHECK_ARG((p.C & 7) == 0 && (p.lddy & 7) == 0 && (p.dy_coff & 7) == 0 && p.count > 0.f, "geometry");
-    CRIS_CHECK_ARG(!p.sum_in_apply || p.part, "sum_in_apply needs the reduce workspace");
     const int M = p.Bn * p.H * p.W;
     const bn_bwd_geom g = bn_bwd_geometry(M, p.C);
     const int rows_per_block = (256 / g.chv) * BN_APPLY_ROWS;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks * cris_cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, p, g.chv,
-                       g.chunks, g.rbs);
+                       g.chunks);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -78,7 +78,6 @@ class BnBwdParams(C.Structure):
                 ("mean2", P), ("invstd2", P), ("scale2", P),
                 ("mul", P),
                 ("sums", P), ("part", P),
-                ("sum_in_apply", I), ("pad_", I),
                 ("dmul", P),
                 ("dy", P), ("lddy", I), ("dy_coff", I),
                 ("dy2", P), ("lddy2", I), ("dy2_coff", I),

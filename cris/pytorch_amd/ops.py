@@ -317,8 +317,6 @@ class PackTable:
 
 
 # ---- BatchNorm ---------------------------------------------------------------------------------
-_BN_SUM_IN_APPLY = os.environ.get("CRIS_BN_SUM_IN_APPLY", "1") == "1"      # launch-structure knob (same results either way)
-
 
 def partials_rows(nparts: int) -> int:
     """rows a partials buffer needs (room for bn_finalize's first-level merge; cris_bn_partials_rows)"""
@@ -418,8 +416,6 @@ def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, 
     if not skip_reduce:
         part = torch.empty(hip.load().cris_bn_bwd_ws_floats(C.byref(p)), dtype=torch.float32, device=dz.device)
         p.part = ptr(part)
-        # without an exchange between the two launches the apply kernel's blocks add up the partial rows themselves
-        p.sum_in_apply = int(between is None and _BN_SUM_IN_APPLY)
         hip.call("cris_bn_bwd_reduce", C.byref(p), s)
     if between is not None:
         between(sums)

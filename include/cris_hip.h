@@ -184,9 +184,6 @@ typedef struct {
     float* sums;                                     /* [4*C]: sum g, sum g*xhat, (branch 2) sum g, sum g*xhat2 (+=) */
     float* part;                                     /* reduce workspace, cris_bn_bwd_ws_floats(p) floats: one partial row of
                                                         sums per row block (<= 64); summed in block order (no atomics) */
-    int sum_in_apply; int pad_;                      /* 1: cris_bn_bwd_apply's blocks add the partial rows themselves and store the
-                                                        totals into `sums` (no separate summation launch); 0: cris_bn_bwd_reduce
-                                                        adds them into `sums` (+=) - SyncBN all-reduces them before the apply */
     float* dmul;                                     /* [Bn][C] grad of mul or NULL */
     cris_bf16* dy;  int lddy, dy_coff;               /* grad wrt y */
     cris_bf16* dy2; int lddy2, dy2_coff;             /* grad wrt y2 or NULL */
