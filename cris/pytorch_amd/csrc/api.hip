@@ -31,6 +31,7 @@ extern "C" int cris_sizeof(const char* name) {
     S(cris_attn_params);
     S(cris_adam_desc);
     S(cris_p2p_params);
+    S(cris_zero_ranges);
 #undef S
     return -1;
 }
@@ -52,6 +53,28 @@ __global__ void zero_bytes_kernel(unsigned char* p, size_t nvec, size_t nbytes) 
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) v[i] = make_uint4(0, 0, 0, 0);
     const size_t tail0 = nvec * 16;
     if (blockIdx.x == 0 && tail0 + threadIdx.x < nbytes) p[tail0 + threadIdx.x] = 0;      // < 16 tail bytes
+}
+
+// several ranges in one launch (grid.y = range)
+__global__ void zero_ranges_kernel(const cris_zero_ranges r) {
+    const cris_zero_range z = r.r[blockIdx.y];
+    const size_t nvec = z.nbytes / 16;
+    uint4* v = reinterpret_cast<uint4*>(z.p);
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += stride) v[i] = make_uint4(0, 0, 0, 0);
+    const size_t tail0 = nvec * 16;
+    if (blockIdx.x == 0 && tail0 + threadIdx.x < z.nbytes) reinterpret_cast<unsigned char*>(z.p)[tail0 + threadIdx.x] = 0;
+}
+extern "C" int cris_zero_many(const cris_zero_ranges* r, void* stream) {
+    CRIS_CHECK_ARG(r && r->n > 0 && r->n <= CRIS_ZERO_RANGES_MAX, "1 .. CRIS_ZERO_RANGES_MAX ranges");
+    size_t big = 0;
+    for (int i = 0; i < r->n; ++i) {
+        CRIS_CHECK_ARG(r->r[i].p && ((uintptr_t)r->r[i].p & 15) == 0, "ranges must be 16-byte aligned");
+        if (r->r[i].nbytes > big) big = r->r[i].nbytes;
+    }
+    hipLaunchKernelGGL(zero_ranges_kernel, dim3(cris_grid_1d((long)(big / 16 + 1), 256, 2048), r->n), dim3(256), 0, (hipStream_t)stream, *r);
+    CRIS_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int cris_zero_bytes(void* p, size_t nbytes, void* stream) {

@@ -166,7 +166,15 @@ class Engine:
             if name.startswith("backbone."):
                 return 4
             return {"neck": 5, "decoder": 6, "proj": 7}[name.split(".")[0]]
-        names = sorted(self.P.keys(), key=lambda k: stage(k))          # stable: keeps module order inside a stage
+        # Inside a stage: first the gradients that are ACCUMULATED into or only partly written each step (BatchNorm sums,
+        # embedding tables: rows of absent tokens / positions must read 0) - they are zeroed at the start of a step, one
+        # contiguous range per stage - then the ones a kernel overwrites completely every step (GEMM weights and their
+        # biases: cris_conv_wgrad stores; LayerNorm: cris_sum_tables stores), which are never zeroed (~480 of 587 MB).
+        def needs_zero(name):
+            pfx = name.rsplit(".", 1)[0]
+            return pfx in bn_set or "embedding" in name or name == "backbone.logit_scale"
+        self.needs_zero = needs_zero
+        names = sorted(self.P.keys(), key=lambda k: (stage(k), 0 if needs_zero(k) else 1))   # stable: module order otherwise
         order, seen = [], set()
         for name in names:
             if name in seen:
@@ -197,13 +205,18 @@ class Engine:
         self.grad_order = order
         self.grad_offsets = offs
         self.bn_pairs = pairs
-        # arena [start, end) of each stage
-        self.stage_ranges = {}
+        # arena [start, end) of each stage, and of the part of it that is zeroed every step
+        self.stage_ranges, zr = {}, {}
         for name in order:
             st = stage(name)
             lo, hi = offs[name][0], offs[name][0] + (offs[name][1] + 3) // 4 * 4
             a, b = self.stage_ranges.get(st, (lo, hi))
             self.stage_ranges[st] = (min(a, lo), max(b, hi))
+            if needs_zero(name):
+                a, b = zr.get(st, (lo, hi))
+                zr[st] = (min(a, lo), max(b, hi))
+        self.zero_ranges = [self.grad_arena[a:b] for a, b in sorted(zr.values())]
+        self._zero_all = os.environ.get("CRIS_ZERO_ALL", "0") == "1"          # debugging aid: clear the whole arena
 
     def _add_pack(self, name, N, Cin, taps, Cpad=None, want_D=True, transposed=False):
         src = self.P[name]
@@ -855,7 +868,10 @@ class Engine:
         self._zero_slab_begin()
         if training:
             self.comm.begin_step()
-            ops.zero_(self.grad_arena)
+            if self._zero_all:
+                ops.zero_(self.grad_arena)
+            else:
+                ops.zero_ranges(self.zero_ranges)
         if not self.packs_current:
             self.repack_weights()
         # token ids index the embedding table and the key-padding mask as int64 (torch.nn.Embedding would raise on anything

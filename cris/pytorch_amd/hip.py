@@ -159,6 +159,17 @@ class AdamDesc(C.Structure):
                 ("transposed", I), ("pad2_", I)]
 
 
+ZERO_RANGES_MAX = 16
+
+
+class ZeroRange(C.Structure):
+    _fields_ = [("p", P), ("nbytes", C.c_size_t)]
+
+
+class ZeroRanges(C.Structure):
+    _fields_ = [("n", I), ("pad_", I), ("r", ZeroRange * ZERO_RANGES_MAX)]
+
+
 class P2PParams(C.Structure):
     _fields_ = [("data", P), ("boxes", P), ("gen_dev", P), ("err", P),
                 ("n", I), ("rank", I), ("world", I),
@@ -171,7 +182,7 @@ class P2PParams(C.Structure):
 STRUCTS = {
     "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_wgrad_group": WgradGroup, "cris_pack_desc": PackDesc,
     "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
-    "cris_ln_bwd_params": LnBwdParams, "cris_sum_entry": SumEntry, "cris_sum_group": SumGroup, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams,
+    "cris_ln_bwd_params": LnBwdParams, "cris_sum_entry": SumEntry, "cris_sum_group": SumGroup, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams, "cris_zero_ranges": ZeroRanges,
 }
 
 # name -> (restype, argtypes); struct launchers take (struct*, stream)
@@ -240,6 +251,7 @@ _SIGS = {
     "cris_train_metric": (I, [P, P, I, I, F, F, P, P]),
     "cris_memset_f32": (I, [P, F, L, P]),
     "cris_zero_bytes": (I, [P, C.c_size_t, P]),
+    "cris_zero_many": (I, [P, P]),
     "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, I, P]),
     "cris_adam_blocks": (I, [P]),
     "cris_adam_block_elems": (I, []),

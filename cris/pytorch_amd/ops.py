@@ -654,6 +654,17 @@ def zero_(t):
     return t
 
 
+def zero_ranges(tensors):
+    """zero several tensors (contiguous views) with one launch per CRIS_ZERO_RANGES_MAX of them"""
+    for i in range(0, len(tensors), hip.ZERO_RANGES_MAX):
+        chunk = tensors[i:i + hip.ZERO_RANGES_MAX]
+        zr = hip.ZeroRanges()
+        zr.n = len(chunk)
+        for j, t in enumerate(chunk):
+            zr.r[j].p, zr.r[j].nbytes = ptr(t), t.numel() * t.element_size()
+        hip.call("cris_zero_many", C.byref(zr), _stream())
+
+
 def torch_op(fn):
     """Run a torch-level op of the step now (stream wait, collective) and, while a step is being recorded, put it on the
     command list bound to the stream that is current now."""

@@ -355,6 +355,12 @@ int cris_train_metric(const float* logits, const float* target, int Bn, int HW, 
 int cris_memset_f32(float* p, float v, long n, void* stream);
 /* zero fill of any 16-byte aligned buffer */
 int cris_zero_bytes(void* p, size_t nbytes, void* stream);
+/* zero several byte ranges in one launch (the parts of the gradient arena that are accumulated into or only partly written:
+ * BatchNorm sums, embedding rows; everything a kernel overwrites completely every step is left alone) */
+#define CRIS_ZERO_RANGES_MAX 16
+typedef struct { void* p; size_t nbytes; } cris_zero_range;
+typedef struct { int n; int pad_; cris_zero_range r[CRIS_ZERO_RANGES_MAX]; } cris_zero_ranges;
+int cris_zero_many(const cris_zero_ranges* r, void* stream);
 
 /* fused multi-tensor Adam (torch.optim.Adam semantics, train.py:105-107): table of {p,g,m,v,n}.
  * p/m/v are in the parameter layout; g is in the parameter layout when taps == 0, else in the GEMM layout

@@ -1,16 +1,19 @@
-"""Generate loss-trajectory fixtures with the CPU oracle + torch.optim.Adam (this container; hours of CPU for R50).
+"""Generate loss-trajectory fixtures with the CPU oracle + torch.optim.Adam (this container; ~1.5 h of CPU for R50 at full size).
 
-    python tests/golden/make_trajectory.py r50 8 416 100 0.1 2e-6     -> tests/golden/traj_r50_b8_s416_d0.1_lr2e-06.json
+    python tests/golden/make_trajectory.py r50 8 416 100 0.1 1e-4        -> tests/golden/traj_r50_b8_s416_d0.1_lr0.0001.json
+    python tests/golden/make_trajectory.py r50 8 416 100 0.1 1e-4 emul   -> ..._bf16emul.json (bf16 storage rounding, informative)
 
 Protocol = the reference train loop on synthetic data (engine/engine.py:37-57, train.py:105-107): fresh seeded batch per
 step (synth.make_batch(rank 0, step t)), forward + BCE loss, backward, Adam(lr, betas .9/.999, eps 1e-8, wd 0) over
-every parameter that receives a gradient, BatchNorm running statistics updated.  lr: the reference's 1e-4 for the tiny
-model; for R50 with random (untrained) weights Adam's first +-1e-4 steps through the 2304-term pixel-text product move
-the logits by ~20 per step (the oracle's own loss goes 0.76 -> 11.0 after ONE step) - a transient no two
-implementations with different rounding can track - so the R50 fixture uses lr 2e-6, where the loss falls smoothly.  Dropout masks come from the shared
-counter hash (oracle/dropout_hash.py) with the trainer's seed rule (step*7919+17), so the HIP path can be compared step by
-step at the full BASELINE.json configs[1] shape WITHOUT running the CPU oracle on the GPU box.  The file is rewritten
-after every step (partial runs are usable)."""
+every parameter that receives a gradient, BatchNorm running statistics updated.  lr = the reference's 1e-4
+(config/refcoco/cris_r50.yaml) for every fixture.  With the untrained synthetic head the first ~30 steps are violent for any
+implementation (fp32 loss 0.90, 1.80, 1.46, 0.78, 1.11, 2.17, ...), then the curve settles.  (A much smaller lr is NOT a
+gentler test for a bf16 path: the CLIP weights sit on the fp16 grid, 1/8 of them exactly on a bf16 rounding tie, and a
++-2e-6 Adam step flips every one of those ties to the descent side - a coherent half-ulp move ~4x the step itself; measured
+with this oracle: loss after one step 0.729 in fp32 against 0.377 with bf16 weight rounding, 0.753 once the weights are
+dithered off the grid.)  Dropout masks come from the shared counter hash (oracle/dropout_hash.py) with the trainer's seed
+rule (step*7919+17), so the HIP path can be compared step by step at the full BASELINE.json configs[1] shape WITHOUT running
+the CPU oracle on the GPU box.  The file is rewritten after every step (partial runs are usable)."""
 import dataclasses
 import json
 import os

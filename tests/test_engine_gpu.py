@@ -96,9 +96,16 @@ def test_training_step_is_deterministic():
     clip, head = arch.specs_by_name("tiny")
     dev = torch.device("cuda:0")
     outs = []
-    for rep in range(3):
+    for rep in range(4):
         sd = arch.synthetic_state_dict(clip, head, 0)
-        tr = NativeTrainer(clip, head, sd, dev)
+        # the last run clears the WHOLE gradient arena every step instead of only the accumulated ranges: identical results
+        # prove that every other gradient really is overwritten completely by its kernel (engine._build_grad_arena)
+        os.environ["CRIS_ZERO_ALL"] = "1" if rep == 3 else "0"
+        try:
+            tr = NativeTrainer(clip, head, sd, dev)
+        finally:
+            os.environ.pop("CRIS_ZERO_ALL", None)
+        assert tr.engine._zero_all == (rep == 3)
         losses = []
         for t in range(4):
             img, word, mask = synth.make_batch(4, 64, head.word_len, 0, t)
