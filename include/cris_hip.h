@@ -30,7 +30,7 @@ int cris_sizeof(const char* struct_name);
 long cris_echo_conv_gemm(const void* conv_gemm_params);
 
 /* ------------------------------------------------------------------------------------------------
- * Implicit-GEMM convolution / linear, bf16 MFMA (v_mfma_f32_16x16x32_bf16), fp32 accumulate.
+ * Implicit-GEMM convolution / linear, bf16 MFMA (v_mfma_f32_32x32x16_bf16; 16x16x32 in the M <= 144 kernel), fp32 accumulate.
  *   out[m, n] = epilogue( sum_k A_im2col[m, k] * Wt[n, k] )
  *   m = (b, oh, ow) over an NHWC input [Bn, H, W, lda] (channels a_coff .. a_coff+C),  k = tap*C + c.
  * Replaces: nn.Conv2d forward everywhere (reference model/clip.py:17-42,77,165-182; model/layers.py:10,58),
