@@ -8,7 +8,7 @@
 // BN coefficients
 // ------------------------------------------------------------------------------------------------
 #define BN_MERGE_SLICES 64      // first-level merge width for long partial lists (see cris_bn_partials_rows)
-#define BN_MERGE_MIN 1024       // lists up to this long go straight to the (64-lane) final merge
+#define BN_MERGE_MIN 512        // lists up to this long go straight to the (16-lane) final merge
 
 // Chan et al. pairwise update of (n, mean, M2) with a block (nb rows, sum sb, M2 mb)
 __device__ __forceinline__ void chan_add(float& n, float& mean, float& m2, float nb, float sb, float mb) {
@@ -48,24 +48,20 @@ __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__
     }
 }
 
-// final merge + coefficients: block = 4 channels x 64 part lanes (the kernel is pure latency - a handful of blocks on an idle
-// chip - so the part list is spread over many lanes: ceil(nparts / 64) dependent merges per lane), then the lanes are merged in
-// lane order (deterministic)
-#define BNF_CH 4
-#define BNF_PL 64
+// final merge + coefficients: block = 16 channels x 16 part lanes (coalesced 64-B rows), LDS tree over the part lanes
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
                                    float count, const float* gamma, const float* beta, float* rmean, float* rvar,
                                    float momentum, float eps, int C, float* scale, float* shift, float* mean_o,
                                    float* invstd_o, float* merged /* optional [2*C]: local (sum, M2) for SyncBN */,
                                    const float* global_stats /* optional [2*C]: (sum, M2 about the global mean) */) {
-    __shared__ float sh[3][BNF_PL][BNF_CH + 1];
-    const int cl = threadIdx.x & (BNF_CH - 1), pl = threadIdx.x / BNF_CH;
-    const int c = blockIdx.x * BNF_CH + cl;
+    __shared__ float sh[3][16][17];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (!global_stats) {
         if (c < C) {
             const int M = (int)count_local;
-            for (int i = pl; i < nparts; i += BNF_PL) {
+            for (int i = pl; i < nparts; i += 16) {
                 const int rows = min(rows_per_part, M - i * rows_per_part);
                 if (rows > 0) chan_add(n, mean, m2, (float)rows, psum[(size_t)i * C + c], pm2[(size_t)i * C + c]);
             }
@@ -73,7 +69,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, con
         sh[0][pl][cl] = n; sh[1][pl][cl] = mean; sh[2][pl][cl] = m2;
         __syncthreads();
         if (pl != 0 || c >= C) return;
-        for (int j = 1; j < BNF_PL; ++j) chan_add(n, mean, m2, sh[0][j][cl], sh[1][j][cl] * sh[0][j][cl], sh[2][j][cl]);
+#pragma unroll
+        for (int j = 1; j < 16; ++j) chan_add(n, mean, m2, sh[0][j][cl], sh[1][j][cl] * sh[0][j][cl], sh[2][j][cl]);
         if (merged) {                       // hand the local (sum, M2) to the SyncBN exchange; finalize runs again after it
             merged[c] = mean * n;
             merged[C + c] = m2;
@@ -147,7 +144,7 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
         nparts = slices;
         rows_per_part *= pps;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, BNF_CH)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
                        count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
                        merged, global_stats);
     CRIS_LAUNCH_CHECK();
@@ -697,50 +694,28 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     return 0;
 }
 
-#define BN_APPLY_ROWS 4                            // rows per thread: a block covers 4 * (256 / chv) rows of its channel chunk
-
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_params p, int chv, int chunks) {
-    __shared__ float s_tot[3][64];                 // totals of this block's channels: sum g | sum g*xhat | sum g*xhat2
+// (a channel-chunked apply geometry, and letting its blocks add up the reduce kernel's partial rows themselves to save the
+// summation launch, were both measured slower: 13.0 against 11.3 us per launch, 16.0 against 15.2 ms per step)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_params p) {
     const int CV = p.C >> 3;
-    const int M = p.Bn * p.H * p.W;
-    const int chunk = blockIdx.x % chunks, ra = blockIdx.x / chunks;
-    const int cvb = chunk * chv;
-    const int cvn = min(chv, CV - cvb);
-    const int RS = 256 / cvn;
-    const int cvl = (int)threadIdx.x % cvn, rsub = threadIdx.x / cvn;
-    const int ncolc = cvn * 8;
-    // totals of the chunk's channels (completed by cris_bn_bwd_reduce's summation launch; under SyncBN all-reduced in between).
-    // (Letting every block add up the <= 64 partial rows of its channels itself, to save that launch, was measured: 16.0
-    // against 15.2 ms per step - the prologue is paid by every one of the hundreds of blocks.)
-    for (int idx = threadIdx.x; idx < 3 * ncolc; idx += 256) {
-        const int kind = idx / ncolc, c = idx - kind * ncolc;
-        if (kind == 2 && !p.y2) continue;
-        s_tot[kind][c] = p.sums[(kind == 0 ? 0 : kind == 1 ? p.C : 3 * p.C) + cvb * 8 + c];
-    }
-    __syncthreads();
-    if (rsub >= RS) return;
+    const long total = (long)p.Bn * p.H * p.W * CV;
     const float invc = 1.0f / p.count;
-    const int c0 = (cvb + cvl) * 8;
-    float s0[8], s1[8], s3[8], sc[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        s0[j] = s_tot[0][cvl * 8 + j];
-        s1[j] = s_tot[1][cvl * 8 + j];
-        s3[j] = p.y2 ? s_tot[2][cvl * 8 + j] : 0.f;
-    }
-    load8f(p.scale + c0, sc);
-    const int mbase = ra * (RS * BN_APPLY_ROWS) + rsub;
-#pragma unroll 1
-    for (int it = 0; it < BN_APPLY_ROWS; ++it) {
-        const int m = mbase + it * RS;
-        if (m >= M) break;
-        float g[8], xh[8], xh2[8], o[8];
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(idx % CV);
+        const int m = (int)(idx / CV);
+        const int c0 = cv * 8;
+        float g[8], xh[8], xh2[8];
         bn_bwd_point(p, m, c0, g, xh, xh2);
+        float s0[8], s1[8], sc[8], o[8];
+        load8f(p.sums + c0, s0);
+        load8f(p.sums + p.C + c0, s1);
+        load8f(p.scale + c0, sc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = sc[j] * (g[j] - s0[j] * invc - xh[j] * s1[j] * invc);
         *reinterpret_cast<uint4*>(p.dy + (size_t)m * p.lddy + p.dy_coff + c0) = pack8(o);
         if (p.y2 && p.dy2) {
-            float sc2[8];
+            float s3[8], sc2[8];
+            load8f(p.sums + 3 * p.C + c0, s3);
             load8f(p.scale2 + c0, sc2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = sc2[j] * (g[j] - s0[j] * invc - xh2[j] * s3[j] * invc);
@@ -763,11 +738,8 @@ extern "C" int cris_bn_bwd_apply(const cris_bn_bwd_params* pp, void* stream) {
     const cris_bn_bwd_params& p = *pp;
     CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums && p.scale && p.dy, "null operand");
     CRIS_CHECK_ARG((p.C & 7) == 0 && (p.lddy & 7) == 0 && (p.dy_coff & 7) == 0 && p.count > 0.f, "geometry");
-    const int M = p.Bn * p.H * p.W;
-    const bn_bwd_geom g = bn_bwd_geometry(M, p.C);
-    const int rows_per_block = (256 / g.chv) * BN_APPLY_ROWS;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(g.chunks * cris_cdiv(M, rows_per_block)), dim3(256), 0, (hipStream_t)stream, p, g.chv,
-                       g.chunks);
+    const long total = (long)p.Bn * p.H * p.W * (p.C >> 3);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(cris_grid_1d(total, 256)), dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

