@@ -165,9 +165,9 @@ __global__ void attn_bwd_dkv_lds_kernel(const cris_attn_params p);
 #define AL_LDS_FWD (3 * 2 * 8192)
 #define AL_LDS_DQ (2 * 3 * 8192)
 #define AL_LDS_DKV (2 * (4 * 8192 + 512))
-static bool attn_use_lds(const cris_attn_params& p, int loop_rows) {
+static bool attn_use_lds(const cris_attn_params& p, int loop_rows, bool key_mask_ok = false) {
     static const int lds_min = cris_env_int("CRIS_ATTN_LDS_MIN", 384);
-    return !p.causal && !p.key_tokens && loop_rows >= lds_min && (p.Lk_pad & 7) == 0 && ((uintptr_t)p.Q & 15) == 0 &&
+    return !p.causal && (key_mask_ok || !p.key_tokens) && loop_rows >= lds_min && (p.Lk_pad & 7) == 0 && ((uintptr_t)p.Q & 15) == 0 &&
            ((uintptr_t)p.K & 15) == 0 && ((uintptr_t)p.V & 15) == 0 && (size_t)p.B * p.Lk * p.ldk * 2 < (1UL << 31) &&
            (size_t)p.B * p.Lq * p.ldq * 2 < (1UL << 31) && (size_t)p.B * p.Hn * 64 * (p.Lk_pad > p.Lq_pad ? p.Lk_pad : p.Lq_pad) * 2 < (1UL << 31);
 }
@@ -415,7 +415,8 @@ extern "C" int cris_attn_bwd_dkv(const cris_attn_params* pp, void* stream) {
     CRIS_CHECK_ARG((p.ldv & 7) == 0 && (p.lddo & 7) == 0 && (p.lddk & 3) == 0 && (p.lddv & 3) == 0, "ld");
     CRIS_CHECK_ARG((p.Lq_pad & 3) == 0 && p.Lq_pad >= ((p.Lq + 31) / 32) * 32, "Lq_pad must cover whole 32-query tiles");
     dim3 grid(cris_cdiv(p.Lk, 64), p.B * p.Hn);
-    if (attn_use_lds(p, p.Lq) && (p.Lq_pad & 7) == 0) return attn_launch_lds(2, p, grid, stream);
+    // (the key side also serves the decoder's cross attention: 17 / 22 keys with a padding mask, but a 676 / 900-query loop)
+    if (attn_use_lds(p, p.Lq, true) && (p.Lq_pad & 7) == 0) return attn_launch_lds(2, p, grid, stream);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return 0;
@@ -431,7 +432,7 @@ extern "C" int cris_attn_bwd_dkv(const cris_attn_params* pp, void* stream) {
 // = zeros) through a ring with counted vmcnt + one raw barrier per 64-row step, and every wave works on TWO 16-row groups
 // (32 queries / keys) so that each fragment read from LDS feeds two MFMA chains.  The arithmetic (S^T formulation, slot
 // permutation of the PV product, online softmax, dropout hash, masks of rows beyond the sequence) is exactly that of the
-// kernels above; no causal / key-padding mask (self-attention only).  One difference in bookkeeping: the rows of the two
+// kernels above; no causal mask, key-padding mask on the key-side backward only (the cross attention's 676-query loop).  One difference in bookkeeping: the rows of the two
 // 16-row MFMA blocks of a 32-row half step are interleaved (block kb takes rows (m>>2)*8 + kb*4 + (m&3)), so that the 8
 // reduction slots a lane owns in the second product are 8 CONSECUTIVE rows fg*8 .. fg*8+7 and every LDS fragment read is one
 // 16-byte ds_read_b128 (hipcc puts an s_waitcnt vmcnt(0) - a full drain of the DMA ring - in front of merged 8-byte LDS
@@ -765,13 +766,14 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
     const int k0w = blockIdx.x * (32 * AL_WAVES) + wave * 32;
 
     int key[2];
-    bool kok[2];
+    bool kok[2], kpad[2];
     bf16x8 bk[2][2], bv[2][2];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
         key[g] = k0w + g * 16 + fr;
         kok[g] = key[g] < p.Lk;
         const int keyc = min(key[g], p.Lk - 1);                // keys beyond Lk read the last key; nothing is stored for them
+        kpad[g] = p.key_tokens != nullptr && p.key_tokens[(size_t)b * p.Lk + keyc] == 0;      // padded key: attends nothing
         const bf16_t* Kp = p.K + (size_t)(b * p.Lk + keyc) * p.ldk + h * 64 + fg * 8;
         const bf16_t* Vp = p.V + (size_t)(b * p.Lk + keyc) * p.ldv + h * 64 + fg * 8;
         bk[g][0] = ld_frag16(Kp);
@@ -869,7 +871,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int qq = q0 + fg * 8 + qb * 4 + r;      // C/D row of this lane = query (interleaved blocks)
-                        const bool ok = qq < p.Lq && kok[g];
+                        const bool ok = qq < p.Lq && kok[g] && !kpad[g];
                         const float pr = ok ? __expf(sv[r] * p.scale - lq[qb * 4 + r]) : 0.f;
                         const float dlt = ok ? dl[qb * 4 + r] : 0.f;
                         float dpv = dp[r];

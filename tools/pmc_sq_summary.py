@@ -39,11 +39,19 @@ for k, x in d.items():
         x["effective_clock_ghz"] = per_xcd / dur
         x["gui_active_summed_over_xcds"] = bool(1.2 <= clk8 <= 2.6)
         x["mfma_util_vs_chip"] = g(x, "SQ_VALU_MFMA_BUSY_CYCLES") / (SIMDS * per_xcd)
+    if dur:
+        # the same ratio against wall time at the 2.4 GHz peak clock: usable for SHORT kernels too (GRBM_GUI_ACTIVE of a
+        # 10-20 us dispatch is dominated by the counter-collection window: "clocks" of 20-40 GHz come out)
+        x["mfma_util_vs_chip_at_2p4ghz"] = g(x, "SQ_VALU_MFMA_BUSY_CYCLES") / (SIMDS * dur * 2.4)
 json.dump(d, open(sys.argv[2], "w"), indent=1)
-print("%-40s %6s %10s %6s %9s %7s %9s %8s %9s" % ("kernel", "n", "wavecyc(M)", "wait%", "waitInst%", "act%", "ldsStall%", "clk GHz", "MFMA/chip%"))
+tot_mf = sum(g(x, "SQ_VALU_MFMA_BUSY_CYCLES") for x in d.values())
+tot_dur = sum(g(x, "duration_ns") for x in d.values())
+if tot_dur:
+    print("all kernels: MFMA busy / (1024 SIMDs x summed kernel time x 2.4 GHz) = %.1f %%" % (100 * tot_mf / (SIMDS * tot_dur * 2.4)))
+print("%-40s %6s %10s %6s %9s %7s %9s %8s %9s %9s" % ("kernel", "n", "wavecyc(M)", "wait%", "waitInst%", "act%", "ldsStall%", "clk GHz", "MFMA/chip%", "@2.4GHz%"))
 for k, x in sorted(d.items(), key=lambda kv: -g(kv[1], "SQ_WAVE_CYCLES"))[:18]:
     wc = g(x, "SQ_WAVE_CYCLES") or 1
-    print("%-40s %6d %10.1f %6.1f %9.1f %7.1f %9.1f %8.2f %9.1f" % (
+    print("%-40s %6d %10.1f %6.1f %9.1f %7.1f %9.1f %8.2f %9.1f %9.1f" % (
         k[:40], x["launches"], wc / 1e6, 100 * g(x, "SQ_WAIT_ANY") / wc, 100 * g(x, "SQ_WAIT_INST_ANY") / wc,
         100 * g(x, "SQ_ACTIVE_INST_ANY") / wc, 100 * g(x, "SQ_WAIT_INST_LDS") / wc, x.get("effective_clock_ghz", 0.0),
-        100 * x.get("mfma_util_vs_chip", 0.0)))
+        100 * x.get("mfma_util_vs_chip", 0.0), 100 * x.get("mfma_util_vs_chip_at_2p4ghz", 0.0)))
