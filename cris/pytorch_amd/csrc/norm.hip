@@ -60,10 +60,23 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, con
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (!global_stats) {
         if (c < C) {
+            // the loads of four list entries are issued together, ahead of the (dependent) merge arithmetic: the kernel is a
+            // handful of blocks on an otherwise idle chip, i.e. pure memory latency
             const int M = (int)count_local;
-            for (int i = pl; i < nparts; i += 16) {
-                const int rows = min(rows_per_part, M - i * rows_per_part);
-                if (rows > 0) chan_add(n, mean, m2, (float)rows, psum[(size_t)i * C + c], pm2[(size_t)i * C + c]);
+            for (int i0 = pl; i0 < nparts; i0 += 64) {
+                float ps[4], pq[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = min(i0 + 16 * u, nparts - 1);
+                    ps[u] = psum[(size_t)i * C + c];
+                    pq[u] = pm2[(size_t)i * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + 16 * u;
+                    const int rows = i < nparts ? min(rows_per_part, M - i * rows_per_part) : 0;
+                    if (rows > 0) chan_add(n, mean, m2, (float)rows, ps[u], pq[u]);
+                }
             }
         }
         sh[0][pl][cl] = n; sh[1][pl][cl] = mean; sh[2][pl][cl] = m2;
