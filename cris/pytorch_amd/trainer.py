@@ -224,6 +224,72 @@ class NativeTrainer:
         self._cmds, self._loss, self._keep = rec, loss, (pred, msk)
         return loss
 
+    # ------------------------------------------------------------------------------------------------
+    # checkpointing (reference train.py:159-174,192-207: {'epoch', 'cur_iou', 'best_iou', 'state_dict', 'optimizer', 'scheduler'})
+    # ------------------------------------------------------------------------------------------------
+    def _param_order(self):
+        """parameter names in the order torch.optim.Adam(param_list) numbers them for `build_segmenter`'s two groups
+        (model/__init__.py:36-48): group 0 = backbone without the positional embeddings, group 1 = the rest - module order
+        inside each group.  `backbone.logit_scale` is a parameter of the reference module too (it just never gets a gradient)."""
+        names = list(self.engine.P.keys())                    # state_dict (= named_parameters) order
+        g0 = [n for n in names if n.startswith("backbone") and "positional_embedding" not in n]
+        g1 = [n for n in names if n not in set(g0)]
+        return g0, g1
+
+    def model_state_dict(self):
+        """the reference module's `state_dict()` (parameters + BatchNorm buffers; clones, on the CPU)"""
+        e = self.engine
+        out = {k: v.detach().cpu().clone() for k, v in e.P.items()}
+        out.update({k: v.detach().cpu().clone() for k, v in e.Bf.items()})
+        steps = self.step_idx
+        for pfx in e.bn_prefixes:
+            out[pfx + ".num_batches_tracked"] = torch.tensor(steps, dtype=torch.int64)
+        return out
+
+    def load_model_state_dict(self, sd):
+        """parameters and BatchNorm buffers from a reference-keyed state_dict; the bf16 operand copies are re-packed on the
+        next forward"""
+        e = self.engine
+        for k, t in list(e.P.items()) + list(e.Bf.items()):
+            t.copy_(sd[k].to(self.device))
+        e.packs_current = False
+
+    def optimizer_state_dict(self):
+        """Adam state in torch.optim.Adam.state_dict() form, loadable by the optimizer `train.py:105-107` builds from
+        `build_segmenter`'s param_list (and by load_optimizer_state_dict)."""
+        g0, g1 = self._param_order()
+        idx = {n: i for i, n in enumerate(self.names)}
+        lr_of = dict(zip(self.names, self.adam.lrs))
+        state, step = {}, self.step_idx
+        for i, n in enumerate(g0 + g1):
+            if n in idx and step > 0:
+                j = idx[n]
+                state[i] = {"step": torch.tensor(float(step)), "exp_avg": self.adam.m[j].detach().cpu().clone(),
+                            "exp_avg_sq": self.adam.v[j].detach().cpu().clone()}
+        def group(names, initial_lr, first):
+            lr = next((lr_of[n] for n in names if n in lr_of), self.base_lr)
+            return {"lr": lr, "initial_lr": initial_lr, "betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": self.weight_decay,
+                    "amsgrad": False, "params": list(range(first, first + len(names)))}
+        return {"state": state, "param_groups": [group(g0, self.lr_multi * self.base_lr, 0), group(g1, self.base_lr, len(g0))]}
+
+    def load_optimizer_state_dict(self, sd):
+        """restore m / v / step count (and the group learning rates) from optimizer_state_dict() or from the state_dict of a
+        torch.optim.Adam over the same param_list"""
+        g0, g1 = self._param_order()
+        idx = {n: i for i, n in enumerate(self.names)}
+        step = 0
+        for i, n in enumerate(g0 + g1):
+            st = sd["state"].get(i)
+            if st is None or n not in idx:
+                continue
+            j = idx[n]
+            self.adam.m[j].copy_(st["exp_avg"].to(self.device))
+            self.adam.v[j].copy_(st["exp_avg_sq"].to(self.device))
+            step = max(step, int(float(st["step"])))
+        self.step_dev.fill_(step)
+        self.adam.step_count = step
+        self.set_group_lrs(sd["param_groups"][0]["lr"], sd["param_groups"][1]["lr"])
+
     @torch.no_grad()
     def eval_forward(self, img, word):
         return self.engine.forward(img, word, None, training=False)

@@ -89,3 +89,33 @@ def test_launch_modes_agree():
     for mode in ("graph", "cmdlist"):
         d = max(abs(a - b) for a, b in zip(curves[mode], curves["eager"]))
         assert d < 1e-2, (mode, curves)             # observed <= 1.5e-3
+
+
+def test_native_trainer_checkpoint_resume_is_exact_and_torch_compatible():
+    """train.py:159-174,192-207 (--resume): model + optimizer state out of the native trainer, into a fresh one - the
+    continued run is bit-identical to the uninterrupted one (the path is deterministic) - and the optimizer part loads into
+    the torch.optim.Adam the reference builds from build_segmenter's param_list."""
+    dev = torch.device("cuda:0")
+    clip, head = arch.specs_by_name("tiny")
+    sd = arch.synthetic_state_dict(clip, head, 0)
+    a = NativeTrainer(clip, head, sd, dev, base_lr=1e-4, launch="eager")
+    for step in range(3):
+        a.train_step(*_batch(step, dev))
+    msd, osd = a.model_state_dict(), a.optimizer_state_dict()
+    cont = [float(a.train_step(*_batch(step, dev))[0]) for step in (3, 4)]
+    b = NativeTrainer(clip, head, msd, dev, base_lr=1e-4, launch="eager")
+    b.load_optimizer_state_dict(osd)
+    resumed = [float(b.train_step(*_batch(step, dev))[0]) for step in (3, 4)]
+    assert resumed == cont, (resumed, cont)
+    assert all(torch.equal(a.engine.P[k], b.engine.P[k]) for k in a.engine.P)
+    # torch-format compatibility with the reference's optimizer construction (train.py:105-107)
+    model, groups = build_segmenter(NS(**TINY))
+    opt = torch.optim.Adam(groups, lr=1e-4, weight_decay=0.0)
+    opt.load_state_dict(osd)
+    n_params = sum(len(g["params"]) for g in opt.state_dict()["param_groups"])
+    assert n_params == len(list(model.parameters()))
+    names = [n for n, _ in model.named_parameters()]
+    i = osd["param_groups"][1]["params"][0]                   # first parameter of the head group
+    first_head = [n for n in names if not (n.startswith("backbone") and "positional_embedding" not in n)][0]
+    assert tuple(osd["state"][i]["exp_avg"].shape) == tuple(dict(model.named_parameters())[first_head].shape)
+    assert int(msd["backbone.visual.bn1.num_batches_tracked"]) == 3
