@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "wgrad.hip", "norm.hip", "attention.hip", "elementwise.hip", "p2p.hip"]
+SOURCES = ["api.hip", "gemm.hip", "wgrad.hip", "norm.hip", "attention.hip", "elementwise.hip", "evalpost.hip", "p2p.hip"]
 LIB = os.path.join(HERE, "libcris_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]

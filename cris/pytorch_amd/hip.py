@@ -249,6 +249,9 @@ _SIGS = {
     "cris_bce_ws_floats": (I, []),
     "cris_bce_bwd": (I, [P, P, L, P, P, P]),
     "cris_train_metric": (I, [P, P, I, I, F, F, P, P]),
+    "cris_sigmoid_bicubic_up": (I, [P, I, I, I, I, I, P, P]),
+    "cris_warp_affine_cubic": (I, [P, I, I, P, I, I, F, P, P]),
+    "cris_threshold_iou": (I, [P, P, L, F, P, P]),
     "cris_memset_f32": (I, [P, F, L, P]),
     "cris_zero_bytes": (I, [P, C.c_size_t, P]),
     "cris_zero_many": (I, [P, P]),

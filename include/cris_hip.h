@@ -351,6 +351,15 @@ int cris_bce_bwd(const float* logits, const float* target, long n, const float* 
 /* trainMetricGPU (utils/misc.py:114-129): out[0] = 100*mean IoU, out[1] = 100*mean(IoU > pr_iou) */
 int cris_train_metric(const float* logits, const float* target, int Bn, int HW, float thr, float pr_iou, float* out,
                       void* stream);
+/* ---- evaluation post-processing (reference engine/engine.py:100-123 validate, :171-188 inference; csrc/evalpost.hip) ----
+ * out[b] = F.interpolate(sigmoid(logits[b]), (H, W), mode='bicubic', align_corners=True)   (engine.py:101-106) */
+int cris_sigmoid_bicubic_up(const float* logits, int Bn, int h, int w, int H, int W, float* out, void* stream);
+/* dst = cv2.warpAffine(src, mat, (w_out, h_out), flags=cv2.INTER_CUBIC, borderValue=border) (engine.py:114-116); mat: HOST
+ * pointer to the 2x3 double matrix the reference passes (param['inverse']); OpenCV's fixed-point algorithm restated */
+int cris_warp_affine_cubic(const float* src, int H, int W, const double* mat, int w_out, int h_out, float border, float* dst,
+                           void* stream);
+/* counts[0] += #(pred > thr & mask), counts[1] += #(pred > thr | mask)  (engine.py:117-122); counts: 2 device ints */
+int cris_threshold_iou(const float* pred, const float* mask, long n, float thr, int* counts, void* stream);
 /* elementwise multiply by per-(batch,channel) scalar handled inside cris_bn_apply (mul) */
 int cris_memset_f32(float* p, float v, long n, void* stream);
 /* zero fill of any 16-byte aligned buffer */
