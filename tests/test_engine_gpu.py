@@ -149,6 +149,7 @@ def test_eval_forward_matches_oracle():
         ref = O.cris_forward(sd, clip, head, img, word, training=False)
     assert pred.shape == ref.shape
     err = float((pred.cpu() - ref).norm() / ref.norm())
+    print("eval forward rel-L2 vs oracle: %.3e" % err)
     assert err < 3e-2, err
 
 

@@ -119,3 +119,24 @@ def test_native_trainer_checkpoint_resume_is_exact_and_torch_compatible():
     first_head = [n for n in names if not (n.startswith("backbone") and "positional_embedding" not in n)][0]
     assert tuple(osd["state"][i]["exp_avg"].shape) == tuple(dict(model.named_parameters())[first_head].shape)
     assert int(msd["backbone.visual.bn1.num_batches_tracked"]) == 3
+
+
+def test_module_under_dataparallel_like_test_py():
+    """test.py:70-72: `model = torch.nn.DataParallel(model).cuda()` then eval forward.  On one visible GPU DataParallel calls
+    the wrapped module directly (no replicate): outputs equal the bare module's; the `module.` key prefix test.py:74-78 strips
+    / expects round-trips."""
+    dev = torch.device("cuda:0")
+    model, _ = build_segmenter(NS(**TINY))
+    wrapped = torch.nn.DataParallel(model, device_ids=[0]).cuda()
+    img, word, _ = _batch(0, dev)
+    wrapped.eval()
+    p1 = wrapped(img, word)
+    p2 = model(img, word)
+    assert p1.shape == (4, 1, 16, 16) and torch.equal(p1, p2)
+    sd = wrapped.state_dict()
+    assert all(k.startswith("module.") for k in sd)
+    other, _ = build_segmenter(NS(**TINY))
+    other = torch.nn.DataParallel(other, device_ids=[0]).cuda()
+    other.load_state_dict(sd, strict=True)                      # test.py:78
+    other.eval()
+    assert torch.equal(other(img, word), p1)
