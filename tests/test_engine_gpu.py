@@ -150,7 +150,7 @@ def test_eval_forward_matches_oracle():
     assert pred.shape == ref.shape
     err = float((pred.cpu() - ref).norm() / ref.norm())
     print("eval forward rel-L2 vs oracle: %.3e" % err)
-    assert err < 3e-2, err
+    assert err < 2e-2, err                    # measured 7.5e-3
 
 
 def _trajectory(name, max_steps=None):
