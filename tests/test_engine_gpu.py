@@ -94,23 +94,25 @@ def test_config4_r50_480_22_tokens_step_matches_oracle():
 def test_r50_other_shapes_run(batch, size, word_len):
     """shapes the reference uses elsewhere: batch 1 (tools/latency.py:51-62), the multi-scale sizes of engine/engine.py:33
     (320 ... 512), other expression lengths - one train step and one eval forward each, everything finite, logits of the
-    expected shape, and the train step within the "small" parity family of the oracle on the same inputs for the first one"""
+    expected shape; the batch-1 eval forward is compared with the oracle"""
     clip, head = arch.specs_by_name("r50")
     head = dataclasses.replace(head, dropout=0.0, word_len=word_len)
     sd = arch.synthetic_state_dict(clip, head, 0)
     dev = torch.device("cuda:0")
     tr = NativeTrainer(clip, head, sd, dev, launch="eager")
     img, word, mask = synth.make_batch(batch, size, word_len, 0, 0)
-    loss, metric = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
+    if batch > 1:          # (the reference cannot train at batch 1 either: BatchNorm1d of neck.txt_proj raises on one sample)
+        loss, metric = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
+        assert math.isfinite(float(loss)) and bool(torch.isfinite(metric).all())
+        assert all(bool(torch.isfinite(p).all()) for p in tr.engine.P.values())
     pred = tr.eval_forward(img.to(dev), word.to(dev))
     torch.cuda.synchronize()
-    assert math.isfinite(float(loss)) and bool(torch.isfinite(metric).all())
     assert pred.shape == (batch, 1, size // 4, size // 4) and bool(torch.isfinite(pred).all())
-    assert all(bool(torch.isfinite(p).all()) for p in tr.engine.P.values())
-    if batch == 1:
+    if batch == 1:         # tools/latency.py's shape: eval forward of one image + expression against the oracle
         with torch.no_grad():
-            _, _, oloss = O.cris_forward(sd, clip, head, img, word, mask, training=True, drop_seed=None)
-        assert abs(float(loss) - float(oloss)) < 2e-2, (float(loss), float(oloss))
+            ref = O.cris_forward(sd, clip, head, img, word, training=False)
+        err = float((pred.cpu() - ref).norm() / ref.norm())
+        assert err < 3e-2, err
 
 
 def test_training_step_is_deterministic():
