@@ -7,6 +7,15 @@
 #include "common.h"
 #include "../../../include/cris_hip.h"
 
+// No fused multiply-adds in this file: the kernels restate torch / OpenCV float arithmetic operation by operation, and hipcc
+// contracts a*b+c by default (HIP's __fmul_rn / __fadd_rn are plain operators defined in a header OUTSIDE this pragma: their
+// results still get fused; the ep_* helpers below are inside it).
+#pragma clang fp contract(off)
+__device__ __forceinline__ float ep_mul(float a, float b) { return a * b; }
+__device__ __forceinline__ float ep_add(float a, float b) { return a + b; }
+__device__ __forceinline__ double ep_dmul(double a, double b) { return a * b; }
+__device__ __forceinline__ double ep_dadd(double a, double b) { return a + b; }
+
 __device__ __forceinline__ float ep_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // torch upsample_bicubic2d (A = -0.75): weights of taps -1, 0, +1, +2 for the fractional offset t
@@ -41,11 +50,11 @@ __global__ __launch_bounds__(256) void sigmoid_bicubic_kernel(const float* __res
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int xx = min(max(ix - 1 + j, 0), w - 1);
-                const float t = __fmul_rn(ep_sigmoid(src[yy * w + xx]), cx[j]);
-                r = j == 0 ? t : __fadd_rn(r, t);
+                const float t = ep_mul(ep_sigmoid(src[yy * w + xx]), cx[j]);
+                r = j == 0 ? t : ep_add(r, t);
             }
-            const float t = __fmul_rn(r, cy[i]);
-            acc = i == 0 ? t : __fadd_rn(acc, t);
+            const float t = ep_mul(r, cy[i]);
+            acc = i == 0 ? t : ep_add(acc, t);
         }
         out[idx] = acc;
     }
@@ -77,9 +86,9 @@ __global__ __launch_bounds__(256) void warp_affine_cubic_kernel(const float* __r
         const double AB = (double)(1 << EP_AB_BITS);
         const int round_delta = (1 << EP_AB_BITS) / (1 << EP_INTER_BITS) / 2;
         // (explicit _rn operations: no fused multiply-add, so that the fixed-point coordinates equal a host evaluation bit for bit)
-        const long adelta = (long)rint(__dmul_rn(__dmul_rn(a.m[0], (double)x), AB)), bdelta = (long)rint(__dmul_rn(__dmul_rn(a.m[3], (double)x), AB));
-        const long X0 = (long)rint(__dmul_rn(__dadd_rn(__dmul_rn(a.m[1], (double)y), a.m[2]), AB)) + round_delta;
-        const long Y0 = (long)rint(__dmul_rn(__dadd_rn(__dmul_rn(a.m[4], (double)y), a.m[5]), AB)) + round_delta;
+        const long adelta = (long)rint(ep_dmul(ep_dmul(a.m[0], (double)x), AB)), bdelta = (long)rint(ep_dmul(ep_dmul(a.m[3], (double)x), AB));
+        const long X0 = (long)rint(ep_dmul(ep_dadd(ep_dmul(a.m[1], (double)y), a.m[2]), AB)) + round_delta;
+        const long Y0 = (long)rint(ep_dmul(ep_dadd(ep_dmul(a.m[4], (double)y), a.m[5]), AB)) + round_delta;
         const long Xq = (X0 + adelta) >> (EP_AB_BITS - EP_INTER_BITS), Yq = (Y0 + bdelta) >> (EP_AB_BITS - EP_INTER_BITS);
         const int sx = (int)(Xq >> EP_INTER_BITS) - 1, sy = (int)(Yq >> EP_INTER_BITS) - 1;
         const int fx = (int)(Xq & 31), fy = (int)(Yq & 31);
@@ -92,8 +101,8 @@ __global__ __launch_bounds__(256) void warp_affine_cubic_kernel(const float* __r
                 const int xx = sx + kx;
                 const bool inside = yy >= 0 && yy < H && xx >= 0 && xx < W;
                 const float v = inside ? src[(size_t)min(max(yy, 0), H - 1) * W + min(max(xx, 0), W - 1)] : border;
-                const float wgt = __fmul_rn(a.tab[fy][ky], a.tab[fx][kx]);
-                acc = __fadd_rn(acc, __fmul_rn(v, wgt));
+                const float wgt = ep_mul(a.tab[fy][ky], a.tab[fx][kx]);
+                acc = ep_add(acc, ep_mul(v, wgt));
             }
         }
         dst[idx] = acc;
