@@ -32,7 +32,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; 
 // row / column are row0 / col0: bias, activation, dropout, residual, bf16|fp32 store, head-split transposed copy and the
 // BatchNorm statistics partial `part` (sum, M2 about the part mean over the FM*16 rows of this wave tile).
 // LEAN: compile-time promise of the plain conv / dgrad case (bf16 output, optional bf16 residual, optional statistics;
-// no bias, activation, dropout, transposed copy, fp32 I/O or fused BN-backward sums) - the epilogue every block of the ~190
+// no bias, activation, dropout, transposed copy or fp32 I/O) - the epilogue every block of the ~190
 // convolution GEMMs per step runs; the general form costs thousands of instructions per wave.
 template <bool LEAN, int MT, int FM, int FN, typename ACC>
 __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, ACC (&acc)[FM][FN], int row0, int col0, int part,
@@ -59,21 +59,12 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
         const_cast<void*>(p.resid), 0, has_res ? (int)((size_t)p.M * p.ldr * res_es) : 0, CRIS_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, has_out ? (int)((size_t)p.M * p.ldc * out_es) : 0,
                                                                         CRIS_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.bnr_y), 0, p.bnr_y ? (int)((size_t)p.M * p.bnr_ldy * 2) : 0, CRIS_BUF_FLAGS);
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const int col = col0 + j * MT + fr;
         const bool cvalid = col < p.N;
         const float bias = (!LEAN && p.bias) ? p.bias[cvalid ? col : 0] : 0.f;
         float vals[FM * NG][4];
-        // fused BatchNorm-backward reduction (see cris_conv_gemm_params.bnr_*)
-        const bool bnr = !LEAN && p.bnr_y != nullptr;
-        float bsc = 0.f, bsh = 0.f, bmu = 0.f, biv = 0.f, bs0 = 0.f, bs1 = 0.f;
-        if (bnr) {
-            const int cc = cvalid ? col : 0;
-            bsc = p.bnr_scale[cc]; bsh = p.bnr_shift[cc]; bmu = p.bnr_mean[cc]; biv = p.bnr_invstd[cc];
-        }
 #pragma unroll
         for (int ig = 0; ig < FM * NG; ++ig) {
             const int i = ig / NG, g = ig % NG;
@@ -100,13 +91,6 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 if (!valid) x = 0.f;
                 v[r] = x;
                 vals[ig][r] = x;
-                if (bnr) {
-                    const unsigned yo = valid ? ((unsigned)m * (unsigned)p.bnr_ldy + (unsigned)(p.bnr_coff + col)) * 2u : CRIS_OOB;
-                    const float yv = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsY, yo, 0, 0));
-                    const float g = (valid && yv * bsc + bsh > 0.f) ? bf2f(f2bf(x)) : 0.f;      // dz as the apply pass reads it
-                    bs0 += g;
-                    bs1 += g * (yv - bmu) * biv;
-                }
                 if (has_out) {
                     const unsigned off = valid ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(p.c_coff + col)) * out_es : CRIS_OOB;
                     if (out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, 0);
@@ -134,18 +118,6 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                         }
                     }
                 }
-            }
-        }
-        if (bnr) {
-            if (MT == 16) {
-                bs0 += __shfl_xor(bs0, 16, 64);
-                bs1 += __shfl_xor(bs1, 16, 64);
-            }
-            bs0 += __shfl_xor(bs0, 32, 64);
-            bs1 += __shfl_xor(bs1, 32, 64);
-            if (fg == 0 && cvalid && part_cnt > 0) {          // per wave-tile partials, summed by cris_sum_partials
-                p.bnr_sums[(size_t)part * 2 * p.N + col] = bs0;
-                p.bnr_sums[(size_t)part * 2 * p.N + p.N + col] = bs1;
             }
         }
         if (p.colsum) {
@@ -531,9 +503,6 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
                    "bad transposed-store geometry");
     CRIS_CHECK_ARG((uintptr_t)p.A % 16 == 0 && (uintptr_t)p.Wt % 16 == 0, "operands must be 16-byte aligned");
     CRIS_CHECK_ARG((long)p.M * p.N < (1L << 32) || p.drop_thresh == 0u, "dropout index overflow");
-    CRIS_CHECK_ARG(!p.bnr_y || (p.bnr_scale && p.bnr_shift && p.bnr_mean && p.bnr_invstd && p.bnr_sums && p.out && !p.out_f32 &&
-                               (size_t)p.M * p.bnr_ldy * 2 < (1UL << 31)),
-                   "fused BatchNorm-backward reduction needs all bnr_* pointers and a bf16 output");
     CRIS_CHECK_ARG((size_t)p.Bn * p.H * p.W * p.lda * 2 < (1UL << 31) && ((size_t)p.N + 256) * p.ldb * 2 < (1UL << 31) &&
                        (!p.out || (size_t)p.M * p.ldc * 4 < (1UL << 31)) && (!p.resid || (size_t)p.M * p.ldr * 4 < (1UL << 31)),
                    "operand extent must stay below 2 GiB (32-bit buffer offsets)");
@@ -556,8 +525,7 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
         cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, lds_ready);
         return lds_ready;
     }
-    const int lean = (!p.bias && p.act == 0 && p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32) &&
-                      !p.bnr_y) ? 1 : 0;
+    const int lean = (!p.bias && p.act == 0 && p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32)) ? 1 : 0;
     switch (pick_variant(p)) {
         case V_SKINNY1:
             hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);

@@ -103,10 +103,6 @@ class Engine:
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue)
         self._wq, self._sq = ops.WgradQueue(self._flush_wgrads), ops.SumQueue()
-        # Folding a BatchNorm's backward reduction into its consumer conv's input-gradient GEMM epilogue is implemented and
-        # parity-tested, but MEASURED SLOWER (21.0 -> 22.0 ms/step at R50/416/B=8: the per-element y reads and extra
-        # arithmetic lengthen every block's epilogue by more than the separate reduction pass costs): off by default.
-        self.fuse_bn_bwd = os.environ.get("CRIS_FUSE_BN_BWD", "0") == "1"
         self._zslab, self._zcur, self._zneed, self._zneed_last = None, 0, 0, 0
         self._tables = {}
         self._build_grad_arena()
@@ -307,10 +303,9 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def gemm(self, x: Act, wname: str, N: int, *, k=1, pad=0, rows=None, bias: Optional[str] = None, out: Optional[Act] = None,
              out_f32=False, resid: Optional[Act] = None, drop: Drop = NO_DROP, stats=False, outT=None, geom: Optional[Geom] = None,
-             no_dgrad=False, stream_grad: Optional[Act] = None, w_transposed=False, fuse_bn_bwd=False):
+             no_dgrad=False, stream_grad: Optional[Act] = None, w_transposed=False):
         """y = conv_k(x) with weight `wname` (rows n0:n1 of it when `rows`), optional bias / residual / dropout /
-        BN statistics / transposed head-split copy.  `fuse_bn_bwd`: x is the output of a plain BatchNorm+ReLU and this
-        conv is its ONLY consumer - the input-gradient GEMM then also accumulates that BatchNorm's backward sums.  `stream_grad`: fp32 residual-stream Act whose gradient is the
+        BN statistics / transposed head-split copy.  `stream_grad`: fp32 residual-stream Act whose gradient is the
         gradient of this layer's output (post dropout) - used for `x + dropout(linear(..))` branches."""
         g = geom or Geom(x.Bn, x.H, x.W, x.C, k, k, 1, pad)
         Wf, Wd = self.WF[wname], self.WD.get(wname)
@@ -360,17 +355,6 @@ class Engine:
             dT = self._dgrad_outT
             if dT is not None:
                 tkw = dict(outT=dT["buf"], T_L=dT["L"], T_Lpad=dT["Lpad"], T_E=dT["E"], T_sec_stride=dT["sec_stride"])
-            src = x.root.aux.get("bnsrc") if (fuse_bn_bwd and self.fuse_bn_bwd and not acc and x.coff == 0) else None
-            if src is not None:
-                Cb = src["C"]
-                if self.sync_bn:
-                    sums = self.zeros(2 * Cb)
-                else:
-                    Gb = self.G[src["pfx"] + ".bias"]
-                    sums = self.grad_arena[Gb.storage_offset():Gb.storage_offset() + 2 * Cb]
-                yb = src["y"]
-                tkw["bnr"] = (yb.t, yb.ld, yb.coff, src["scale"], src["shift"], src["mean"], src["invstd"], sums)
-                x.root.aux["bn_reduced"] = sums
             ops.conv_gemm(gy, wd, gD, Wd.shape[0], lda=gy_ld, a_coff=gy_coff, ldb=Wd.shape[1], out=gx, ldc=x.ld, c_coff=x.coff,
                           resid=gx if acc else None, ldr=x.ld, r_coff=x.coff, **tkw)
 
@@ -426,19 +410,12 @@ class Engine:
             return out
         dmul = self.empty(y.Bn, C, dtype=F32) if mul is not None else None
         out.aux["dmul"] = dmul
-        if relu and not pool and ident is None and y2 is None and mul is None and out.coff == 0 and out.C == C:
-            # a consumer conv may fold this BatchNorm's backward reduction into its input-gradient GEMM (gemm(fuse_bn_bwd))
-            out.aux["bnsrc"] = dict(pfx=pfx, y=y, scale=scale, shift=shift, mean=mean, invstd=invstd, C=C)
-
         def bwd():
             Gb = self.G[pfx + ".bias"]
             # [dbeta | dgamma] (and the paired downsample block) are contiguous in the arena
             nblk = 4 * C if y2 is not None else 2 * C
             arena_block = self.grad_arena[Gb.storage_offset():Gb.storage_offset() + nblk]
-            reduced = out.aux.get("bn_reduced")           # sums already accumulated by the consumer's dgrad GEMM
-            if reduced is not None:
-                sums = reduced
-            elif self.sync_bn:
+            if self.sync_bn:
                 sums = self.zeros(nblk)
             else:
                 sums = arena_block
@@ -462,7 +439,7 @@ class Engine:
                        mean2=mean2, invstd2=inv2, scale2=sc2, dy2=dy2, lddy2=None if y2 is None else y2.ld,
                        dy2_coff=0 if y2 is None else y2.coff, mul=mul, dmul=dmul, dident=did,
                        lddi=None if ident is None else ident.ld, di_coff=0 if ident is None else ident.coff,
-                       dident_accum=bool(did_acc), between=between if self.sync_bn else None, skip_reduce=reduced is not None)
+                       dident_accum=bool(did_acc), between=between if self.sync_bn else None)
 
         self.tape.append(bwd)
         return out
@@ -549,8 +526,8 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def _bottleneck(self, x: Act, p: str, planes: int, stride: int, has_ds: bool) -> Act:
         a1 = self.conv_bn(x, p + ".conv1", p + ".bn1", planes)
-        a2 = self.conv_bn(a1, p + ".conv2", p + ".bn2", planes, k=3, pad=1, pool=stride > 1, fuse_bn_bwd=True)
-        y3, st3 = self.gemm(a2, p + ".conv3.weight", planes * 4, stats=True, fuse_bn_bwd=True)
+        a2 = self.conv_bn(a1, p + ".conv2", p + ".bn2", planes, k=3, pad=1, pool=stride > 1)
+        y3, st3 = self.gemm(a2, p + ".conv3.weight", planes * 4, stats=True)
         if has_ds:
             xi = x
             if stride > 1:
@@ -575,8 +552,8 @@ class Engine:
         y = self.new_act(B, H // 2, W // 2, w // 2)
         _, st = self.gemm(xcol, v + ".conv1.weight", w // 2, geom=Geom.linear(xcol.M, 32), stats=True, no_dgrad=True, out=y)
         x = self.bn(y, st, v + ".bn1")
-        x = self.conv_bn(x, v + ".conv2", v + ".bn2", w // 2, k=3, pad=1, fuse_bn_bwd=True)
-        x = self.conv_bn(x, v + ".conv3", v + ".bn3", w, k=3, pad=1, pool=True, fuse_bn_bwd=True)
+        x = self.conv_bn(x, v + ".conv2", v + ".bn2", w // 2, k=3, pad=1)
+        x = self.conv_bn(x, v + ".conv3", v + ".bn3", w, k=3, pad=1, pool=True)
         feats = []
         inpl = w
         for li, nblk in enumerate(self.clip.vision_layers):
@@ -737,7 +714,7 @@ class Engine:
         ops.fill_coords(cc.t, cc.ld, fo[1], cc.ld - fo[1], cc.Bn, cc.H, cc.W)
         self._neck_taps = dict(f5=f5, f4=f4, f3=f3, aggr=cc.slice(0, fo[1]), s=s)
         fq = self.conv_bn(cc, n + ".coordconv.0.conv1.0", n + ".coordconv.0.conv1.1", fo[1], k=3, pad=1)
-        fq = self.conv_bn(fq, n + ".coordconv.1.0", n + ".coordconv.1.1", fo[1], k=3, pad=1, fuse_bn_bwd=True)
+        fq = self.conv_bn(fq, n + ".coordconv.1.0", n + ".coordconv.1.1", fo[1], k=3, pad=1)
         return fq
 
     def _upsample(self, x: Act, out: Act):
@@ -828,7 +805,7 @@ class Engine:
         u2 = self.new_act(B, z1.H * 2, z1.W * 2, z1.C)
         self._upsample(z1, u2)
         z2 = self.conv_bn(u2, p + ".vis.3.0", p + ".vis.3.1", c, k=3, pad=1)
-        x = self.gemm(z2, p + ".vis.4.weight", c, bias=p + ".vis.4.bias", fuse_bn_bwd=True)
+        x = self.gemm(z2, p + ".vis.4.weight", c, bias=p + ".vis.4.bias")
         nwb = c * 9 + 1
         wb = Act(self.zeros(B, pad8(nwb)), B, 1, 1, nwb, pad8(nwb))
         self._wb_layer(state, wb, nwb)

@@ -28,9 +28,7 @@ class ConvGemmParams(C.Structure):
                 ("ldc", I), ("c_coff", I), ("out_f32", I),
                 ("T_L", I), ("T_Lpad", I), ("T_E", I),
                 ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U),
-                ("drop_seed_dev", P),
-                ("bnr_y", P), ("bnr_scale", P), ("bnr_shift", P), ("bnr_mean", P), ("bnr_invstd", P), ("bnr_sums", P),
-                ("bnr_ldy", I), ("bnr_coff", I)]
+                ("drop_seed_dev", P)]
 
 
 class WgradParams(C.Structure):

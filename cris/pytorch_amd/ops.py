@@ -80,7 +80,7 @@ NO_DROP = Drop(0.0, 0, 0)
 
 def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None, act=0, resid=None, ldr=None, r_coff=0,
               out=None, ldc=None, c_coff=0, outT=None, T_L=0, T_Lpad=0, T_E=0, T_sec_stride=0, stats=False,
-              drop: Drop = NO_DROP, bnr=None):
+              drop: Drop = NO_DROP):
     """out[M,N] = epi(A_im2col @ Wt^T).  A bf16 NHWC buffer (row stride lda), Wt bf16 [N][ldb].
     stats=True: also returns the BatchNorm statistics partials (Stats) of the output columns."""
     p = hip.ConvGemmParams()
@@ -107,13 +107,6 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
         p.T_L, p.T_Lpad, p.T_E, p.T_sec_stride = T_L, T_Lpad, T_E, T_sec_stride
     p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
     p.drop_seed_dev = ptr(drop.dev)
-    bnr_part = None
-    if bnr is not None:        # (y, ldy, y_coff, scale, shift, mean, invstd, sums): fused BatchNorm-backward reduction
-        y, p.bnr_ldy, p.bnr_coff = bnr[0], bnr[1], bnr[2]
-        p.bnr_y, p.bnr_scale, p.bnr_shift, p.bnr_mean, p.bnr_invstd = ptr(y), ptr(bnr[3]), ptr(bnr[4]), ptr(bnr[5]), ptr(bnr[6])
-        rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))
-        bnr_part = torch.empty((g.M + rows - 1) // rows, 2 * N, dtype=torch.float32, device=A.device)
-        p.bnr_sums = ptr(bnr_part)
     st = None
     if stats:
         rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))          # depends on the tile variant the library picks
@@ -124,12 +117,8 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
         KERNEL_TIMER.launch("skinny_gemm" if rows == 16 else "conv_gemm", 2.0 * g.M * N * g.K,
                             2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p),
                             tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
-        if bnr_part is not None:
-            hip.call("cris_sum_partials", ptr(bnr_part), bnr_part.shape[0], 2 * N, ptr(bnr[7]), _stream())
         return st
     hip.call("cris_conv_gemm", C.byref(p), _stream())
-    if bnr_part is not None:      # per-row-block partials -> the BatchNorm's [sum g | sum g*xhat] block (+=)
-        hip.call("cris_sum_partials", ptr(bnr_part), bnr_part.shape[0], 2 * N, ptr(bnr[7]), _stream())
     return st
 
 
@@ -390,9 +379,8 @@ def bn_apply(y, scale, shift, z, Bn, H, W, C_, *, ldy=None, y_coff=0, ldz=None, 
 def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, lddz=None, dz_coff=0, ldy=None, y_coff=0,
            lddy=None, dy_coff=0, relu=True, pool=False, z=None, ldz=None, z_coff=0, y2=None, ldy2=None, y2_coff=0, mean2=None,
            invstd2=None, scale2=None, dy2=None, lddy2=None, dy2_coff=0, mul=None, dmul=None, dident=None, lddi=None,
-           di_coff=0, dident_accum=False, between=None, skip_reduce=False):
-    """reduce + apply.  `between(sums)` (optional) runs between the two launches (SyncBN all-reduce).  skip_reduce: the
-    sums were already accumulated by the consumer conv's input-gradient GEMM (conv_gemm(bnr=...))."""
+           di_coff=0, dident_accum=False, between=None):
+    """reduce + apply.  `between(sums)` (optional) runs between the two launches (SyncBN all-reduce)."""
     p = hip.BnBwdParams()
     p.dz, p.lddz, p.dz_coff = ptr(dz), lddz if lddz is not None else dz.shape[-1], dz_coff
     if z is not None:
@@ -413,10 +401,9 @@ def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, 
     p.relu, p.pool = int(relu), int(pool)
     p.count = float(count)
     s = _stream()
-    if not skip_reduce:
-        part = torch.empty(hip.load().cris_bn_bwd_ws_floats(C.byref(p)), dtype=torch.float32, device=dz.device)
-        p.part = ptr(part)
-        hip.call("cris_bn_bwd_reduce", C.byref(p), s)
+    part = torch.empty(hip.load().cris_bn_bwd_ws_floats(C.byref(p)), dtype=torch.float32, device=dz.device)
+    p.part = ptr(part)
+    hip.call("cris_bn_bwd_reduce", C.byref(p), s)
     if between is not None:
         between(sums)
     hip.call("cris_bn_bwd_apply", C.byref(p), s)

@@ -62,15 +62,6 @@ typedef struct {
     uint32_t drop_thresh;    /* keep iff hash >= drop_thresh; host computes min(int(p*2^32), 2^32-1); 0 = off */
     uint32_t drop_seed, drop_stream;
     const uint32_t* drop_seed_dev; /* optional device word added to drop_seed (per-step seed of a replayed HIP graph) */
-    /* optional fused BatchNorm-backward reduction: when this GEMM is the input-gradient of the conv that consumes
-     * z = relu(bn(y)), its output IS dz; the epilogue then also writes, per row-block of cris_conv_gemm_stat_rows(p)
-     * rows (the same blocks as colsum), bnr_sums[part][c] = sum_m g and bnr_sums[part][N + c] = sum_m g * xhat with
-     * g = dz * [y*scale+shift > 0], xhat = (y - mean) * invstd - what cris_bn_bwd_reduce computes in a separate pass
-     * over dz and y.  cris_sum_partials adds the blocks into the [2N] sums.  y: [M][bnr_ldy] (+bnr_coff). */
-    const cris_bf16* bnr_y;
-    const float* bnr_scale; const float* bnr_shift; const float* bnr_mean; const float* bnr_invstd;
-    float* bnr_sums;
-    int bnr_ldy, bnr_coff;
 } cris_conv_gemm_params;
 int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
 /* rows per BatchNorm-statistics partial written for this problem (depends on the tile variant chosen; host only) */
