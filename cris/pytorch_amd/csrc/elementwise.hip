@@ -398,16 +398,6 @@ extern "C" int cris_axpy_f32(float* dst, const float* src, float alpha, long n, 
     CRIS_LAUNCH_CHECK();
     return 0;
 }
-__global__ void memset_f32_kernel(float* p, float v, long n) {
-    GRID_STRIDE(i, n) p[i] = v;
-}
-extern "C" int cris_memset_f32(float* p, float v, long n, void* stream) {
-    CRIS_CHECK_ARG(p && n > 0, "bad args");
-    hipLaunchKernelGGL(memset_f32_kernel, dim3(cris_grid_1d(n, 256)), dim3(256), 0, (hipStream_t)stream, p, v, n);
-    CRIS_LAUNCH_CHECK();
-    return 0;
-}
-
 // ------------------------------------------------------------------------------------------------
 // embedding
 // ------------------------------------------------------------------------------------------------

@@ -127,13 +127,6 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 void cris_launch_sum_partials(const float* part, int nparts, int ncol, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, stream, part, nparts, ncol, out);
 }
-extern "C" int cris_sum_partials(const float* part, int nparts, int ncol, float* out, void* stream) {
-    CRIS_CHECK_ARG(part && out && nparts > 0 && ncol > 0, "bad args");
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, part, nparts, ncol, out);
-    CRIS_LAUNCH_CHECK();
-    return 0;
-}
-
 // rows the caller must allocate for a partials buffer of `nparts` parts (room for the level-1 merge output)
 extern "C" int cris_bn_partials_rows(int nparts) { return nparts > BN_MERGE_MIN ? nparts + BN_MERGE_SLICES : nparts; }
 
@@ -160,22 +153,6 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
                        count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
                        merged, global_stats);
-    CRIS_LAUNCH_CHECK();
-    return 0;
-}
-
-// re-centre a rank-local M2 about the global mean: m2[c] += n_local * (mean_local[c] - gsum[c]/count_global)^2
-__global__ void bn_recentre_kernel(float* m2, const float* mean_local, const float* gsum, float n_local, float count_global, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float d = mean_local[c] - gsum[c] / count_global;
-    m2[c] += n_local * d * d;
-}
-extern "C" int cris_bn_recentre(float* m2, const float* mean_local, const float* gsum, float n_local, float count_global, int C,
-                                void* stream) {
-    CRIS_CHECK_ARG(m2 && mean_local && gsum && C > 0, "bad args");
-    hipLaunchKernelGGL(bn_recentre_kernel, dim3(cris_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, m2, mean_local, gsum, n_local,
-                       count_global, C);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -199,9 +199,7 @@ _SIGS = {
     "cris_pack_block_elems": (I, []),
     "cris_conv_gemm_stat_rows": (I, [P]),
     "cris_bn_partials_rows": (I, [I]),
-    "cris_sum_partials": (I, [P, I, I, P, P]),
     "cris_bn_finalize": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P, P]),
-    "cris_bn_recentre": (I, [P, P, P, F, F, I, P]),
     "cris_bn_sync_pack": (I, [P, P, P, F, I, P]),
     "cris_bn_sync_unpack": (I, [P, P, F, I, P]),
     "cris_colstats_bf16": (I, [P, I, I, I, I, I, P, P, P]),
@@ -250,7 +248,6 @@ _SIGS = {
     "cris_sigmoid_bicubic_up": (I, [P, I, I, I, I, I, P, P]),
     "cris_warp_affine_cubic": (I, [P, I, I, P, I, I, F, P, P]),
     "cris_threshold_iou": (I, [P, P, L, F, P, P]),
-    "cris_memset_f32": (I, [P, F, L, P]),
     "cris_zero_bytes": (I, [P, C.c_size_t, P]),
     "cris_zero_many": (I, [P, P]),
     "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, I, P]),

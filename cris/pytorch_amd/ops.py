@@ -335,10 +335,6 @@ def bn_finalize(st: Optional[Stats], count_local, count, gamma, beta, rmean, rva
              ptr(global_stats), _stream())
 
 
-def bn_recentre(m2, mean_local, gsum, n_local, count_global, C_):
-    hip.call("cris_bn_recentre", ptr(m2), ptr(mean_local), ptr(gsum), float(n_local), float(count_global), C_, _stream())
-
-
 def bn_sync_pack(merged, mean_local, ref, n_local, C_):
     hip.call("cris_bn_sync_pack", ptr(merged), ptr(mean_local), ptr(ref), float(n_local), C_, _stream())
 
@@ -667,10 +663,6 @@ def torch_op(fn):
                 with torch.cuda.stream(s):
                     fn()
         rec.cmds.append((run, None, "torch_op"))
-
-
-def memset_f32(t, v=0.0):
-    hip.call("cris_memset_f32", ptr(t), float(v), t.numel(), _stream())
 
 
 class _AdamDeviceTable:

@@ -125,20 +125,15 @@ int cris_pack_block_elems(void);
  * Statistics arrive as per-row-block partials (column sum, M2 about the block mean) from the conv GEMM
  * epilogue or cris_colstats_bf16 and are merged with Chan's parallel-variance formula.
  * SyncBN: call once with `merged` (local sum / M2 / mean out), exchange (cris_bn_sync_pack + ONE all-reduce +
- * cris_bn_sync_unpack; or all-reduce the sums, cris_bn_recentre the M2, all-reduce the M2), then call again with
- * `global_stats`.
+ * cris_bn_sync_unpack), then call again with `global_stats`.
  * Long partial lists are merged in two levels: psum / pm2 must have room for cris_bn_partials_rows(nparts) rows of C
  * floats each (the first-level result is written behind the nparts partial rows).
  * ---------------------------------------------------------------------------------------------- */
 int cris_bn_partials_rows(int nparts);
-/* out[c] += sum_p part[p][c]  (p < nparts, c < ncol): deterministic column sums of a partials table */
-int cris_sum_partials(const float* part, int nparts, int ncol, float* out, void* stream);
 int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local, float count,
                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                      float eps, int C, float* scale, float* shift, float* mean, float* invstd, float* merged,
                      const float* global_stats, void* stream);
-int cris_bn_recentre(float* m2, const float* mean_local, const float* gsum, float n_local, float count_global, int C,
-                     void* stream);
 /* single-exchange SyncBN: pack the local (sum | M2) [2C] into moments about `ref` (identical on every rank, e.g. the
  * running mean), all-reduce the 2C floats once, unpack into (global sum | M2 about the global mean) for
  * cris_bn_finalize(global_stats=...) */
@@ -351,8 +346,6 @@ int cris_warp_affine_cubic(const float* src, int H, int W, const double* mat, in
                            void* stream);
 /* counts[0] += #(pred > thr & mask), counts[1] += #(pred > thr | mask)  (engine.py:117-122); counts: 2 device ints */
 int cris_threshold_iou(const float* pred, const float* mask, long n, float thr, int* counts, void* stream);
-/* elementwise multiply by per-(batch,channel) scalar handled inside cris_bn_apply (mul) */
-int cris_memset_f32(float* p, float v, long n, void* stream);
 /* zero fill of any 16-byte aligned buffer */
 int cris_zero_bytes(void* p, size_t nbytes, void* stream);
 /* zero several byte ranges in one launch (the parts of the gradient arena that are accumulated into or only partly written:
