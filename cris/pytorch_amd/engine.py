@@ -13,7 +13,6 @@ Reference call graph being restated (file:line in DerrickWang005/CRIS.pytorch):
 """
 from __future__ import annotations
 
-import contextlib
 import os
 from typing import Callable, Dict, List, Optional
 
@@ -102,13 +101,7 @@ class Engine:
         # the text encoder (12 layers of M = B*L ~ 136-row GEMMs: latency-bound, ~16 workgroups each) is independent of
         # the visual encoder until the neck: it runs on a second HIP stream, forward and backward, underneath the convs
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
-        # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue).
-        # Weight gradients only feed the gradient arena, which nothing reads before the end of backward: on one GPU they are
-        # issued on the text-encoder stream (CRIS_WGRAD_SIDE, see _wgrad_stream) underneath the latency-bound dgrad /
-        # BatchNorm chain of the launch stream.  With several ranks a stage's gradients are exchanged as soon as the stage is
-        # done, so they stay on the launch stream there.
-        self.wgrad_side = (self.side is not None and self.comm.world == 1 and os.environ.get("CRIS_WGRAD_SIDE", "0") == "1")
-        self._wkeep = []
+        # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue)
         self._wq, self._sq = ops.WgradQueue(self._flush_wgrads), ops.SumQueue()
         self._zslab, self._zcur, self._zneed, self._zneed_last = None, 0, 0, 0
         self._tables = {}
@@ -292,28 +285,13 @@ class Engine:
         t = (self.zeros if zero else self.empty)(Bn * H * W, ld, dtype=dtype)
         return Act(t, Bn, H, W, C, ld)
 
-    def _wgrad_stream(self, *keep):
-        """context in which weight-gradient launches are issued: the current stream, or (wgrad_side) the side stream after
-        everything issued so far on the current one.  `keep`: operand tensors, held until backward() has joined the streams (a
-        block freed earlier could be handed out again on the launch stream while the side stream still reads it)."""
-        import contextlib
-        cur = torch.cuda.current_stream()
-        if not self.wgrad_side or cur == self.side:
-            return contextlib.nullcontext()
-        ops.torch_op(lambda: self.side.wait_stream(cur))
-        self._wkeep.extend(keep)
-        return torch.cuda.stream(self.side)
-
     def _flush_wgrads(self):
-        if not self._wq.items:
-            return
-        with self._wgrad_stream():
-            self._wkeep.extend(self._wq.flush())
+        self._wq.flush()
 
     def _flush_queues(self):
-        """launch what backward has queued so far: grouped weight gradients and (on the current stream) the ordered sums of
-        the LayerNorm parameter-gradient partials"""
-        self._flush_wgrads()
+        """launch what backward has queued so far on the current stream: grouped weight gradients and the ordered sums of the
+        LayerNorm parameter-gradient partials"""
+        self._wq.flush()
         self._sq.flush()
 
     def drop(self, layer, site):
@@ -360,15 +338,13 @@ class Engine:
                 gy_ld, gy_coff = pad8(N), 0
             else:
                 gy, gy_ld, gy_coff = out.g, out.ld, out.coff
-            queued = g.M <= ops._WGRAD_GROUP_M                    # (queued problems are launched - and routed - at the next flush)
-            with (contextlib.nullcontext() if queued else self._wgrad_stream(gy, x.t)):
-                if w_transposed:
-                    # parameter stored [in, out] (used as x @ P): dP = x^T dY - same kernel with the operand roles swapped
-                    ops.conv_wgrad(x.t, gy, Geom.linear(out.M, pad8(N)), x.C, Gw, ldy=x.ld, y_coff=x.coff, N_ld=x.C, ldx=gy_ld,
-                                   x_coff=gy_coff, queue=self._wq)
-                else:
-                    ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff,
-                                   dbias=None if bias is None else self.G[bias][n0:n0 + N], queue=self._wq)
+            if w_transposed:
+                # parameter stored [in, out] (used as x @ P): dP = x^T dY - same kernel with the operand roles swapped
+                ops.conv_wgrad(x.t, gy, Geom.linear(out.M, pad8(N)), x.C, Gw, ldy=x.ld, y_coff=x.coff, N_ld=x.C, ldx=gy_ld,
+                               x_coff=gy_coff, queue=self._wq)
+            else:
+                ops.conv_wgrad(gy, x.t, g, N, Gw, ldy=gy_ld, y_coff=gy_coff, N_ld=pad8(N), ldx=x.ld, x_coff=x.coff,
+                               dbias=None if bias is None else self.G[bias][n0:n0 + N], queue=self._wq)
             if no_dgrad:
                 return
             assert N % 8 == 0, "dgrad path needs N % 8 == 0 (pad the gradient buffer otherwise)"
@@ -980,7 +956,6 @@ class Engine:
         self._flush_queues()
         if self.side is not None:
             ops.torch_op(lambda: main.wait_stream(self.side))
-        self._wkeep = []
         self._zneed_last = max(self._zneed_last, self._zneed)
         Act._engine = None
         self.tape = []
