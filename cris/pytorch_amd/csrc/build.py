@@ -9,7 +9,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = ["api.hip", "gemm.hip", "wgrad.hip", "norm.hip", "attention.hip", "elementwise.hip", "evalpost.hip", "p2p.hip"]
 LIB = os.path.join(HERE, "libcris_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# -fno-slp-vectorize -fno-vectorize: keep packed-FP32 VALU instructions (v_pk_mul/add/fma_f32) out of the code object.
+# Measured on MI355X (tools/concurrency_probe.py, profiles/r02_packed_fp32_concurrency.md): a wave executing them
+# occasionally gets a wrong result while waves of an MFMA kernel launched on ANOTHER stream share its CU - the LayerNorm
+# backward of the text encoder (side stream) differed from run to run underneath the convolution GEMMs until its packed
+# ops were gone.  The step time is unchanged (the affected kernels are memory-bound).  packed_fp32_ops() is the check.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize", "-fno-vectorize"]
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
 def _digest():
@@ -43,6 +49,33 @@ def build(force=False, verbose=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def packed_fp32_ops(lib=LIB):
+    """{kernel symbol: count} of v_pk_{mul,add,fma}_f32 instructions in the gfx950 code objects of `lib` (None when
+    llvm-objdump is not available)"""
+    import re
+    import shutil
+    import tempfile
+    if not os.path.exists(OBJDUMP):
+        return None
+    found = {}
+    with tempfile.TemporaryDirectory() as td:
+        so = os.path.join(td, "lib.so")
+        shutil.copy(lib, so)
+        subprocess.run([OBJDUMP, "--offloading", so], cwd=td, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in sorted(os.listdir(td)):
+            if "gfx950" not in f:
+                continue
+            asm = subprocess.run([OBJDUMP, "-d", os.path.join(td, f)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+            name = "?"
+            for line in asm.splitlines():
+                m = re.match(r"^[0-9a-f]+ <(.*)>:", line)
+                if m:
+                    name = m.group(1)
+                elif re.search(r"\bv_pk_(mul|add|fma)_f32\b", line):
+                    found[name] = found.get(name, 0) + 1
+    return found
+
+
 def _compile(dig, verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objs = []
@@ -65,6 +98,10 @@ def _compile(dig, verbose):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n%s" % r.stdout.decode())
+    bad = packed_fp32_ops(tmp)
+    if bad:
+        os.remove(tmp)
+        raise RuntimeError("packed-FP32 VALU instructions in the code object (see FLAGS): %r" % bad)
     if os.path.exists(STAMP):
         os.remove(STAMP)
     os.replace(tmp, LIB)

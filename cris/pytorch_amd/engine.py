@@ -101,6 +101,13 @@ class Engine:
         # the text encoder (12 layers of M = B*L ~ 136-row GEMMs: latency-bound, ~16 workgroups each) is independent of
         # the visual encoder until the neck: it runs on a second HIP stream, forward and backward, underneath the convs
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
+        if os.environ.get("CRIS_NO_SIDE", "0") == "1":          # diagnostic: text encoder on the launch stream
+            self.side = None
+        # diagnostics (tools/determinism_check.py): "sleep" holds the device back at the backward fork so that the two
+        # encoders' backward passes queue up and run fully concurrently; _dbg_taps (a list) collects stream-ordered copies
+        # of the gradient buffers after every text-backward closure
+        self._dbg = os.environ.get("CRIS_DEBUG", "")
+        self._dbg_taps = None
         # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue)
         self._wq, self._sq = ops.WgradQueue(self._flush_wgrads), ops.SumQueue()
         self._zslab, self._zcur, self._zneed, self._zneed_last = None, 0, 0, 0
@@ -287,6 +294,30 @@ class Engine:
 
     def _flush_wgrads(self):
         self._wq.flush()
+
+    def _tap(self, i, fn):
+        """diagnostic: copies (in stream order) of every gradient buffer the closure that just ran can see"""
+        objs = list(fn.__defaults__ or ()) + [c.cell_contents for c in (fn.__closure__ or ())]
+        rec = []
+        for k, o in enumerate(objs):
+            if isinstance(o, Act) and o.g is not None:
+                rec.append(("%d.g" % k, o.g.clone()))
+            elif isinstance(o, dict) and "buf" in o:
+                b = o["buf"]
+                for j, t in enumerate(b if isinstance(b, (tuple, list)) else (b,)):
+                    if torch.is_tensor(t):
+                        rec.append(("%d.buf%d" % (k, j), t.clone()))
+        extra = {}
+        if fn.__qualname__.startswith("Engine.ln."):                     # the closure's own inputs, by cell name
+            for nm, c in zip(fn.__code__.co_freevars, fn.__closure__ or ()):
+                o = c.cell_contents
+                if torch.is_tensor(o):
+                    extra[nm] = o.clone()
+                elif isinstance(o, Act):
+                    extra[nm + ".t"] = o.t.clone()
+                    if o.g is not None:
+                        extra[nm + ".g"] = o.g.clone()
+        self._dbg_taps.append((i, fn.__qualname__, rec, extra))
 
     def _flush_queues(self):
         """launch what backward has queued so far on the current stream: grouped weight gradients and the ordered sums of the
@@ -934,28 +965,35 @@ class Engine:
             self.tape[i]()
             fire(i)
         self._flush_queues()
+        if "sleep" in self._dbg:
+            torch.cuda._sleep(60000000)
         # the two encoders' backward passes are independent: text on the side stream, visual on the launch stream
         main = torch.cuda.current_stream()
+
+        def text_section():
+            for i in range(t1 - 1, t0 - 1, -1):
+                self.tape[i]()
+                if self._dbg_taps is not None:
+                    self._tap(i, self.tape[i])
+            self._flush_queues()
+            if on_stage_done is not None:
+                on_stage_done(4)                         # issued from the side stream: the exchange waits for it only
+
+        def visual_section():
+            for i in range(v1 - 1, v0 - 1, -1):
+                self.tape[i]()
+                fire(i)                                  # visual stages 3, 2, 1, 0 as their layer groups finish
+            self._flush_queues()
+
         if self.side is not None:
             ops.torch_op(lambda: self.side.wait_stream(main))
             with torch.cuda.stream(self.side):
-                for i in range(t1 - 1, t0 - 1, -1):
-                    self.tape[i]()
-                self._flush_queues()
-                if on_stage_done is not None:
-                    on_stage_done(4)                     # issued from the side stream: the exchange waits for it only
-        else:
-            for i in range(t1 - 1, t0 - 1, -1):
-                self.tape[i]()
-            self._flush_queues()
-            if on_stage_done is not None:
-                on_stage_done(4)
-        for i in range(v1 - 1, v0 - 1, -1):
-            self.tape[i]()
-            fire(i)                                      # visual stages 3, 2, 1, 0 as their layer groups finish
-        self._flush_queues()
-        if self.side is not None:
+                text_section()
+            visual_section()
             ops.torch_op(lambda: main.wait_stream(self.side))
+        else:
+            text_section()
+            visual_section()
         self._zneed_last = max(self._zneed_last, self._zneed)
         Act._engine = None
         self.tape = []

@@ -95,3 +95,14 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(hip, "LIB_PATH", "/nonexistent/libcris_hip.so")
     with pytest.raises(hip.HipLibraryError):
         hip.load()
+
+
+def test_no_packed_fp32_valu_instructions():
+    """csrc/build.py FLAGS: v_pk_{mul,add,fma}_f32 gave wrong results under two-stream concurrency on MI355X
+    (profiles/r02_packed_fp32_concurrency.md) - the shipped code object must not contain any"""
+    from cris.pytorch_amd.csrc import build
+    lib = build.build()
+    found = build.packed_fp32_ops(lib)
+    if found is None:
+        pytest.skip("llvm-objdump not available")
+    assert found == {}, found

@@ -144,6 +144,35 @@ def test_training_step_is_deterministic():
         assert all(torch.equal(params[k], outs[0][2][k]) for k in params)
 
 
+def test_two_streams_do_not_disturb_each_other():
+    """The text encoder runs on a second stream underneath the convolutions.  (1) tools/concurrency_probe.py: its backward
+    pattern repeated from fixed inputs stays bit-identical under every kind of load on the other stream (it did not while
+    the library contained packed-FP32 VALU instructions - csrc/build.py FLAGS).  (2) the full R50 step with the device held
+    back at the backward fork, so that both encoders' backward passes run completely concurrently: two trainers, eager
+    launches, identical losses, gradients and parameters."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import concurrency_probe
+    for load in ("gemm", "wgrad", "skinny"):
+        assert concurrency_probe.run(load, 300) == (0, 0), load
+    clip, head = arch.specs_by_name("r50")
+    dev = torch.device("cuda:0")
+    outs = []
+    for rep in range(2):
+        tr = NativeTrainer(clip, head, arch.synthetic_state_dict(clip, head, 0), dev, launch="eager")
+        tr.engine._dbg = "sleep"
+        losses = []
+        for t in range(5):
+            img, word, mask = synth.make_batch(8, 416, head.word_len, 0, t % 4)
+            loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        outs.append((losses, tr.engine.grad_arena.clone(), {k: v.clone() for k, v in tr.engine.P.items()}))
+        del tr
+    assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert all(torch.equal(outs[0][2][k], outs[1][2][k]) for k in outs[0][2])
+
+
 def test_stage_isolated_parity():
     """Every stage (bottlenecks, attnpool, text encoder, FPN, decoder with/without dropout, projector + loss) fed with the
     oracle's bf16-rounded inputs and a random upstream gradient: errors cannot compound across stages here, so the bounds
