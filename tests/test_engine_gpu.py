@@ -260,6 +260,9 @@ def test_loss_trajectory_r50_full_size_100_steps():
     print("r50 trajectory hip / fp32 oracle / bf16-emulated oracle:",
           ["%.4f/%.4f/%.4f" % (a, b, c) for a, b, c in zip(losses, ref, ref_e)])
     de = [abs(a - b) for a, b in zip(ref_e, ref)]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):         # the measured curve, for profiles/parity_r02.json
+        with open(os.path.join(ROOT, "gpurun_out", "traj_r50_hip.json"), "w") as f:
+            json.dump({"loss_hip": [round(x, 6) for x in losses]}, f)
     print("max |hip-fp32| %.3e mean %.3e ; bf16-emulated oracle vs fp32: max %.3e mean %.3e"
           % (max(diffs), sum(diffs) / n, max(de), sum(de) / n))
     assert abs(losses[0] - ref[0]) < 5e-3                      # before any update
