@@ -168,6 +168,10 @@ class ZeroRanges(C.Structure):
     _fields_ = [("n", I), ("pad_", I), ("r", ZeroRange * ZERO_RANGES_MAX)]
 
 
+class SampleDesc(C.Structure):
+    _fields_ = [("img", P), ("mask", P), ("H", I), ("W", I), ("inv", C.c_double * 6)]
+
+
 class P2PParams(C.Structure):
     _fields_ = [("data", P), ("boxes", P), ("gen_dev", P), ("err", P),
                 ("n", I), ("rank", I), ("world", I),
@@ -181,6 +185,7 @@ STRUCTS = {
     "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_wgrad_group": WgradGroup, "cris_pack_desc": PackDesc,
     "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
     "cris_ln_bwd_params": LnBwdParams, "cris_sum_entry": SumEntry, "cris_sum_group": SumGroup, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams, "cris_zero_ranges": ZeroRanges,
+    "cris_sample_desc": SampleDesc,
 }
 
 # name -> (restype, argtypes); struct launchers take (struct*, stream)
@@ -248,6 +253,9 @@ _SIGS = {
     "cris_sigmoid_bicubic_up": (I, [P, I, I, I, I, I, P, P]),
     "cris_warp_affine_cubic": (I, [P, I, I, P, I, I, F, P, P]),
     "cris_threshold_iou": (I, [P, P, L, F, P, P]),
+    "cris_preprocess_batch": (I, [P, I, I, I, P, P, P, P, P, P, P, P]),
+    "cris_invert_affine": (I, [P, P]),
+    "cris_remap_tables_u8": (I, [P, P]),
     "cris_zero_bytes": (I, [P, C.c_size_t, P]),
     "cris_zero_many": (I, [P, P]),
     "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, I, P]),

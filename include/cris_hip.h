@@ -346,6 +346,26 @@ int cris_warp_affine_cubic(const float* src, int H, int W, const double* mat, in
                            void* stream);
 /* counts[0] += #(pred > thr & mask), counts[1] += #(pred > thr | mask)  (engine.py:117-122); counts: 2 device ints */
 int cris_threshold_iou(const float* pred, const float* mask, long n, float thr, int* counts, void* stream);
+/* ---- input preprocessing (reference utils/dataset.py:146-168 RefDataset.__getitem__, :207-221 convert; csrc/inputpipe.hip) ----
+ * One launch per batch: img_out[b] = ((cv2.warpAffine(rgb_u8, mat, (S_w, S_h), INTER_CUBIC, borderValue=border_rgb).float()
+ * / 255 - mean) / std) as [3][S_h][S_w] (through lut_img [3][256]), mask_out[b] = cv2.warpAffine(mask_u8, mat, ...,
+ * INTER_LINEAR, borderValue=0) / 255 (through lut_mask [256]).  OpenCV's 8-bit fixed-point algorithm restated (unpinned:
+ * cv2 is not available offline).  samples_dev: DEVICE array of n descriptors; img [H][W][3] / mask [H][W] device bytes (either
+ * may be NULL); inv = destination->source matrix (cris_invert_affine of the matrix getTransformMat returns, :190-205). */
+typedef struct {
+    const unsigned char* img;
+    const unsigned char* mask;
+    int H, W;
+    double inv[6];
+} cris_sample_desc;
+typedef struct { unsigned char v[4]; } cris_u8x4;
+int cris_preprocess_batch(const cris_sample_desc* samples_dev, int n, int S_h, int S_w, const short* tab_linear, const short* tab_cubic,
+                          const float* lut_img, const float* lut_mask, const unsigned char* border_rgb /* host, 3 bytes */,
+                          float* img_out, float* mask_out, void* stream);
+/* host: inv = cv::invertAffineTransform(mat) (2x3 doubles) */
+int cris_invert_affine(const double* mat, double* inv);
+/* host: the 16-bit remap weight tables of cv::initInterTab2D(fixpt): tab_linear [1024][4], tab_cubic [1024][16] (copy to the device) */
+int cris_remap_tables_u8(short* tab_linear, short* tab_cubic);
 /* zero fill of any 16-byte aligned buffer */
 int cris_zero_bytes(void* p, size_t nbytes, void* stream);
 /* zero several byte ranges in one launch (the parts of the gradient arena that are accumulated into or only partly written:
