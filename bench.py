@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the Python schedule (no graph / command list)")
-    ap.add_argument("--launch", default=None, choices=["graph", "cmdlist", "eager"], help="default: graph on 1 GPU, cmdlist on N > 1")
+    ap.add_argument("--launch", default=None, choices=["graph", "cmdlist", "eager"], help="default: graph (N > 1: falls back to cmdlist if the capture fails on any rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     ap.add_argument("--shape-table", default=None, help="write the per-shape GEMM timing table (tsv) here")
     args = ap.parse_args()

@@ -81,6 +81,7 @@ class TorchDistComm:
         # the default group the tiny SyncBN all-reduces of the layers still in backward would queue behind 100+ MB
         # gradient messages and stall the compute stream
         self.grad_group = dist.new_group(ranks=list(range(self.world)))
+        self.capturable = dist.get_backend() == "nccl"       # RCCL kernels can be captured into a HIP graph; gloo cannot
         self.p2p, self._gen_dev, self._slot = None, None, 0
 
     def enable_p2p(self, slots, max_floats, gen_dev):

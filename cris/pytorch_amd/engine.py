@@ -93,7 +93,8 @@ class Engine:
         self.clip, self.head, self.dev = clip, head, device
         self.P, self.Bf = params, buffers
         self.comm = comm or Comm()
-        self.sync_bn = sync_bn and self.comm.world > 1
+        # (CRIS_FORCE_DIST=1: diagnostic - take the multi-rank code paths with a 1-rank communicator, tools/dist1_check.py)
+        self.sync_bn = sync_bn and (self.comm.world > 1 or os.environ.get("CRIS_FORCE_DIST", "0") == "1")
         self.tape: List[Callable[[], None]] = []
         self.training = True
         self.seed = 0

@@ -83,7 +83,11 @@ class NativeTrainer:
             if use_graph is False or os.environ.get("CRIS_NO_GRAPH", "0") == "1":
                 launch = "eager"
             else:
-                launch = "graph" if self.comm.world == 1 else "cmdlist"
+                # one captured HIP graph per step on any number of ranks: RCCL's kernels are captured like every other
+                # launch (measured with a 1-rank RCCL group, tools/dist1_check.py: 15.4 ms/step captured against 16.9 as a
+                # command list, ~145 collectives per step); a capture that fails on ANY rank makes every rank fall back
+                # to the command list (train_step).  Communicators that cannot be captured (gloo: host copies) say so.
+                launch = "graph" if getattr(self.comm, "capturable", True) else "cmdlist"
         if torch.device(device).type != "cuda":
             launch = "eager"
         assert launch in ("graph", "cmdlist", "eager"), launch
@@ -135,7 +139,7 @@ class NativeTrainer:
                 ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         else:
             ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
-        if self.comm.world > 1:
+        if self.comm.world > 1 or os.environ.get("CRIS_FORCE_DIST", "0") == "1":
             def on_stage(st):
                 lo, hi = e.stage_ranges[st]
                 ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))
@@ -172,13 +176,25 @@ class NativeTrainer:
                 s_word.copy_(word, non_blocking=True)
                 s_mask.copy_(mask, non_blocking=True)
                 return self._record(), self.metric            # this call executes the step while recording it
+            err = None
             try:
                 self._capture()
             except Exception as ex:              # noqa: BLE001 - e.g. a collective that cannot be captured
-                self.graph_error = repr(ex)
+                err = repr(ex)
+            if self.comm.world > 1:              # the ranks must agree on the launch mode
+                err = next((x for x in self.comm.all_gather_object(err) if x), None)
+            if err is not None:
+                self.graph_error, self._graph = err, None
+                torch.cuda.synchronize(self.device)
+                if self.comm.world > 1:
+                    self.launch = "cmdlist"
+                    _, s_img, s_word, s_mask = self._static
+                    s_img.copy_(img, non_blocking=True)
+                    s_word.copy_(word, non_blocking=True)
+                    s_mask.copy_(mask, non_blocking=True)
+                    return self._record(), self.metric
                 self.use_graph = False
                 self.launch = "eager"
-                torch.cuda.synchronize(self.device)
                 loss, _, _ = self._step_body(img, word, mask, None)
                 return loss, self.metric
         _, s_img, s_word, s_mask = self._static

@@ -106,3 +106,27 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(launch):
         # (a sum over ~1e5 parameters that each moved by +-lr per step: Adam's sign noise allows ~1e-2 of the sum)
         assert abs(p0[k] - ref_probe[k]) <= 1e-2 * max(1.0, abs(ref_probe[k])), (k, p0[k], ref_probe[k])
     assert abs(rm0 - rm1) < 1e-6 and abs(rm0 - ref_rm) < 1e-3 * max(1.0, abs(ref_rm))     # SyncBN: global running stats
+
+
+def test_rccl_collectives_inside_the_captured_graph():
+    """The multi-rank code paths (142 SyncBN all-reduces per step on the compute stream, 8 staged gradient all-reduces on their
+    own communicator and stream) over a ONE-rank RCCL group - the only RCCL this one-GPU box can run: the step captured into
+    a HIP graph (the default launch mode on N ranks) and the command-list replay give the same losses as plain eager launches,
+    and the capture reports no error (tools/dist1_check.py)."""
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for i, mode in enumerate(("graph", "cmdlist", "eager")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist1_check.py"), mode, "4"], env=env, stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=600)
+        out = r.stdout.decode()
+        line = [x for x in out.splitlines() if x.startswith("mode ")]
+        assert r.returncode == 0 and line, out[-2000:]
+        m = re.match(r"mode (\w+) -> launch (\w+) graph_error (.*?) \| .* losses (\[.*?\]) \.\.\. ([0-9.]+)", line[0])
+        assert m, line[0]
+        assert m.group(2) == mode and m.group(3) == "None", line[0]
+        got[mode] = (m.group(4), m.group(5))
+    assert got["graph"] == got["cmdlist"] == got["eager"], got
