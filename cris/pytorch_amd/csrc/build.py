@@ -15,6 +15,7 @@ STAMP = os.path.join(HERE, ".build_stamp")
 # backward of the text encoder (side stream) differed from run to run underneath the convolution GEMMs until its packed
 # ops were gone.  The step time is unchanged (the affected kernels are memory-bound).  packed_fp32_ops() is the check.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-fno-slp-vectorize", "-fno-vectorize"]
+FLAGS += os.environ.get("CRIS_EXTRA_HIPCC_FLAGS", "").split()      # experiments (-D switches); part of the build stamp
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 
