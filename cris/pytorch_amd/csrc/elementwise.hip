@@ -676,7 +676,9 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const bf16_t* __restri
     for (int i = threadIdx.x; i < ldwb; i += 256) part[i] = i < C * 9 + 1 ? sdw[i] : 0.f;      // padding columns: zeros
 }
 
+#ifndef DYNCONV_BWD_PPB
 #define DYNCONV_BWD_PPB 128                       // pixels per block: 85 x B blocks at 104 x 104 (was 512: 22 x B blocks, 89 us)
+#endif
 static int dynconv_bwd_blocks(int HW) { return cris_cdiv(HW, DYNCONV_BWD_PPB); }
 extern "C" long cris_dynconv_bwd_ws_floats(int Bn, int H, int W, int ldwb) { return (long)dynconv_bwd_blocks(H * W) * Bn * ldwb; }
 void cris_launch_sum_partials(const float* part, int nparts, int ncol, float* out, hipStream_t stream);      // norm.hip
@@ -816,7 +818,9 @@ extern "C" int cris_train_metric(const float* logits, const float* target, int B
 // ------------------------------------------------------------------------------------------------
 // fused multi-tensor Adam (torch.optim.Adam, non-amsgrad)
 // ------------------------------------------------------------------------------------------------
+#ifndef ADAM_ELEMS
 #define ADAM_ELEMS 8192
+#endif
 #define AP_T 64                                   // packed tensors: a block owns 64 output rows x 64 input channels x all taps
 #define AP_LROW(PT) (AP_T * (PT) + 2)             // bf16 elements per LDS tile row (+1 dword: conflict-free column reads)
 

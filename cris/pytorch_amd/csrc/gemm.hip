@@ -18,6 +18,19 @@
 #include <type_traits>
 
 #define BK 64
+// LDS-DMA ring depth per tile variant (K-steps in flight = depth - 1); -D switches for the A/B in profiles/r02_ab_experiments.md
+#ifndef ST_64x64
+#define ST_64x64 3
+#endif
+#ifndef ST_64x128
+#define ST_64x128 3
+#endif
+#ifndef ST_128x64
+#define ST_128x64 3
+#endif
+#ifndef ST_128x128
+#define ST_128x128 2
+#endif
 #define SKINNY_MAX_M 144      // M <= this and a 1x1 geometry -> skinny kernel (no LDS staging, K split over the waves)
 
 
@@ -373,7 +386,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
 // 512-B runs); fragments go straight from L2/HBM into registers (no LDS staging, no barrier in the loop), two K-chunks
 // per trip with all loads issued before the first MFMA; the partial accumulators are summed through LDS in a fixed wave
 // order (deterministic); full epilogue by wave 0.
+#ifndef SK_WAVES
 #define SK_WAVES 8
+#endif
 template <int FM>
 __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_conv_gemm_params p) {
     constexpr int FN = 2;
@@ -508,19 +523,21 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
                    "operand extent must stay below 2 GiB (32-bit buffer offsets)");
     hipStream_t s = (hipStream_t)stream;
     // <= 72 KB per block: two blocks (8 waves) share a CU's 160 KB LDS and hide each other's barriers / epilogues
-    constexpr int LDS_128x64 = 3 * (128 + 64) * 128, LDS_64x128 = 3 * (64 + 128) * 128, LDS_128x128 = 2 * (128 + 128) * 128;
-    constexpr int LDS_64x64 = 3 * (64 + 64) * 128;
+    constexpr int LDS_128x64 = ST_128x64 * (128 + 64) * 128, LDS_64x128 = ST_64x128 * (64 + 128) * 128;
+    constexpr int LDS_128x128 = ST_128x128 * (128 + 128) * 128, LDS_64x64 = ST_64x64 * (64 + 64) * 128;
     typedef void (*kern_t)(const cris_conv_gemm_params);
     // [variant][lean]
-    static const kern_t k_128x64[2] = {conv_gemm_kernel<128, 64, 4, 1, 3, false>, conv_gemm_kernel<128, 64, 4, 1, 3, true>};
-    static const kern_t k_64x128[2] = {conv_gemm_kernel<64, 128, 2, 2, 3, false>, conv_gemm_kernel<64, 128, 2, 2, 3, true>};
-    static const kern_t k_128x128[2] = {conv_gemm_kernel<128, 128, 2, 2, 2, false>, conv_gemm_kernel<128, 128, 2, 2, 2, true>};
+    static const kern_t k_128x64[2] = {conv_gemm_kernel<128, 64, 4, 1, ST_128x64, false>, conv_gemm_kernel<128, 64, 4, 1, ST_128x64, true>};
+    static const kern_t k_64x128[2] = {conv_gemm_kernel<64, 128, 2, 2, ST_64x128, false>, conv_gemm_kernel<64, 128, 2, 2, ST_64x128, true>};
+    static const kern_t k_128x128[2] = {conv_gemm_kernel<128, 128, 2, 2, ST_128x128, false>,
+                                        conv_gemm_kernel<128, 128, 2, 2, ST_128x128, true>};
     // (measured alternatives for this variant: 16x16x32 MFMA with four accumulators 19.50 vs 19.39 ms/step, a 2-stage ring
     // with 5 blocks per CU 20.00 ms/step - neither helps)
-    static const kern_t k_64x64[2] = {conv_gemm_kernel<64, 64, 2, 2, 3, false>, conv_gemm_kernel<64, 64, 2, 2, 3, true>};
+    static const kern_t k_64x64[2] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64, false>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, true>};
     static const int lds_ready = set_lds((const void*)k_128x64[0], LDS_128x64) | set_lds((const void*)k_128x64[1], LDS_128x64) |
                                  set_lds((const void*)k_64x128[0], LDS_64x128) | set_lds((const void*)k_64x128[1], LDS_64x128) |
-                                 set_lds((const void*)k_128x128[0], LDS_128x128) | set_lds((const void*)k_128x128[1], LDS_128x128);
+                                 set_lds((const void*)k_128x128[0], LDS_128x128) | set_lds((const void*)k_128x128[1], LDS_128x128) |
+                                 set_lds((const void*)k_64x64[0], LDS_64x64) | set_lds((const void*)k_64x64[1], LDS_64x64);
     if (lds_ready != 0) {
         cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, lds_ready);
         return lds_ready;

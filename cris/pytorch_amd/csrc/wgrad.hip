@@ -26,7 +26,9 @@
 #define WG_MS 32          // pixel rows per pipeline step
 #define WG_STAGES 3       // ring depth: 3 x 2 x 32 x 256 B = 48 KB LDS -> 3 blocks per CU
 #define WG_LDS (WG_STAGES * 2 * WG_MS * 256)
+#ifndef WG_RUN
 #define WG_RUN 8          // consecutive tiles handed to one XCD (they share the dY tile)
+#endif
 
 typedef __attribute__((ext_vector_type(4))) short wg_s16x4;
 typedef __attribute__((ext_vector_type(8))) short wg_s16x8;
