@@ -163,6 +163,7 @@ KERNEL_TIMER = None
 
 _WGRAD_BLOCKS = int(os.environ.get("CRIS_WGRAD_BLOCKS", "512"))      # launch-geometry knobs (never change results)
 _WGRAD_GROUP_M = int(os.environ.get("CRIS_WGRAD_GROUP_M", "8192"))    # problems up to this many pixel rows are queued
+_WGRAD_MIN_STEPS = int(os.environ.get("CRIS_WGRAD_MIN_STEPS", "8"))    # 128-row steps per split at least
 _WGRAD_FLUSH_BLOCKS = int(os.environ.get("CRIS_WGRAD_FLUSH_BLOCKS", "3072"))
 
 
@@ -172,7 +173,7 @@ def wgrad_splits(M: int, N: int, K: int) -> int:
     tiles = ((N + 127) // 128) * ((K + 127) // 128)
     steps = (M + 127) // 128
     want = max(1, (_WGRAD_BLOCKS + tiles // 2) // tiles)
-    return max(1, min(want, (steps + 7) // 8, 256))
+    return max(1, min(want, (steps + _WGRAD_MIN_STEPS - 1) // _WGRAD_MIN_STEPS, 256))
 
 
 def _wgrad_params(dY, X, g: Geom, N: int, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, splits, dbias):
