@@ -62,7 +62,7 @@ def cpu_baseline(spec, batch, size, word_len, threads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--spec", default="r50")
     ap.add_argument("--size", type=int, default=416)
