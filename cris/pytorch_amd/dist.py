@@ -130,6 +130,84 @@ class TorchDistComm:
             torch.cuda.current_stream().wait_stream(self.side)
 
 
+class RcclComm:
+    """The same exchanges on communicators the LIBRARY owns (csrc/comm.hip, include/cris_hip.h cris_comm_*): RCCL called from
+    libcris_hip.so, no torch.distributed process group on the data path.  `store`: any c10d Store (TCPStore / FileStore /
+    HashStore for one rank) - host-side bootstrap only: it carries rank 0's RCCL ids to the other ranks and the few host
+    objects the trainer gathers (batch-size check, graph-capture agreement).  Interface = TorchDistComm's, so
+    NativeTrainer(comm=RcclComm(...)) is the only change; all calls enqueue on HIP streams and are captured into the step's
+    graph like every other launch.
+
+        store = torch.distributed.TCPStore("127.0.0.1", port, world, is_master=(rank == 0))
+        comm = RcclComm(rank, world, torch.device("cuda", local_rank), store)
+    """
+    capturable = True
+
+    def __init__(self, rank, world, device, store, prefix="cris_comm"):
+        from . import hip
+        self.hip, self.lib = hip, hip.load()
+        self.rank, self.world, self.device, self.store, self.prefix = rank, world, device, store, prefix
+        torch.cuda.set_device(device)                      # cris_comm_init binds to the current device
+        nbytes = 256                                       # CRIS_COMM_ID_BYTES
+        key = prefix + "/id"
+        if rank == 0:
+            buf = (ctypes.c_ubyte * nbytes)()
+            hip.check(self.lib.cris_comm_unique_id(buf), "cris_comm_unique_id")
+            store.set(key, bytes(buf))
+        ids = bytes(store.get(key))
+        assert len(ids) == nbytes
+        handle = ctypes.c_void_p()
+        hip.check(self.lib.cris_comm_init(rank, world, (ctypes.c_ubyte * nbytes).from_buffer_copy(ids), ctypes.byref(handle)),
+                  "cris_comm_init")
+        self.handle = handle
+        self._gathers = 0
+        self.p2p = None
+
+    def rccl_path(self):
+        p = self.lib.cris_comm_rccl_path()
+        return p.decode() if p else None
+
+    def begin_step(self):
+        return
+
+    # --- SyncBN exchanges: inline on the compute stream ---
+    def allreduce_sum(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self.hip.check(self.lib.cris_comm_syncbn_exchange(self.handle, t.data_ptr(), t.numel(),
+                                                          torch.cuda.current_stream().cuda_stream), "cris_comm_syncbn_exchange")
+
+    def allreduce_sum_op(self, t):
+        return lambda: self.allreduce_sum(t)
+
+    # --- gradient exchange: own communicator + side stream inside the library ---
+    def allreduce_async(self, t):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        self.hip.check(self.lib.cris_comm_allreduce_bucket(self.handle, t.data_ptr(), t.numel(),
+                                                           torch.cuda.current_stream().cuda_stream), "cris_comm_allreduce_bucket")
+
+    def wait_all(self):
+        self.hip.check(self.lib.cris_comm_wait(self.handle, torch.cuda.current_stream().cuda_stream), "cris_comm_wait")
+
+    def broadcast(self, t, src=0):
+        assert t.is_contiguous()
+        self.hip.check(self.lib.cris_comm_broadcast(self.handle, t.data_ptr(), t.numel() * t.element_size(), src,
+                                                    torch.cuda.current_stream().cuda_stream), "cris_comm_broadcast")
+
+    # --- host objects (set-up time only) through the store ---
+    def all_gather_object(self, obj):
+        import pickle
+        n = self._gathers
+        self._gathers += 1
+        self.store.set("%s/g%d/%d" % (self.prefix, n, self.rank), pickle.dumps(obj))
+        return [pickle.loads(bytes(self.store.get("%s/g%d/%d" % (self.prefix, n, q)))) for q in range(self.world)]
+
+    def close(self):
+        if self.handle:
+            torch.cuda.synchronize(self.device)
+            self.lib.cris_comm_destroy(self.handle)
+            self.handle = None
+
+
 def merge_batchnorm_partials(sum_l, m2_l, n_l, comm, ref=None):
     """Reference arithmetic of the SyncBN forward exchange on plain tensors (used by the CPU/gloo tests): local
     (sum, M2 about the local mean, count) -> global (mean, biased var) with ONE all-reduce of the moments about `ref`

@@ -269,6 +269,16 @@ _SIGS = {
     "cris_p2p_import": (I, [P, P]),
     "cris_p2p_close": (I, [P]),
     "cris_p2p_allreduce_sum": (I, [P, P]),
+    "cris_comm_rccl_path": (C.c_char_p, []),
+    "cris_comm_unique_id": (I, [P]),
+    "cris_comm_init": (I, [I, I, P, P]),
+    "cris_comm_destroy": (I, [P]),
+    "cris_comm_rank": (I, [P]),
+    "cris_comm_world": (I, [P]),
+    "cris_comm_syncbn_exchange": (I, [P, P, C.c_size_t, P]),
+    "cris_comm_allreduce_bucket": (I, [P, P, C.c_size_t, P]),
+    "cris_comm_wait": (I, [P, P]),
+    "cris_comm_broadcast": (I, [P, P, C.c_size_t, I, P]),
 }
 EXPORTS = sorted(_SIGS)
 

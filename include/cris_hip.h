@@ -425,6 +425,35 @@ typedef struct {
 } cris_p2p_params;
 int cris_p2p_allreduce_sum(const cris_p2p_params* p, void* stream);
 
+/* ---- Data-parallel exchanges on library-owned RCCL communicators (csrc/comm.hip) ---------------------------------------
+ * What the reference gets from `dist.init_process_group("nccl")` + `DistributedDataParallel` + `SyncBatchNorm`
+ * (train.py:80-102; SURVEY.md 8b "comm entry points"), without torch.distributed on the data path.  One cris_comm per
+ * process (= per GPU, the device current at cris_comm_init).  RCCL is resolved at run time (the librccl.so.1 already in the
+ * process, else the system one; CRIS_RCCL_LIB overrides): the library does not link against it.
+ *   bootstrap:  rank 0 calls cris_comm_unique_id and ships the CRIS_COMM_ID_BYTES bytes to the other ranks by any host
+ *               channel (a c10d Store, a file, MPI); every rank then calls cris_comm_init (collective).
+ *   SyncBN:     cris_comm_syncbn_exchange - in-place fp32 sum over ranks on the CALLER's stream (replaces the all_gather of
+ *               (mean, invstd, count) / the all_reduce of (sum_dy, sum_dy_xmu) in torch.nn.SyncBatchNorm).
+ *   gradients:  cris_comm_allreduce_bucket - in-place fp32 sum of one range of the gradient arena on the communicator's OWN
+ *               side stream and OWN RCCL communicator, after everything `ready_stream` has queued so far (replaces DDP's
+ *               bucketed all-reduce; the caller chooses few large ranges: xGMI is per-link bound); cris_comm_wait makes
+ *               `stream` wait for every range issued since the last wait (before the optimizer).  Averaging (1/world) is
+ *               left to the optimizer's grad_scale.
+ *   start-up:   cris_comm_broadcast - rank root's bytes to all ranks (DDP broadcasts parameters and buffers when it wraps).
+ * All calls enqueue on streams and return; they can be captured into a HIP graph together with the step's kernels. */
+#define CRIS_COMM_ID_BYTES 256                 /* two ncclUniqueId: the statistics and the gradient communicator */
+typedef struct cris_comm cris_comm;
+const char* cris_comm_rccl_path(void);         /* which RCCL was resolved (NULL + cris_last_error() if none) */
+int cris_comm_unique_id(void* id_bytes);
+int cris_comm_init(int rank, int world, const void* id_bytes, cris_comm** out);
+int cris_comm_destroy(cris_comm* c);
+int cris_comm_rank(const cris_comm* c);
+int cris_comm_world(const cris_comm* c);
+int cris_comm_syncbn_exchange(cris_comm* c, float* stats, size_t n, void* stream);
+int cris_comm_allreduce_bucket(cris_comm* c, float* buf, size_t n, void* ready_stream);
+int cris_comm_wait(cris_comm* c, void* stream);
+int cris_comm_broadcast(cris_comm* c, void* buf, size_t nbytes, int root, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

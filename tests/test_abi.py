@@ -106,3 +106,22 @@ def test_no_packed_fp32_valu_instructions():
     if found is None:
         pytest.skip("llvm-objdump not available")
     assert found == {}, found
+
+
+def test_comm_entry_points_resolve_rccl_and_fail_loudly_without_a_gpu(lib):
+    """cris_comm_*: RCCL is resolved at run time (no link-time dependency: `ldd` must not list it); without a device the
+    communicator cannot be created and says why."""
+    import torch
+    hip, l = lib
+    deps = subprocess.check_output(["ldd", hip.LIB_PATH]).decode()
+    assert "rccl" not in deps
+    path = l.cris_comm_rccl_path()
+    assert path, l.cris_last_error()
+    buf = (C.c_ubyte * 256)()
+    assert l.cris_comm_unique_id(buf) == 0, l.cris_last_error()
+    assert any(buf[:128]) and any(buf[128:]) and bytes(buf[:128]) != bytes(buf[128:])     # two distinct communicator ids
+    if not torch.cuda.is_available():
+        h = C.c_void_p()
+        assert l.cris_comm_init(0, 1, buf, C.byref(h)) != 0
+        assert b"cris_comm_init" in l.cris_last_error()
+    assert l.cris_comm_init(3, 2, buf, None) != 0                                         # bad arguments are rejected

@@ -1,0 +1,35 @@
+"""Library-owned RCCL communicators (include/cris_hip.h cris_comm_*, csrc/comm.hip, dist.RcclComm) on the GPU: run in a child
+process with a time limit (tools/comm1_check.py) so that a misbehaving RCCL bootstrap cannot take the rest of the suite with
+it.  One rank (the test box has one GPU): the exchanges are identities - checked are the resolution of RCCL from inside the
+library, stream ordering of the side-stream gradient exchange, the trainer's multi-rank code paths on it (SyncBN single
+exchange, staged gradient all-reduce, broadcast at construction) and the capture of the whole step, RCCL kernels included,
+into one HIP graph."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_rccl_comm_one_rank_trainer_and_graph_capture():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "comm1_check.py"), "tiny", "6"], env=env, cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+    text = r.stdout.decode()
+    line = next((ln for ln in text.splitlines() if ln.startswith("COMM1 ")), None)
+    assert r.returncode == 0 and line is not None, text[-3000:]
+    out = json.loads(line[6:])
+    print(out)
+    assert out["rccl"] and out["primitives_ok"] and out["gather"] and out["sync_bn"]
+    assert out["launch"] == "graph" and out["graph_error"] is None          # RCCL's kernels were captured with the step
+    assert out["losses_graph"] == out["losses_eager"]                       # same schedule, replayed or launched one by one
+    # SyncBN's single exchange takes the moments about the running mean instead of the batch mean: same statistics, another
+    # summation order - the losses of the plain single-GPU path agree to rounding
+    for a, b in zip(out["losses_graph"], out["losses_local"]):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), (out["losses_graph"], out["losses_local"])
