@@ -101,6 +101,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 if (has_drop) x = cris_keep(dkey, (uint32_t)m * (uint32_t)p.N + (uint32_t)col, dthr) ? x * dscale : 0.f;
                 const bool valid = cvalid && m < p.M;
                 x += rres[r];
+                if (act == 3) x = fmaxf(x, 0.f);
                 if (!valid) x = 0.f;
                 v[r] = x;
                 vals[ig][r] = x;
@@ -595,6 +596,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const cris_pack_desc*
             const int n = (int)(r / d.taps);
             float v = 0.f;
             if (c < d.Cin) v = d.src_transposed ? d.src[(size_t)c * d.N + n] : d.src[((size_t)n * d.Cin + c) * d.taps + tap];
+            if (d.row_scale) v *= d.row_scale[n];
             d.dstF[i] = f2bf(v);
         }
     } else {
@@ -611,11 +613,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const cris_pack_desc*
             float v = 0.f;
             if (d.src_transposed) {                                    // src[c][n]: read along n
                 const int c = ct * 64 + rr, n = nt * 64 + tx;
-                if (c < d.Cin && n < d.N) v = d.src[(size_t)c * d.N + n];
+                if (c < d.Cin && n < d.N) v = d.src[(size_t)c * d.N + n] * (d.row_scale ? d.row_scale[n] : 1.f);
                 tile[tx][rr] = v;                                      // tile[n][c]
             } else {                                                   // src[n][c][tap]: read along c
                 const int n = nt * 64 + rr, c = ct * 64 + tx;
-                if (n < d.N && c < d.Cin) v = d.src[((size_t)n * d.Cin + c) * d.taps + tap];
+                if (n < d.N && c < d.Cin) v = d.src[((size_t)n * d.Cin + c) * d.taps + tap] * (d.row_scale ? d.row_scale[n] : 1.f);
                 tile[rr][tx] = v;
             }
         }

@@ -50,7 +50,7 @@ class WgradGroup(C.Structure):
 
 
 class PackDesc(C.Structure):
-    _fields_ = [("src", P), ("dstF", P), ("dstD", P),
+    _fields_ = [("src", P), ("dstF", P), ("dstD", P), ("row_scale", P),
                 ("N", I), ("Cin", I), ("taps", I), ("Cpad", I), ("Npad", I), ("src_transposed", I),
                 ("block_start", I), ("pad_", I)]
 

@@ -263,16 +263,16 @@ class PackTable:
         self.dev = None
         self.total_blocks = 0
 
-    def add(self, src, N, Cin, taps, Cpad=None, Npad=None, want_F=True, want_D=True, src_transposed=False):
+    def add(self, src, N, Cin, taps, Cpad=None, Npad=None, want_F=True, want_D=True, src_transposed=False, row_scale=None):
         Cpad = Cpad if Cpad is not None else pad8(Cin)
         Npad = Npad if Npad is not None else pad8(N)
         dstF = torch.zeros(N, taps * Cpad, dtype=BF16, device=src.device) if want_F else None
         dstD = torch.zeros(Cin, taps * Npad, dtype=BF16, device=src.device) if want_D else None
         d = hip.PackDesc()
-        d.src, d.dstF, d.dstD = ptr(src), ptr(dstF), ptr(dstD)
+        d.src, d.dstF, d.dstD, d.row_scale = ptr(src), ptr(dstF), ptr(dstD), ptr(row_scale)
         d.N, d.Cin, d.taps, d.Cpad, d.Npad, d.src_transposed = N, Cin, taps, Cpad, Npad, int(src_transposed)
         self.descs.append(d)
-        self.keep.append((src, dstF, dstD))
+        self.keep.append((src, dstF, dstD, row_scale))
         self.info.append((dstF, dstD, N, Cin, taps, Cpad, Npad, bool(src_transposed)))
         self.dev = None
         return dstF, dstD

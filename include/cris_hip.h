@@ -54,7 +54,8 @@ typedef struct {
     int OH, OW, KH, KW, stride, pad;
     int ldb;
     int M, N, K;
-    int act;                 /* 0 none, 1 relu, 2 QuickGELU x*sigmoid(1.702x) (model/clip.py:234-236) */
+    int act;                 /* 0 none, 1 relu, 2 QuickGELU x*sigmoid(1.702x) (model/clip.py:234-236); 3 relu applied AFTER the
+                              * residual add (Bottleneck tail `out += identity; relu` model/clip.py:55-56 with the BatchNorm folded) */
     int ldr, r_coff, resid_f32;
     int ldc, c_coff, out_f32;
     int T_L, T_Lpad, T_E;    /* outT[sec][(b*(T_E/64)+h)*64+d][l], m = b*T_L + l, n = sec*T_E + h*64 + d */
@@ -109,6 +110,8 @@ typedef struct {
     const float* src;        /* [N][Cin][taps]  (or [Cin][N] when src_transposed, taps == 1) */
     cris_bf16* dstF;         /* or NULL */
     cris_bf16* dstD;         /* or NULL */
+    const float* row_scale;  /* or NULL; [N]: output row n is multiplied by row_scale[n] before rounding - an inference-time
+                              * BatchNorm folded into its convolution (gamma / sqrt(running_var + eps), cris_bn_eval_coeffs) */
     int N, Cin, taps, Cpad, Npad, src_transposed;
     int block_start;         /* first block of this tensor in the launch grid (prefix sum) */
     int pad_;
