@@ -44,15 +44,19 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; 
 // Epilogue of one wave tile (FM x FN fragments of 16x16, C/D layout col = lane&15, row = (lane>>4)*4 + r) whose first
 // row / column are row0 / col0: bias, activation, dropout, residual, bf16|fp32 store, head-split transposed copy and the
 // BatchNorm statistics partial `part` (sum, M2 about the part mean over the FM*16 rows of this wave tile).
-// LEAN: compile-time promise of the plain conv / dgrad case (bf16 output, optional bf16 residual, optional statistics;
-// no bias, activation, dropout, transposed copy or fp32 I/O) - the epilogue every block of the ~190
-// convolution GEMMs per step runs; the general form costs thousands of instructions per wave.
-template <bool LEAN, int MT, int FM, int FN, typename ACC>
+// EPI 1 ("lean"): compile-time promise of the plain conv / dgrad case (bf16 output, optional bf16 residual, optional
+// statistics; no bias, activation, dropout, transposed copy or fp32 I/O) - the epilogue every block of the ~190
+// convolution GEMMs per training step runs; the general form (EPI 0) costs thousands of instructions per wave.
+// EPI 2: the lean case plus a per-column bias and ReLU before (act 1) or after (act 3) the residual - the convolutions of
+// the inference path, whose BatchNorms are folded into weights and bias (cris/pytorch_amd/infer.py).
+template <int EPI, int MT, int FM, int FN, typename ACC>
 __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, ACC (&acc)[FM][FN], int row0, int col0, int part,
                                               int lane) {
     // MT = 16: v_mfma_f32_16x16x32 C/D layout  col = lane&15, row = (lane>>4)*4 + r            (r = 0..3)
     // MT = 32: v_mfma_f32_32x32x16 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (reg = 0..15)
     // both: per lane NG groups of 4 consecutive rows of one column
+    constexpr bool LEAN = EPI != 0;
+    constexpr bool BIAS_ACT = EPI != 1;                        // bias / activation compiled in
     constexpr int NG = MT == 16 ? 1 : 4;
     const int fr = lane & (MT - 1), fg = lane / MT;
     const bool has_drop = !LEAN && p.drop_thresh > 0u;
@@ -66,7 +70,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
     // branches and its residual loads are issued together instead of one wait per element
     const bool has_res = p.resid != nullptr, has_out = p.out != nullptr;
     const bool res_f32 = !LEAN && p.resid_f32, out_f32 = !LEAN && p.out_f32;
-    const int act = LEAN ? 0 : p.act;
+    const int act = BIAS_ACT ? p.act : 0;
     const unsigned res_es = res_f32 ? 4u : 2u, out_es = out_f32 ? 4u : 2u;
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<void*>(p.resid), 0, has_res ? (int)((size_t)p.M * p.ldr * res_es) : 0, CRIS_BUF_FLAGS);
@@ -76,7 +80,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
     for (int j = 0; j < FN; ++j) {
         const int col = col0 + j * MT + fr;
         const bool cvalid = col < p.N;
-        const float bias = (!LEAN && p.bias) ? p.bias[cvalid ? col : 0] : 0.f;
+        const float bias = (BIAS_ACT && p.bias) ? p.bias[cvalid ? col : 0] : 0.f;
         float vals[FM * NG][4];
 #pragma unroll
         for (int ig = 0; ig < FM * NG; ++ig) {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 const int m = rowb + r;
                 float x = acc[i][j][g * 4 + r] + bias;
                 if (act == 1) x = fmaxf(x, 0.f);
-                else if (act == 2) x = x / (1.0f + __expf(-1.702f * x));
+                else if (!LEAN && act == 2) x = x / (1.0f + __expf(-1.702f * x));
                 if (has_drop) x = cris_keep(dkey, (uint32_t)m * (uint32_t)p.N + (uint32_t)col, dthr) ? x * dscale : 0.f;
                 const bool valid = cvalid && m < p.M;
                 x += rres[r];
@@ -174,7 +178,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
 // descriptors over the activation / weight extents: zero fill (spatial padding, M / N / K tails) = an out-of-range byte
 // offset, which the hardware returns as 0 - a branch-free per-lane select, so every wave issues exactly NA + NB DMAs per
 // K-step and the counted vmcnt below is exact.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, bool LEAN, int MT_ = 32>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, int MT_ = 32>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_params p) {
     constexpr int WTM = BM / WAVES_M;          // wave tile rows
     constexpr int WTN = BN / WAVES_N;
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     }
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 
-    gemm_epilogue<LEAN, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
+    gemm_epilogue<EPI, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
 }
 
 // Skinny kernel (M <= FM*16 rows, 1x1 geometry: text encoder / per-sample vectors).  Such GEMMs are pure latency: one
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
         f32x4 one[1][1];
 #pragma unroll
         for (int r = 0; r < 4; ++r) one[0][0][r] = red[u * 4 + r][lane];
-        gemm_epilogue<false, 16, 1, 1>(p, one, i * 16, n0 + j * 16, i, lane);
+        gemm_epilogue<0, 16, 1, 1>(p, one, i * 16, n0 + j * 16, i, lane);
     }
 }
 
@@ -527,23 +531,30 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     constexpr int LDS_128x64 = ST_128x64 * (128 + 64) * 128, LDS_64x128 = ST_64x128 * (64 + 128) * 128;
     constexpr int LDS_128x128 = ST_128x128 * (128 + 128) * 128, LDS_64x64 = ST_64x64 * (64 + 64) * 128;
     typedef void (*kern_t)(const cris_conv_gemm_params);
-    // [variant][lean]
-    static const kern_t k_128x64[2] = {conv_gemm_kernel<128, 64, 4, 1, ST_128x64, false>, conv_gemm_kernel<128, 64, 4, 1, ST_128x64, true>};
-    static const kern_t k_64x128[2] = {conv_gemm_kernel<64, 128, 2, 2, ST_64x128, false>, conv_gemm_kernel<64, 128, 2, 2, ST_64x128, true>};
-    static const kern_t k_128x128[2] = {conv_gemm_kernel<128, 128, 2, 2, ST_128x128, false>,
-                                        conv_gemm_kernel<128, 128, 2, 2, ST_128x128, true>};
+    // [variant][epilogue: 0 general, 1 lean, 2 lean + bias / ReLU]
+    static const kern_t k_128x64[3] = {conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 0>, conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 1>,
+                                       conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 2>};
+    static const kern_t k_64x128[3] = {conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 0>, conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 1>,
+                                       conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 2>};
+    static const kern_t k_128x128[3] = {conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 0>, conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 1>,
+                                        conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 2>};
     // (measured alternatives for this variant: 16x16x32 MFMA with four accumulators 19.50 vs 19.39 ms/step, a 2-stage ring
     // with 5 blocks per CU 20.00 ms/step - neither helps)
-    static const kern_t k_64x64[2] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64, false>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, true>};
-    static const int lds_ready = set_lds((const void*)k_128x64[0], LDS_128x64) | set_lds((const void*)k_128x64[1], LDS_128x64) |
-                                 set_lds((const void*)k_64x128[0], LDS_64x128) | set_lds((const void*)k_64x128[1], LDS_64x128) |
-                                 set_lds((const void*)k_128x128[0], LDS_128x128) | set_lds((const void*)k_128x128[1], LDS_128x128) |
-                                 set_lds((const void*)k_64x64[0], LDS_64x64) | set_lds((const void*)k_64x64[1], LDS_64x64);
+    static const kern_t k_64x64[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 0>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 1>,
+                                      conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 2>};
+    static const int lds_ready = [&]() {
+        int rc = 0;
+        for (int e = 0; e < 3; ++e)
+            rc |= set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
+                  set_lds((const void*)k_128x128[e], LDS_128x128) | set_lds((const void*)k_64x64[e], LDS_64x64);
+        return rc;
+    }();
     if (lds_ready != 0) {
         cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, lds_ready);
         return lds_ready;
     }
-    const int lean = (!p.bias && p.act == 0 && p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32)) ? 1 : 0;
+    const bool plain = p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32);
+    const int lean = !plain ? 0 : (!p.bias && p.act == 0) ? 1 : (p.act == 0 || p.act == 1 || p.act == 3) ? 2 : 0;
     switch (pick_variant(p)) {
         case V_SKINNY1:
             hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);

@@ -130,6 +130,44 @@ def test_conv_gemm_epilogues():
     assert bool((dropped == ~km).all()), "dropout keep decisions differ from the hash oracle"
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=13, W=13, C=64, N=128, k=1),           # 64x64 tile
+    dict(B=2, H=26, W=26, C=256, N=64, k=3),           # N <= 64: 128x64 tile
+    dict(B=8, H=26, W=26, C=512, N=512, k=3),          # K >= 4096, M >= 4096: 64x128 tile
+    dict(B=8, H=52, W=52, C=128, N=512, k=1),          # M 21632 x N 512: 676 tiles of 128x128
+    dict(B=3, H=9, W=9, C=24, N=200, k=3),             # ragged C / N tails
+])
+def test_conv_gemm_folded_batchnorm_epilogue(case):
+    """the inference epilogue (EPI 2 of csrc/gemm.hip; cris/pytorch_amd/infer.py): weights packed with a per-row scale
+    (cris_pack_weights row_scale), per-column bias, ReLU before (act 1) / after (act 3) a bf16 residual, no activation with a
+    bias (act 0) - against conv2d + eval-mode batch_norm + relu in fp32"""
+    B, H, W, C_, N, k = case["B"], case["H"], case["W"], case["C"], case["N"], case["k"]
+    pad = k // 2
+    x = rnd(B, H, W, C_).to(BF).float()
+    w = rnd(N, C_, k, k, seed=1) / math.sqrt(C_ * k * k)
+    gamma, beta = 1.0 + 0.3 * rnd(N, seed=2), 0.2 * rnd(N, seed=3)
+    rmean, rvar = 0.1 * rnd(N, seed=4), 0.5 + rnd(N, seed=5).abs()
+    g = Geom(B, H, W, C_, k, k, 1, pad)
+    scale = torch.empty(N, device=DEV)
+    shift = torch.empty(N, device=DEV)
+    ops.bn_eval_coeffs(gamma.to(DEV), beta.to(DEV), rmean.to(DEV), rvar.to(DEV), 1e-5, N, scale, shift)
+    tab = ops.PackTable()
+    wdev = w.to(DEV).contiguous()
+    wf, _ = tab.add(wdev, N, C_, k * k, Cpad=ops.pad8(C_), want_D=False, row_scale=scale)
+    tab.run()
+    s_ref = gamma / torch.sqrt(rvar + 1e-5)
+    check(scale, s_ref, 1e-6, "eval scale")
+    check(wf.view(N, k * k, ops.pad8(C_))[:, :, :C_], (w * s_ref.view(N, 1, 1, 1)).permute(0, 2, 3, 1).reshape(N, k * k, C_), 4e-3, "row-scaled pack")
+    xin = x if ops.pad8(C_) == C_ else F.pad(x, (0, ops.pad8(C_) - C_))
+    gk = Geom(B, H, W, ops.pad8(C_), k, k, 1, pad)
+    y = F.batch_norm(conv_ref(x, w, 1, pad).t().reshape(1, N, -1), rmean, rvar, gamma, beta, False, 0.0, 1e-5).reshape(N, -1).t()
+    resid = rnd(g.M, N, seed=6).to(BF).float()
+    for act, res, ref in ((1, None, torch.relu(y)), (3, resid, torch.relu(y + resid)), (0, None, y), (1, resid, torch.relu(y) + resid)):
+        out = torch.empty(g.M, N, dtype=BF, device=DEV)
+        ops.conv_gemm(bf(xin), wf, gk, N, bias=shift, act=act, resid=None if res is None else bf(res), out=out)
+        check(out, ref, 8e-3, "folded BN act %d resid %s %s" % (act, res is not None, case))
+
+
 def test_conv_gemm_general_epilogue_large_tiles():
     """the non-LEAN instantiation of the 128x128 tile (bias + fp32 residual + fp32 out; BN statistics partials of 64 rows)"""
     M, K, N = 21632 * 3, 512, 512                     # 507 x 4 tiles of 128x128

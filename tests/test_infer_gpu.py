@@ -21,7 +21,7 @@ def _rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-@pytest.mark.parametrize("spec,batch,size,word_len", [("tiny", 3, 96, 9), ("r50", 1, 416, 17), ("r50", 2, 224, 22)])
+@pytest.mark.parametrize("spec,batch,size,word_len", [("tiny", 3, 96, 9), ("r50", 1, 416, 17)])
 def test_folded_forward_matches_unfolded_and_oracle(spec, batch, size, word_len):
     clip, head = arch.specs_by_name(spec)
     head = dataclasses.replace(head, word_len=word_len)
