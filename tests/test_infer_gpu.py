@@ -40,7 +40,9 @@ def test_folded_forward_matches_unfolded_and_oracle(spec, batch, size, word_len)
     assert a.shape == ref.shape == (batch, 1, size // 4, size // 4)
     ef, ep, eo = _rel(a.cpu(), b.cpu()), _rel(b.cpu(), ref), _rel(a.cpu(), ref)
     print("folded vs unfolded %.3e | unfolded vs oracle %.3e | folded vs oracle %.3e" % (ef, ep, eo))
-    assert ef < 2e-2 and eo < 3e-2, (ef, ep, eo)
+    # measured (call AB): tiny 5.9e-3 / 8.6e-3 / 7.3e-3; R50 416x416 batch 1: 1.9e-2 / 1.7e-2 / 9.2e-3 (the two HIP paths sit on
+    # different sides of the oracle; results are bit-reproducible, so these are fixed numbers, not noise margins)
+    assert ef < 3e-2 and eo < 2e-2, (ef, ep, eo)
 
 
 def test_graph_replay_equals_eager_and_upsample_is_fused():
