@@ -33,6 +33,8 @@ extern "C" int cris_sizeof(const char* name) {
     S(cris_p2p_params);
     S(cris_zero_ranges);
     S(cris_sample_desc);
+    S(cris_jpeg_info);
+    S(cris_jpeg_image);
 #undef S
     return -1;
 }

@@ -172,6 +172,19 @@ class SampleDesc(C.Structure):
     _fields_ = [("img", P), ("mask", P), ("H", I), ("W", I), ("inv", C.c_double * 6)]
 
 
+class JpegInfo(C.Structure):
+    _fields_ = [("width", I), ("height", I), ("ncomp", I), ("hmax", I), ("vmax", I), ("mcus_x", I), ("mcus_y", I),
+                ("restart_interval", I),
+                ("comp_h", I * 3), ("comp_v", I * 3), ("blocks_w", I * 3), ("blocks_h", I * 3), ("down_w", I * 3), ("down_h", I * 3),
+                ("quant", (C.c_ushort * 64) * 3),
+                ("coef_offset", L * 3), ("coef_count", L), ("plane_offset", L * 3), ("plane_bytes", L), ("scan_offset", L),
+                ("total_blocks", I), ("pad_", I)]
+
+
+class JpegImage(C.Structure):
+    _fields_ = [("coef", P), ("planes", P), ("rgb", P), ("info", JpegInfo)]
+
+
 class P2PParams(C.Structure):
     _fields_ = [("data", P), ("boxes", P), ("gen_dev", P), ("err", P),
                 ("n", I), ("rank", I), ("world", I),
@@ -185,7 +198,7 @@ STRUCTS = {
     "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_wgrad_group": WgradGroup, "cris_pack_desc": PackDesc,
     "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
     "cris_ln_bwd_params": LnBwdParams, "cris_sum_entry": SumEntry, "cris_sum_group": SumGroup, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams, "cris_zero_ranges": ZeroRanges,
-    "cris_sample_desc": SampleDesc,
+    "cris_sample_desc": SampleDesc, "cris_jpeg_info": JpegInfo, "cris_jpeg_image": JpegImage,
 }
 
 # name -> (restype, argtypes); struct launchers take (struct*, stream)
@@ -269,6 +282,10 @@ _SIGS = {
     "cris_p2p_import": (I, [P, P]),
     "cris_p2p_close": (I, [P]),
     "cris_p2p_allreduce_sum": (I, [P, P]),
+    "cris_jpeg_read_header": (I, [P, C.c_size_t, P]),
+    "cris_jpeg_decode_coefficients": (I, [P, C.c_size_t, P, P]),
+    "cris_jpeg_decode_coefficients_batch": (I, [I, P, P, P, P, I]),
+    "cris_jpeg_reconstruct": (I, [P, I, I, L, P]),
     "cris_comm_rccl_path": (C.c_char_p, []),
     "cris_comm_unique_id": (I, [P]),
     "cris_comm_init": (I, [I, I, P, P]),

@@ -15,6 +15,7 @@
  */
 #ifndef CRIS_HIP_H
 #define CRIS_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -456,6 +457,47 @@ int cris_comm_syncbn_exchange(cris_comm* c, float* stats, size_t n, void* stream
 int cris_comm_allreduce_bucket(cris_comm* c, float* buf, size_t n, void* ready_stream);
 int cris_comm_wait(cris_comm* c, void* stream);
 int cris_comm_broadcast(cris_comm* c, void* buf, size_t nbytes, int root, void* stream);
+
+/* ---- Baseline JPEG decoding (csrc/jpeg.hip) -------------------------------------------------------------
+ * Replaces `cv2.imdecode(np.frombuffer(ref['img'], np.uint8), cv2.IMREAD_COLOR)` + `cv2.cvtColor(.., COLOR_BGR2RGB)` of the
+ * reference's loader (utils/dataset.py:127-129) for the files its LMDB records hold (tools/folder2lmdb.py:50-56 stores the raw
+ * JPEG bytes): 8-bit baseline sequential Huffman JPEG, one interleaved scan, gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart
+ * intervals.  Hybrid split, as the bit-serial part does not parallelise inside an image:
+ *   host   cris_jpeg_read_header, cris_jpeg_decode_coefficients(_batch): marker parsing + Huffman decoding (T.81 Annex F) into
+ *          quantised coefficient blocks int16 [component][block row][block col][64] (natural order), one image per thread;
+ *   device cris_jpeg_reconstruct: dequantisation + libjpeg's islow inverse DCT -> sample planes, then fancy chroma upsampling +
+ *          YCbCr -> RGB -> uint8 [H][W][3], a whole ragged batch in two launches; the result is what cris_preprocess_batch reads.
+ * Bit-exact with libjpeg(-turbo) at its default settings (JDCT_ISLOW, do_fancy_upsampling) - pinned against Pillow's
+ * libjpeg-turbo through oracle/jpeg_baseline.py.  Anything else (progressive, arithmetic, 12-bit, CMYK, multi-scan, other
+ * samplings) is refused with an error: the caller keeps such a file on its CPU decoder.  EXIF orientation is not applied. */
+typedef struct {
+    int width, height, ncomp;            /* ncomp 1 (gray) or 3 (YCbCr) */
+    int hmax, vmax;                      /* luma sampling factors: (1,1) 4:4:4, (2,1) 4:2:2, (2,2) 4:2:0 */
+    int mcus_x, mcus_y, restart_interval;
+    int comp_h[3], comp_v[3];
+    int blocks_w[3], blocks_h[3];        /* block grid of each component (whole MCUs) */
+    int down_w[3], down_h[3];            /* real samples of each component (libjpeg downsampled_width / height) */
+    unsigned short quant[3][64];         /* quantisation table of each component, natural order */
+    long coef_offset[3];                 /* int16 index of each component's blocks inside the image's coefficient buffer */
+    long coef_count;                     /* int16 elements of that buffer */
+    long plane_offset[3];                /* byte index of each component's [blocks_h*8][blocks_w*8] sample plane in the scratch */
+    long plane_bytes;
+    long scan_offset;                    /* byte offset of the entropy-coded segment in the file */
+    int total_blocks, pad_;
+} cris_jpeg_info;
+int cris_jpeg_read_header(const unsigned char* data, size_t nbytes, cris_jpeg_info* info);                         /* host */
+int cris_jpeg_decode_coefficients(const unsigned char* data, size_t nbytes, const cris_jpeg_info* info, short* coef); /* host */
+/* host: images [0, n) on up to n_threads threads; returns 0 or the first failing image's error (cris_last_error names it) */
+int cris_jpeg_decode_coefficients_batch(int n, const unsigned char* const* data, const size_t* nbytes, const cris_jpeg_info* infos,
+                                        short* const* coefs, int n_threads);
+typedef struct {
+    const short* coef;                   /* DEVICE: info.coef_count int16 */
+    unsigned char* planes;               /* DEVICE scratch: info.plane_bytes */
+    unsigned char* rgb;                  /* DEVICE out: [height][width][3] */
+    cris_jpeg_info info;
+} cris_jpeg_image;
+/* dev_table: DEVICE array of n images; max_blocks / max_pixels: the largest info.total_blocks / width*height in the batch */
+int cris_jpeg_reconstruct(const cris_jpeg_image* dev_table, int n, int max_blocks, long max_pixels, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,101 @@
+"""JPEG decoding without a GPU (reference call site utils/dataset.py:127-129):
+  1. the oracle (oracle/jpeg_baseline.py) is PINNED to libjpeg-turbo as built into Pillow - bit exact on every case;
+  2. the library's host half (marker parsing + Huffman decoding, csrc/jpeg.hip) gives the oracle's coefficients bit for bit;
+  3. the arithmetic of the device half (csrc/jpeg_core.h - the header the HIP kernels include) compiled by g++ into a probe
+     gives Pillow's pixels bit for bit;
+  4. unsupported files are refused with a message, corrupt ones do not crash.
+The kernels themselves are compared with the same references on the GPU (tests/test_jpeg_gpu.py)."""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+PIL = pytest.importorskip("PIL")
+
+from cris.pytorch_amd import hip, jpegdec  # noqa: E402
+from oracle import jpeg_baseline as J  # noqa: E402
+import jpeg_cases  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def files():
+    return list(jpeg_cases.cases(big=(120, 160)))
+
+
+@pytest.fixture(scope="module")
+def probe():
+    d = tempfile.mkdtemp()
+    exe = os.path.join(d, "jpeg_core_probe")
+    subprocess.check_call(["g++", "-O1", "-o", exe, os.path.join(ROOT, "tests", "jpeg_core_probe.cpp")])
+    return exe
+
+
+def test_oracle_is_pinned_to_libjpeg_turbo(files):
+    for name, data in files:
+        assert np.array_equal(J.decode(data), jpeg_cases.pil_decode(data)), name
+
+
+def test_host_half_matches_oracle_coefficients(files):
+    datas = [d for _, d in files]
+    infos, coef, offs = jpegdec.decode_coefficients(datas, threads=4)
+    for i, (name, data) in enumerate(files):
+        h = J.parse(data)
+        ref = J.entropy_decode(data, h)
+        I = infos[i]
+        assert (I.width, I.height, I.ncomp, I.hmax, I.vmax, I.restart_interval) == (h.width, h.height, len(h.comps), h.hmax, h.vmax, h.restart_interval), name
+        for c, comp in enumerate(h.comps):
+            assert (I.blocks_w[c], I.blocks_h[c], I.down_w[c], I.down_h[c]) == (comp["bw"], comp["bh"], comp["dw"], comp["dh"]), name
+            assert np.array_equal(np.array(I.quant[c][:], dtype=np.int64), h.qt[comp["tq"]]), name
+            n = comp["bw"] * comp["bh"] * 64
+            got = coef[offs[i] + I.coef_offset[c]: offs[i] + I.coef_offset[c] + n].numpy().reshape(comp["bh"], comp["bw"], 64)
+            assert np.array_equal(got, ref[c]), (name, c)
+    # one thread gives the same
+    _, coef1, _ = jpegdec.decode_coefficients(datas, threads=1)
+    for i in range(len(datas)):
+        a, b = offs[i], offs[i] + infos[i].coef_count
+        assert bool((coef1[a:b] == coef[a:b]).all())
+
+
+def test_device_arithmetic_on_the_cpu_matches_pillow(files, probe):
+    datas = [d for _, d in files]
+    infos, coef, offs = jpegdec.decode_coefficients(datas, threads=4)
+    with tempfile.TemporaryDirectory() as td:
+        for i, (name, data) in enumerate(files):
+            I = infos[i]
+            open(os.path.join(td, "i.bin"), "wb").write(bytes(I))
+            coef[offs[i]:offs[i] + I.coef_count].numpy().tofile(os.path.join(td, "c.bin"))
+            subprocess.check_call([probe, os.path.join(td, "i.bin"), os.path.join(td, "c.bin"), os.path.join(td, "o.rgb")])
+            got = np.fromfile(os.path.join(td, "o.rgb"), dtype=np.uint8).reshape(I.height, I.width, 3)
+            assert np.array_equal(got, jpeg_cases.pil_decode(data)), name
+
+
+def test_unsupported_and_corrupt_files_are_refused():
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
+    with pytest.raises(hip.HipLibraryError, match="progressive"):
+        jpegdec.read_header(jpeg_cases.encode(img, quality=80, progressive=True))
+    with pytest.raises(hip.HipLibraryError, match="not a JPEG"):
+        jpegdec.read_header(b"\x89PNG\r\n\x1a\n" + bytes(64))
+    good = jpeg_cases.encode(img, quality=80, subsampling=2)
+    with pytest.raises(hip.HipLibraryError):
+        jpegdec.read_header(good[:100])                      # cut inside the tables
+    # a file cut inside the entropy-coded data decodes (missing data reads as zero bits, like libjpeg) or is refused - no crash
+    for cut in (len(good) // 2, len(good) - 3):
+        try:
+            jpegdec.decode_coefficients([good[:cut]], threads=1)
+        except hip.HipLibraryError:
+            pass
+    # random bytes after a valid header
+    junk = good[:jpegdec.read_header(good).scan_offset] + bytes(rng.integers(0, 256, 400, dtype=np.uint8))
+    try:
+        jpegdec.decode_coefficients([junk], threads=1)
+    except hip.HipLibraryError:
+        pass
+    # the batch call names the failing image
+    with pytest.raises(hip.HipLibraryError, match="image 1"):
+        jpegdec.decode_coefficients([good, b"\xff\xd8\xff\xd9"], threads=2)
