@@ -15,8 +15,6 @@ import pytest
 
 from conftest import ROOT
 
-PIL = pytest.importorskip("PIL")
-
 from cris.pytorch_amd import hip, jpegdec  # noqa: E402
 from oracle import jpeg_baseline as J  # noqa: E402
 import jpeg_cases  # noqa: E402
@@ -24,6 +22,7 @@ import jpeg_cases  # noqa: E402
 
 @pytest.fixture(scope="module")
 def files():
+    pytest.importorskip("PIL")                       # the encoder of the test files and the pinning decoder
     return list(jpeg_cases.cases(big=(120, 160)))
 
 
@@ -38,6 +37,25 @@ def probe():
 def test_oracle_is_pinned_to_libjpeg_turbo(files):
     for name, data in files:
         assert np.array_equal(J.decode(data), jpeg_cases.pil_decode(data)), name
+
+
+def test_oracle_and_library_reproduce_the_committed_vectors(probe):
+    """tests/golden/jpeg/vectors.npz (tests/golden/make_jpeg_golden.py): files + the pixels Pillow's libjpeg-turbo gave for them
+    when the fixture was made - needs no Pillow at test time"""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "jpeg", "vectors.npz"))
+    names = [str(n) for n in g["names"]]
+    assert len(names) >= 10
+    datas = [g["jpg%d" % i].tobytes() for i in range(len(names))]
+    infos, coef, offs = jpegdec.decode_coefficients(datas, threads=2)
+    with tempfile.TemporaryDirectory() as td:
+        for i, name in enumerate(names):
+            ref = g["rgb%d" % i]
+            assert np.array_equal(J.decode(datas[i]), ref), name
+            I = infos[i]
+            open(os.path.join(td, "i.bin"), "wb").write(bytes(I))
+            coef[offs[i]:offs[i] + I.coef_count].numpy().tofile(os.path.join(td, "c.bin"))
+            subprocess.check_call([probe, os.path.join(td, "i.bin"), os.path.join(td, "c.bin"), os.path.join(td, "o.rgb")])
+            assert np.array_equal(np.fromfile(os.path.join(td, "o.rgb"), dtype=np.uint8).reshape(ref.shape), ref), name
 
 
 def test_host_half_matches_oracle_coefficients(files):
@@ -75,6 +93,7 @@ def test_device_arithmetic_on_the_cpu_matches_pillow(files, probe):
 
 
 def test_unsupported_and_corrupt_files_are_refused():
+    pytest.importorskip("PIL")
     rng = np.random.default_rng(1)
     img = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
     with pytest.raises(hip.HipLibraryError, match="progressive"):
