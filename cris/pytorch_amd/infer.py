@@ -133,15 +133,22 @@ class InferenceRunner:
     the second is captured, later ones replay the graph: one host call per batch."""
 
     def __init__(self, clip: ClipSpec, head: HeadSpec, state_dict, device, fold_bn: bool = True, use_graph: bool = True,
-                 upsample: bool = False):
+                 upsample: bool = False, tensors=None):
+        """state_dict: a reference-keyed state_dict (copied to `device`); or `tensors=(params, buffers)`: dicts of device
+        tensors to run on IN PLACE (the drop-in module hands over its own parameters; call `invalidate()` when they change)"""
         from .trainer import split_state_dict
         self.device = device
-        params, buffers = split_state_dict(state_dict, device)
+        params, buffers = tensors if tensors is not None else split_state_dict(state_dict, device)
         self.engine = InferEngine(clip, head, params, buffers, device, fold_bn=fold_bn)
         self.use_graph = use_graph and torch.device(device).type == "cuda"
         self.upsample = upsample
         self._shapes = {}               # shape key -> dict(calls, img, word, graph, out)
         self.graph_error = None
+
+    def invalidate(self):
+        """the tensors this runner works on were changed by someone else: fold, pack and capture again"""
+        self.engine.invalidate()
+        self._shapes = {}
 
     def load_state_dict(self, sd):
         e = self.engine

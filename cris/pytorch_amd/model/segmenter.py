@@ -174,4 +174,26 @@ class CRIS(nn.Module):
                 torch._foreach_add_(nbt, 1)
             return pred.detach(), msk, loss
         with torch.no_grad():
+            if os.environ.get("CRIS_EVAL_FOLD", "1") == "1":
+                return self._eval_forward_folded(img, word)
             return eng.forward(img, word, None, training=False).detach()
+
+    def _eval_forward_folded(self, img, word):
+        """`model.eval()` forward (engine/engine.py:100,171; test.py; tools/latency.py:62) on the inference engine: BatchNorms
+        folded into their convolutions, one HIP graph per input shape (infer.py).  The folded weights are a cache of the
+        parameters and running statistics: it is rebuilt when any of them changed since it was made - torch's version counters
+        see optimizer steps and load_state_dict, `_steps` sees the running statistics the HIP training forward updates."""
+        from ..infer import InferenceRunner
+        eng = self._engine
+        tensors = list(eng.P.values()) + list(eng.Bf.values())
+        named = dict(self.named_parameters())
+        named.update(dict(self.named_buffers()))
+        sig = (self._engine_key, self._steps, sum(t._version for t in named.values()))
+        if getattr(self, "_infer", None) is None or self._infer_key != self._engine_key:
+            self._infer = InferenceRunner(self.clip_spec, self.head_spec, None, img.device, tensors=(eng.P, eng.Bf))
+            self._infer_key, self._infer_sig = self._engine_key, sig
+        elif sig != self._infer_sig:
+            self._infer.invalidate()
+            self._infer_sig = sig
+        _ = tensors
+        return self._infer(img.float().contiguous(), word).clone()           # (the runner's buffer is overwritten by its next call)

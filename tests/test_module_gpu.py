@@ -140,3 +140,40 @@ def test_module_under_dataparallel_like_test_py():
     other.load_state_dict(sd, strict=True)                      # test.py:78
     other.eval()
     assert torch.equal(other(img, word), p1)
+
+
+def test_module_eval_runs_folded_and_tracks_parameter_changes(monkeypatch):
+    """`model.eval()` forwards run on the inference engine (BatchNorms folded, HIP graph per shape; infer.py).  The folded
+    weights are a cache: an optimizer step (+ the running statistics the training forward updates) and a load_state_dict must
+    each refresh it - checked against freshly built modules."""
+    dev = torch.device("cuda:0")
+    clip, head = arch.specs_by_name("tiny")
+    sd0 = arch.synthetic_state_dict(clip, head, 0)
+    model, groups = build_segmenter(NS(**TINY))
+    model.load_state_dict(sd0)
+    model = model.to(dev).eval()
+    img, word, mask = _batch(0, dev)
+    a = [model(img, word) for _ in range(3)]                      # eager, captured, replayed
+    assert torch.equal(a[0], a[1]) and torch.equal(a[0], a[2]) and a[0].data_ptr() != a[1].data_ptr()
+    run = model._infer
+    assert len(run.engine._fold) == len(run.engine.bn_prefixes) - 2 and next(iter(run._shapes.values()))["graph"] is not None
+    monkeypatch.setenv("CRIS_EVAL_FOLD", "0")
+    b = model(img, word)                                          # the training engine's eval forward (apply kernels)
+    monkeypatch.delenv("CRIS_EVAL_FOLD")
+    err = float((a[0] - b).norm() / b.norm())
+    assert 0 < err < 3e-2, err
+    # one optimizer step: parameters AND running statistics move
+    model.train()
+    opt = torch.optim.Adam(groups, lr=1e-3)
+    model(img, word, mask)[2].backward()
+    opt.step()
+    model.eval()
+    c = model(img, word)
+    fresh, _ = build_segmenter(NS(**TINY))
+    fresh.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    d = fresh.to(dev).eval()(img, word)
+    assert torch.equal(c, d) and not torch.equal(c, a[0])
+    assert model._infer is run                                    # same runner, refreshed
+    # back to the first state through load_state_dict
+    model.load_state_dict(sd0)
+    assert torch.equal(model(img, word), a[0])
