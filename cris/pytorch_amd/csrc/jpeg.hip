@@ -1,8 +1,9 @@
 // Baseline JPEG decoding for the input pipeline (include/cris_hip.h "Baseline JPEG decoding"; reference call site
 // utils/dataset.py:127-129: cv2.imdecode + cvtColor on the raw file bytes of an LMDB record).
 //
-// Host part (this file, plain C++): marker parsing and Huffman entropy decoding (ITU-T T.81 Annex B / F) into quantised
-// coefficient blocks - bit-serial, data-dependent, one image per host thread.  Device part: everything that is arithmetic.
+// Host part (this file, plain C++): marker parsing and Huffman entropy decoding (ITU-T T.81 Annex B / F; progressive files:
+// Annex G - DC / AC first and refinement scans accumulated into the same coefficient blocks) into quantised coefficient
+// blocks - bit-serial, data-dependent, one image per host thread.  Device part: everything that is arithmetic.
 //   jpeg_idct_kernel   one 8x8 block per 8 lanes (64 lanes = 8 blocks): lane (b, c) dequantises and transforms COLUMN c of
 //                      block b (pass 1), the 8x8 workspace goes through LDS, lane (b, r) transforms ROW r (pass 2) and
 //                      writes its 8 samples with one 8-byte store.  Reads 128 B of coefficients per block (the quantisation
@@ -77,7 +78,7 @@ int parse_header(const unsigned char* d, size_t n, cris_jpeg_info* info, Tables*
     if (n < 4 || d[0] != 0xFF || d[1] != 0xD8) JERR("cris_jpeg: not a JPEG file (no SOI)");
     memset(info, 0, sizeof(*info));
     size_t pos = 2;
-    bool have_sof = false;
+    bool have_sof = false, progressive = false, first_scan_all = true;
     int comp_id[3] = {0, 0, 0};
     for (;;) {
         while (pos < n && d[pos] != 0xFF) ++pos;
@@ -115,7 +116,8 @@ int parse_header(const unsigned char* d, size_t n, cris_jpeg_info* info, Tables*
                 if (build_huff(tc ? T.ac[th] : T.dc[th], s + i + 1, s + i + 17, nsym)) JERR("cris_jpeg: invalid Huffman table");
                 i += 17 + nsym;
             }
-        } else if (m == 0xC0 || m == 0xC1) {
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+            if (m == 0xC2) progressive = true;
             if (sl < 6 || s[0] != 8) JERR("cris_jpeg: only 8-bit samples are supported");
             info->height = (s[1] << 8) | s[2];
             info->width = (s[3] << 8) | s[4];
@@ -130,19 +132,20 @@ int parse_header(const unsigned char* d, size_t n, cris_jpeg_info* info, Tables*
                 if (T.comp_tq[c] > 3) JERR("cris_jpeg: bad quantisation table index");
             }
             have_sof = true;
-        } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
-            JERR("cris_jpeg: unsupported JPEG process SOF%d (progressive / lossless / arithmetic): decode this file on the CPU", m - 0xC0);
+        } else if (m >= 0xC3 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
+            JERR("cris_jpeg: unsupported JPEG process SOF%d (lossless / arithmetic coding): decode this file on the CPU", m - 0xC0);
         } else if (m == 0xDD) {
             if (sl < 2) JERR("cris_jpeg: bad DRI");
             info->restart_interval = (s[0] << 8) | s[1];
         } else if (m == 0xDA) {
             if (!have_sof) JERR("cris_jpeg: SOS before SOF");
-            if (sl < 1 || s[0] != info->ncomp || sl < (size_t)(1 + 2 * info->ncomp + 3)) JERR("cris_jpeg: multi-scan baseline files are not supported");
-            for (int k = 0; k < info->ncomp; ++k) {
+            if (sl < 1 || s[0] < 1 || s[0] > info->ncomp || sl < (size_t)(1 + 2 * s[0] + 3)) JERR("cris_jpeg: bad SOS");
+            first_scan_all = s[0] == info->ncomp;
+            for (int k = 0; k < s[0]; ++k) {
                 int c = -1;
                 for (int q = 0; q < info->ncomp; ++q)
                     if (comp_id[q] == s[1 + 2 * k]) c = q;
-                if (c != k) JERR("cris_jpeg: scan components out of frame order");
+                if (c < 0 || (first_scan_all && c != k)) JERR("cris_jpeg: scan components out of frame order");
                 T.comp_td[c] = s[2 + 2 * k] >> 4;
                 T.comp_ta[c] = s[2 + 2 * k] & 15;
                 if (T.comp_td[c] > 3 || T.comp_ta[c] > 3) JERR("cris_jpeg: bad Huffman table index");
@@ -180,7 +183,10 @@ int parse_header(const unsigned char* d, size_t n, cris_jpeg_info* info, Tables*
     info->coef_count = co;
     info->plane_bytes = po;
     info->total_blocks = nb;
-    if (tb)
+    // 1: the coefficients are spread over several scans (progressive, or a sequential file with one scan per component):
+    // decode_general walks all of them; 0: one interleaved sequential scan (decode_scan)
+    info->multiscan = (progressive || !first_scan_all) ? (progressive ? 2 : 1) : 0;
+    if (tb && !info->multiscan)
         for (int c = 0; c < info->ncomp; ++c)
             if (!T.dc[T.comp_td[c]].present || !T.ac[T.comp_ta[c]].present) JERR("cris_jpeg: missing Huffman table");
     return 0;
@@ -297,6 +303,206 @@ int decode_scan(const unsigned char* d, size_t n, const cris_jpeg_info& I, const
     return 0;
 }
 
+
+// ---- multi-scan files: progressive (T.81 Annex G, libjpeg jdphuff.c) and sequential files with one scan per component ----
+struct Scan {
+    int ns, comp[3], td[3], ta[3], Ss, Se, Ah, Al;
+};
+
+// one block of a scan; returns non-zero on corrupt data
+inline int scan_block(BitReader& br, const Scan& S, int k_in_scan, const Tables& T, bool progressive, short* blk, int& pred, int& eobrun) {
+    const HuffTable& dc = T.dc[S.td[k_in_scan]];
+    const HuffTable& ac = T.ac[S.ta[k_in_scan]];
+    if (!progressive) {
+        int s = br.symbol(dc);
+        if (s < 0 || s > 15) return -1;
+        if (s) pred += huff_extend(br.bits(s), s);
+        blk[0] = (short)pred;
+        for (int k = 1; k < 64;) {
+            const int rs = br.symbol(ac);
+            if (rs < 0) return -1;
+            const int r = rs >> 4;
+            s = rs & 15;
+            if (s == 0) {
+                if (r != 15) break;
+                k += 16;
+                continue;
+            }
+            k += r;
+            blk[kNatural[k]] = (short)huff_extend(br.bits(s), s);
+            ++k;
+        }
+        return 0;
+    }
+    if (S.Ss == 0) {
+        if (S.Ah == 0) {                               // DC first pass
+            const int s = br.symbol(dc);
+            if (s < 0 || s > 15) return -1;
+            if (s) pred += huff_extend(br.bits(s), s);
+            blk[0] = (short)(pred * (1 << S.Al));
+        } else if (br.bits(1)) {                       // DC refinement
+            blk[0] = (short)(blk[0] | (1 << S.Al));
+        }
+        return 0;
+    }
+    if (S.Ah == 0) {                                   // AC first pass
+        if (eobrun > 0) {
+            --eobrun;
+            return 0;
+        }
+        for (int k = S.Ss; k <= S.Se; ++k) {
+            const int rs = br.symbol(ac);
+            if (rs < 0) return -1;
+            const int r = rs >> 4, s = rs & 15;
+            if (s) {
+                k += r;
+                blk[kNatural[k]] = (short)(huff_extend(br.bits(s), s) * (1 << S.Al));
+            } else if (r == 15) {
+                k += 15;
+            } else {
+                eobrun = (1 << r) + (r ? br.bits(r) : 0) - 1;
+                break;
+            }
+        }
+        return 0;
+    }
+    // AC refinement (jdphuff.c decode_mcu_AC_refine)
+    const int p1 = 1 << S.Al, m1 = -(1 << S.Al);
+    int k = S.Ss;
+    if (eobrun == 0) {
+        for (; k <= S.Se; ++k) {
+            const int rs = br.symbol(ac);
+            if (rs < 0) return -1;
+            int r = rs >> 4, s = rs & 15;
+            if (s) {
+                s = br.bits(1) ? p1 : m1;
+            } else if (r != 15) {
+                eobrun = (1 << r) + (r ? br.bits(r) : 0);
+                break;
+            }
+            do {
+                short* c = blk + kNatural[k];
+                if (*c != 0) {
+                    if (br.bits(1) && (*c & p1) == 0) *c = (short)(*c + (*c >= 0 ? p1 : m1));
+                } else if (--r < 0) {
+                    break;
+                }
+                ++k;
+            } while (k <= S.Se);
+            if (s) blk[kNatural[k]] = (short)s;
+        }
+    }
+    if (eobrun > 0) {
+        for (; k <= S.Se; ++k) {
+            short* c = blk + kNatural[k];
+            if (*c != 0 && br.bits(1) && (*c & p1) == 0) *c = (short)(*c + (*c >= 0 ? p1 : m1));
+        }
+        --eobrun;
+    }
+    return 0;
+}
+
+int decode_general(const unsigned char* d, size_t n, const cris_jpeg_info& I, short* coef) {
+    memset(coef, 0, (size_t)I.coef_count * sizeof(short));
+    const bool progressive = I.multiscan == 2;
+    Tables T;
+    int ri = 0, comp_id[3] = {0, 0, 0};
+    size_t pos = 2;
+    int scans = 0;
+    while (pos < n) {
+        while (pos < n && d[pos] != 0xFF) ++pos;
+        while (pos < n && d[pos] == 0xFF) ++pos;
+        if (pos >= n) break;
+        const int m = d[pos++];
+        if (m == 0xD8 || m == 0x01 || m == 0x00 || (m >= 0xD0 && m <= 0xD7)) continue;
+        if (m == 0xD9) break;
+        if (pos + 2 > n) break;
+        const size_t len = ((size_t)d[pos] << 8) | d[pos + 1];
+        if (len < 2 || pos + len > n) JERR("cris_jpeg: truncated segment");
+        const unsigned char* s = d + pos + 2;
+        const size_t sl = len - 2;
+        pos += len;
+        if (m == 0xC4) {
+            size_t i = 0;
+            while (i < sl) {
+                if (i + 17 > sl) JERR("cris_jpeg: bad DHT");
+                const int tc = s[i] >> 4, th = s[i] & 15;
+                int nsym = 0;
+                for (int k = 0; k < 16; ++k) nsym += s[i + 1 + k];
+                if (tc > 1 || th > 3 || nsym > 256 || i + 17 + nsym > sl) JERR("cris_jpeg: bad DHT");
+                if (build_huff(tc ? T.ac[th] : T.dc[th], s + i + 1, s + i + 17, nsym)) JERR("cris_jpeg: invalid Huffman table");
+                i += 17 + nsym;
+            }
+        } else if (m == 0xDD) {
+            if (sl < 2) JERR("cris_jpeg: bad DRI");
+            ri = (s[0] << 8) | s[1];
+        } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {
+            for (int c = 0; c < I.ncomp && sl >= (size_t)(6 + 3 * I.ncomp); ++c) comp_id[c] = s[6 + 3 * c];
+        } else if (m == 0xDA) {
+            Scan S;
+            if (sl < 1 || s[0] < 1 || s[0] > I.ncomp || sl < (size_t)(1 + 2 * s[0] + 3)) JERR("cris_jpeg: bad SOS");
+            S.ns = s[0];
+            for (int k = 0; k < S.ns; ++k) {
+                int c = -1;
+                for (int q = 0; q < I.ncomp; ++q)
+                    if (comp_id[q] == s[1 + 2 * k]) c = q;
+                if (c < 0) JERR("cris_jpeg: unknown component in SOS");
+                S.comp[k] = c;
+                S.td[k] = s[2 + 2 * k] >> 4;
+                S.ta[k] = s[2 + 2 * k] & 15;
+                if (S.td[k] > 3 || S.ta[k] > 3) JERR("cris_jpeg: bad Huffman table index");
+            }
+            S.Ss = s[1 + 2 * S.ns]; S.Se = s[2 + 2 * S.ns]; S.Ah = s[3 + 2 * S.ns] >> 4; S.Al = s[3 + 2 * S.ns] & 15;
+            if (!progressive) { S.Ss = 0; S.Se = 63; S.Ah = 0; S.Al = 0; }
+            if (S.Ss > S.Se || S.Se > 63 || S.Al > 13 || (S.Ss == 0 && S.Se != 0 && progressive) || (S.Ss > 0 && S.ns != 1))
+                JERR("cris_jpeg: invalid progressive scan parameters (Ss %d Se %d Ah %d Al %d, %d components)", S.Ss, S.Se, S.Ah, S.Al, S.ns);
+            for (int k = 0; k < S.ns; ++k) {
+                const bool need_dc = !progressive || (S.Ss == 0 && S.Ah == 0), need_ac = !progressive || S.Ss > 0;
+                if ((need_dc && !T.dc[S.td[k]].present) || (need_ac && !T.ac[S.ta[k]].present)) JERR("cris_jpeg: missing Huffman table");
+            }
+            BitReader br(d, n, pos);
+            int pred[3] = {0, 0, 0}, eobrun = 0, left = ri;
+            auto restart_if_due = [&]() -> int {
+                if (ri && left == 0) {
+                    if (!br.restart()) return -1;
+                    pred[0] = pred[1] = pred[2] = 0;
+                    eobrun = 0;
+                    left = ri;
+                }
+                return 0;
+            };
+            if (S.ns == 1) {                                      // non-interleaved: the component's real blocks
+                const int c = S.comp[0];
+                const int bw = (I.down_w[c] + 7) / 8, bh = (I.down_h[c] + 7) / 8;
+                for (int by = 0; by < bh; ++by)
+                    for (int bx = 0; bx < bw; ++bx) {
+                        if (restart_if_due()) JERR("cris_jpeg: missing restart marker");
+                        short* blk = coef + I.coef_offset[c] + ((long)by * I.blocks_w[c] + bx) * 64;
+                        if (scan_block(br, S, 0, T, progressive, blk, pred[0], eobrun)) JERR("cris_jpeg: corrupt entropy-coded data");
+                        --left;
+                    }
+            } else {
+                for (int my = 0; my < I.mcus_y; ++my)
+                    for (int mx = 0; mx < I.mcus_x; ++mx) {
+                        if (restart_if_due()) JERR("cris_jpeg: missing restart marker");
+                        for (int k = 0; k < S.ns; ++k) {
+                            const int c = S.comp[k];
+                            for (int v = 0; v < I.comp_v[c]; ++v)
+                                for (int u = 0; u < I.comp_h[c]; ++u) {
+                                    short* blk = coef + I.coef_offset[c] + ((long)(my * I.comp_v[c] + v) * I.blocks_w[c] + (mx * I.comp_h[c] + u)) * 64;
+                                    if (scan_block(br, S, k, T, progressive, blk, pred[k], eobrun)) JERR("cris_jpeg: corrupt entropy-coded data");
+                                }
+                        }
+                        --left;
+                    }
+            }
+            pos = br.pos;                                          // the reader never passes the marker that ends the scan
+            ++scans;
+        }
+    }
+    if (scans == 0) JERR("cris_jpeg: no scan");
+    return 0;
+}
 }  // namespace
 
 extern "C" int cris_jpeg_read_header(const unsigned char* data, size_t nbytes, cris_jpeg_info* info) {
@@ -312,6 +518,7 @@ extern "C" int cris_jpeg_decode_coefficients(const unsigned char* data, size_t n
     if (again.coef_count != info->coef_count || again.scan_offset != info->scan_offset || again.width != info->width ||
         again.height != info->height)
         JERR("cris_jpeg_decode_coefficients: info does not belong to this file");
+    if (again.multiscan) return decode_general(data, nbytes, again, coef);
     return decode_scan(data, nbytes, again, T, coef);
 }
 

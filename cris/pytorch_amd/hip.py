@@ -178,7 +178,7 @@ class JpegInfo(C.Structure):
                 ("comp_h", I * 3), ("comp_v", I * 3), ("blocks_w", I * 3), ("blocks_h", I * 3), ("down_w", I * 3), ("down_h", I * 3),
                 ("quant", (C.c_ushort * 64) * 3),
                 ("coef_offset", L * 3), ("coef_count", L), ("plane_offset", L * 3), ("plane_bytes", L), ("scan_offset", L),
-                ("total_blocks", I), ("pad_", I)]
+                ("total_blocks", I), ("multiscan", I)]
 
 
 class JpegImage(C.Structure):

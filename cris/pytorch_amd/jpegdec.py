@@ -6,8 +6,9 @@ without the pixels ever visiting the host.
 Hybrid split (include/cris_hip.h, csrc/jpeg.hip): Huffman decoding into quantised coefficients on host threads (bit-serial),
 inverse DCT + chroma upsampling + colour conversion as two launches over the whole ragged batch.  The coefficients cross
 PCIe as int16: 3 bytes per pixel at 4:2:0, the same as the decoded image would.  Bit-exact with libjpeg(-turbo) at its
-default settings (oracle/jpeg_baseline.py, pinned against Pillow's libjpeg-turbo).  Unsupported files (progressive,
-arithmetic-coded, CMYK, multi-scan, other samplings) raise hip.HipLibraryError: there is no CPU decoder in here.
+default settings (oracle/jpeg_baseline.py, pinned against Pillow's libjpeg-turbo).  Sequential and progressive Huffman files
+are decoded; unsupported ones (arithmetic-coded, lossless, CMYK, other samplings) raise hip.HipLibraryError: there is no CPU
+decoder in here.
 """
 import ctypes as C
 import os

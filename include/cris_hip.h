@@ -461,15 +461,15 @@ int cris_comm_broadcast(cris_comm* c, void* buf, size_t nbytes, int root, void* 
 /* ---- Baseline JPEG decoding (csrc/jpeg.hip) -------------------------------------------------------------
  * Replaces `cv2.imdecode(np.frombuffer(ref['img'], np.uint8), cv2.IMREAD_COLOR)` + `cv2.cvtColor(.., COLOR_BGR2RGB)` of the
  * reference's loader (utils/dataset.py:127-129) for the files its LMDB records hold (tools/folder2lmdb.py:50-56 stores the raw
- * JPEG bytes): 8-bit baseline sequential Huffman JPEG, one interleaved scan, gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart
- * intervals.  Hybrid split, as the bit-serial part does not parallelise inside an image:
+ * JPEG bytes): 8-bit Huffman-coded JPEG, sequential (one interleaved scan or one scan per component) or progressive
+ * (spectral selection + successive approximation), gray or YCbCr 4:4:4 / 4:2:2 / 4:2:0, restart intervals.  Hybrid split, as the bit-serial part does not parallelise inside an image:
  *   host   cris_jpeg_read_header, cris_jpeg_decode_coefficients(_batch): marker parsing + Huffman decoding (T.81 Annex F) into
  *          quantised coefficient blocks int16 [component][block row][block col][64] (natural order), one image per thread;
  *   device cris_jpeg_reconstruct: dequantisation + libjpeg's islow inverse DCT -> sample planes, then fancy chroma upsampling +
  *          YCbCr -> RGB -> uint8 [H][W][3], a whole ragged batch in two launches; the result is what cris_preprocess_batch reads.
  * Bit-exact with libjpeg(-turbo) at its default settings (JDCT_ISLOW, do_fancy_upsampling) - pinned against Pillow's
- * libjpeg-turbo through oracle/jpeg_baseline.py.  Anything else (progressive, arithmetic, 12-bit, CMYK, multi-scan, other
- * samplings) is refused with an error: the caller keeps such a file on its CPU decoder.  EXIF orientation is not applied. */
+ * libjpeg-turbo through oracle/jpeg_baseline.py.  Anything else (arithmetic coding, lossless, 12-bit, CMYK, other samplings)
+ * is refused with an error: the caller keeps such a file on its CPU decoder.  EXIF orientation is not applied. */
 typedef struct {
     int width, height, ncomp;            /* ncomp 1 (gray) or 3 (YCbCr) */
     int hmax, vmax;                      /* luma sampling factors: (1,1) 4:4:4, (2,1) 4:2:2, (2,2) 4:2:0 */
@@ -483,7 +483,8 @@ typedef struct {
     long plane_offset[3];                /* byte index of each component's [blocks_h*8][blocks_w*8] sample plane in the scratch */
     long plane_bytes;
     long scan_offset;                    /* byte offset of the entropy-coded segment in the file */
-    int total_blocks, pad_;
+    int total_blocks;
+    int multiscan;                       /* 0: one interleaved sequential scan; 1: sequential, one scan per component; 2: progressive (SOF2) */
 } cris_jpeg_info;
 int cris_jpeg_read_header(const unsigned char* data, size_t nbytes, cris_jpeg_info* info);                         /* host */
 int cris_jpeg_decode_coefficients(const unsigned char* data, size_t nbytes, const cris_jpeg_info* info, short* coef); /* host */

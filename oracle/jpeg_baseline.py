@@ -10,8 +10,9 @@ h2v1 / h2v2 triangle filters), YCbCr -> RGB with the 16-bit fixed-point tables o
 PARITY PIN: cv2 is not installed here, but libjpeg-turbo itself is - inside Pillow (PIL 12.2.0, libjpeg-turbo, API 6.2):
 tests/test_jpeg_oracle.py checks this file bit for bit against PIL's decoder on JPEGs of all supported samplings, qualities,
 odd sizes, optimised Huffman tables and restart intervals, and against the committed vectors under tests/golden/jpeg/.
-Not restated (the product rejects them too): progressive / arithmetic / 12-bit / CMYK files, multi-scan baseline files, EXIF
-orientation (OpenCV >= 4.5 rotates on IMREAD_COLOR; COCO's train2014 files carry none).
+Progressive files (SOF2: spectral selection + successive approximation, T.81 Annex G / jdphuff.c) and sequential files with
+one scan per component are restated too (entropy_decode_general).  Not restated (the product rejects them too): arithmetic
+coding / 12-bit / lossless / CMYK files, EXIF orientation (OpenCV >= 4.5 rotates on IMREAD_COLOR; COCO's train2014 files carry none).
 
 Only tests/, bench.py's cpu_baseline and selfcheck may import this module.  Pure Python / numpy: use small images.
 """
@@ -36,7 +37,7 @@ def parse(data: bytes) -> Header:
         raise JpegError("not a JPEG (no SOI)")
     h = Header()
     h.qt, h.dc, h.ac, h.restart_interval = {}, {}, {}, 0
-    h.comps = None
+    h.comps, h.progressive, h.multiscan = None, False, False
     pos = 2
     while True:
         while data[pos] != 0xFF:
@@ -75,19 +76,21 @@ def parse(data: bytes) -> Header:
                 syms = list(seg[i + 17:i + 17 + nsym])
                 i += 17 + nsym
                 (h.ac if tc else h.dc)[th] = _huff_table(counts, syms)
-        elif m == 0xC0 or m == 0xC1:                    # SOF0 / SOF1 (8-bit Huffman sequential)
+        elif m in (0xC0, 0xC1, 0xC2):                   # SOF0 / SOF1 (Huffman sequential), SOF2 (Huffman progressive)
+            h.progressive = m == 0xC2
             if seg[0] != 8:
                 raise JpegError("only 8-bit samples")
             h.height, h.width, nc = (seg[1] << 8) | seg[2], (seg[3] << 8) | seg[4], seg[5]
             h.comps = [dict(id=seg[6 + 3 * c], h=seg[7 + 3 * c] >> 4, v=seg[7 + 3 * c] & 15, tq=seg[8 + 3 * c]) for c in range(nc)]
-        elif 0xC2 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
-            raise JpegError("unsupported JPEG process (SOF%d: progressive / lossless / arithmetic)" % (m - 0xC0))
+        elif 0xC3 <= m <= 0xCF and m not in (0xC4, 0xC8, 0xCC):
+            raise JpegError("unsupported JPEG process (SOF%d: lossless / arithmetic)" % (m - 0xC0))
         elif m == 0xDD:
             h.restart_interval = (seg[0] << 8) | seg[1]
         elif m == 0xDA:                                 # SOS
             ns = seg[0]
-            if h.comps is None or ns != len(h.comps):
-                raise JpegError("multi-scan baseline files are not supported")
+            if h.comps is None:
+                raise JpegError("SOS before SOF")
+            h.multiscan = h.progressive or ns != len(h.comps)          # more scans follow: entropy_decode_general
             for s in range(ns):
                 cid, tabs = seg[1 + 2 * s], seg[2 + 2 * s]
                 c = next(c for c in h.comps if c["id"] == cid)
@@ -209,6 +212,154 @@ def entropy_decode(data: bytes, h: Header):
     return coefs
 
 
+# ---- multi-scan files: progressive (T.81 Annex G; libjpeg jdphuff.c) and sequential files with one scan per component -----
+def _scan_blocks(h, scomps):
+    """(component index, block row, block col) per MCU of a scan, with the restart-interval unit (one MCU)"""
+    if len(scomps) == 1:                                              # non-interleaved: the component's REAL blocks, raster order
+        ci = scomps[0]
+        c = h.comps[ci]
+        for by in range(-(-c["dh"] // 8)):
+            for bx in range(-(-c["dw"] // 8)):
+                yield [(ci, by, bx)]
+    else:
+        for my in range(h.mcus_y):
+            for mx in range(h.mcus_x):
+                yield [(ci, my * h.comps[ci]["v"] + v, mx * h.comps[ci]["h"] + u)
+                       for ci in scomps for v in range(h.comps[ci]["v"]) for u in range(h.comps[ci]["h"])]
+
+
+def entropy_decode_general(data: bytes, h: Header):
+    """every scan of the file accumulated into the coefficient arrays: DC / AC first and refinement passes of a progressive
+    file, or the per-component scans of a sequential one"""
+    coefs = [np.zeros((c["bh"], c["bw"], 64), dtype=np.int16) for c in h.comps]
+    dc, ac, ri = {}, {}, 0
+    pos = 2
+    while pos < len(data):
+        while pos < len(data) and data[pos] != 0xFF:
+            pos += 1
+        while pos < len(data) and data[pos] == 0xFF:
+            pos += 1
+        if pos >= len(data):
+            break
+        m = data[pos]
+        pos += 1
+        if m in (0xD8, 0x01) or 0xD0 <= m <= 0xD7 or m == 0x00:
+            continue
+        if m == 0xD9:
+            break
+        n = (data[pos] << 8) | data[pos + 1]
+        seg = data[pos + 2:pos + n]
+        pos += n
+        if m == 0xC4:
+            i = 0
+            while i < len(seg):
+                tc, th = seg[i] >> 4, seg[i] & 15
+                counts = list(seg[i + 1:i + 17])
+                nsym = sum(counts)
+                (ac if tc else dc)[th] = _huff_table(counts, list(seg[i + 17:i + 17 + nsym]))
+                i += 17 + nsym
+        elif m == 0xDD:
+            ri = (seg[0] << 8) | seg[1]
+        elif m == 0xDA:
+            ns = seg[0]
+            scomps, tabs = [], {}
+            for k in range(ns):
+                ci = next(i for i, c in enumerate(h.comps) if c["id"] == seg[1 + 2 * k])
+                scomps.append(ci)
+                tabs[ci] = (seg[2 + 2 * k] >> 4, seg[2 + 2 * k] & 15)
+            Ss, Se, Ah, Al = seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns] >> 4, seg[3 + 2 * ns] & 15
+            if not h.progressive:
+                Ss, Se, Ah, Al = 0, 63, 0, 0
+            br = _Bits(data, pos)
+            pred = {ci: 0 for ci in scomps}
+            eobrun, left = 0, ri
+            for mcu in _scan_blocks(h, scomps):
+                if ri and left == 0:
+                    br.restart()
+                    pred = {ci: 0 for ci in scomps}
+                    eobrun, left = 0, ri
+                for ci, by, bx in mcu:
+                    blk = coefs[ci][by, bx]
+                    if not h.progressive:
+                        s = br.symbol(dc[tabs[ci][0]])
+                        if s:
+                            pred[ci] += _extend(br.bits(s), s)
+                        blk[0] = pred[ci]
+                        k = 1
+                        while k < 64:
+                            rs = br.symbol(ac[tabs[ci][1]])
+                            r, s = rs >> 4, rs & 15
+                            if s == 0:
+                                if r != 15:
+                                    break
+                                k += 16
+                                continue
+                            k += r
+                            blk[ZIGZAG[k]] = _extend(br.bits(s), s)
+                            k += 1
+                    elif Ss == 0:
+                        if Ah == 0:                                   # DC first pass (G.1.2.1)
+                            s = br.symbol(dc[tabs[ci][0]])
+                            if s:
+                                pred[ci] += _extend(br.bits(s), s)
+                            blk[0] = pred[ci] << Al
+                        elif br.bit():                                # DC refinement: one more bit
+                            blk[0] |= 1 << Al
+                    elif Ah == 0:                                     # AC first pass (G.1.2.2)
+                        if eobrun > 0:
+                            eobrun -= 1
+                            continue
+                        k = Ss
+                        while k <= Se:
+                            rs = br.symbol(ac[tabs[ci][1]])
+                            r, s = rs >> 4, rs & 15
+                            if s:
+                                k += r
+                                blk[ZIGZAG[k]] = _extend(br.bits(s), s) << Al
+                            elif r == 15:
+                                k += 15
+                            else:
+                                eobrun = (1 << r) + (br.bits(r) if r else 0) - 1
+                                break
+                            k += 1
+                    else:                                             # AC refinement (G.1.2.3; jdphuff.c decode_mcu_AC_refine)
+                        p1, m1 = 1 << Al, -1 << Al
+                        k = Ss
+                        if eobrun == 0:
+                            while k <= Se:
+                                rs = br.symbol(ac[tabs[ci][1]])
+                                r, s = rs >> 4, rs & 15
+                                if s:
+                                    s = p1 if br.bit() else m1
+                                elif r != 15:
+                                    eobrun = (1 << r) + (br.bits(r) if r else 0)
+                                    break
+                                while k <= Se:
+                                    z = ZIGZAG[k]
+                                    if blk[z] != 0:
+                                        if br.bit() and (int(blk[z]) & p1) == 0:
+                                            blk[z] += p1 if blk[z] >= 0 else m1
+                                    else:
+                                        r -= 1
+                                        if r < 0:
+                                            break
+                                    k += 1
+                                if s:
+                                    blk[ZIGZAG[k]] = s
+                                k += 1
+                        if eobrun > 0:
+                            while k <= Se:
+                                z = ZIGZAG[k]
+                                if blk[z] != 0 and br.bit() and (int(blk[z]) & p1) == 0:
+                                    blk[z] += p1 if blk[z] >= 0 else m1
+                                k += 1
+                            eobrun -= 1
+                left -= 1
+            # the reader stops in front of the marker that ends the scan (or ran over it by at most its look-ahead: none here)
+            pos = br.pos
+    return coefs
+
+
 # ---- jidctint.c: jpeg_idct_islow -----------------------------------------------------------------------------------
 CONST_BITS, PASS1_BITS = 13, 2
 F_0_298631336, F_0_390180644, F_0_541196100, F_0_765366865 = 2446, 3196, 4433, 6270
@@ -323,4 +474,5 @@ def reconstruct(h: Header, planes):
 
 def decode(data: bytes):
     h = parse(data)
-    return reconstruct(h, idct_planes(h, entropy_decode(data, h)))
+    coefs = entropy_decode_general(data, h) if h.multiscan else entropy_decode(data, h)
+    return reconstruct(h, idct_planes(h, coefs))

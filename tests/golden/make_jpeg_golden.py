@@ -8,6 +8,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 import jpeg_cases  # noqa: E402
 
 import PIL  # noqa: E402
@@ -15,6 +16,7 @@ from PIL import features  # noqa: E402
 
 out = {}
 keep = ("37x53_s2_q85_smooth", "37x53_s1_q30_noise", "33x31_s0_q100_smooth", "17x2_s2_q85_smooth", "9x4_s1_q85_noise", "1x1_s2_q85_smooth",
+        "37x53_s2_q90_prog", "33x31_s1_q30_prog", "17x2_s2_q100_prog", "41x57_prog_rst", "20x33_gray_prog", "37x53_s2_q85_nonint",
         "64x48_s2_q100_noise", "41x57_qual90_rest3_subs2", "41x57_qual90_rest1_subs1", "24x40_opti", "20x33_gray", "40x56_opti")
 names = []
 for name, data in jpeg_cases.cases():

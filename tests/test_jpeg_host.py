@@ -63,7 +63,7 @@ def test_host_half_matches_oracle_coefficients(files):
     infos, coef, offs = jpegdec.decode_coefficients(datas, threads=4)
     for i, (name, data) in enumerate(files):
         h = J.parse(data)
-        ref = J.entropy_decode(data, h)
+        ref = J.entropy_decode_general(data, h) if h.multiscan else J.entropy_decode(data, h)
         I = infos[i]
         assert (I.width, I.height, I.ncomp, I.hmax, I.vmax, I.restart_interval) == (h.width, h.height, len(h.comps), h.hmax, h.vmax, h.restart_interval), name
         for c, comp in enumerate(h.comps):
@@ -96,8 +96,13 @@ def test_unsupported_and_corrupt_files_are_refused():
     pytest.importorskip("PIL")
     rng = np.random.default_rng(1)
     img = rng.integers(0, 256, (40, 40, 3), dtype=np.uint8)
-    with pytest.raises(hip.HipLibraryError, match="progressive"):
-        jpegdec.read_header(jpeg_cases.encode(img, quality=80, progressive=True))
+    import io
+    from PIL import Image
+    b = io.BytesIO()
+    Image.fromarray(rng.integers(0, 256, (16, 16, 4), dtype=np.uint8), "CMYK").save(b, "JPEG", quality=80)
+    with pytest.raises(hip.HipLibraryError, match="1 or 3 components"):
+        jpegdec.read_header(b.getvalue())
+    assert jpegdec.read_header(jpeg_cases.encode(img, quality=80, progressive=True)).multiscan == 2
     with pytest.raises(hip.HipLibraryError, match="not a JPEG"):
         jpegdec.read_header(b"\x89PNG\r\n\x1a\n" + bytes(64))
     good = jpeg_cases.encode(img, quality=80, subsampling=2)
