@@ -124,6 +124,7 @@ int parse_header(const unsigned char* d, size_t n, cris_jpeg_info* info, Tables*
             info->ncomp = s[5];
             if ((info->ncomp != 1 && info->ncomp != 3) || sl < (size_t)(6 + 3 * info->ncomp)) JERR("cris_jpeg: 1 or 3 components are supported (got %d)", info->ncomp);
             if (info->width <= 0 || info->height <= 0) JERR("cris_jpeg: empty image");
+            if ((long)info->width * info->height > (1L << 28)) JERR("cris_jpeg: image larger than 2^28 pixels (%d x %d)", info->width, info->height);
             for (int c = 0; c < info->ncomp; ++c) {
                 comp_id[c] = s[6 + 3 * c];
                 info->comp_h[c] = s[7 + 3 * c] >> 4;

@@ -123,3 +123,34 @@ def test_unsupported_and_corrupt_files_are_refused():
     # the batch call names the failing image
     with pytest.raises(hip.HipLibraryError, match="image 1"):
         jpegdec.decode_coefficients([good, b"\xff\xd8\xff\xd9"], threads=2)
+
+
+def test_corrupted_files_never_crash_the_host_decoder():
+    """6000 mutations (flipped bytes anywhere, truncation, damaged entropy-coded data, inserted bytes) of sequential and
+    progressive files: every one is either decoded (libjpeg, too, decodes what it can of a damaged scan) or refused with an
+    error - the process survives and no call hangs"""
+    pytest.importorskip("PIL")
+    rng = np.random.default_rng(7)
+    seeds = [d for _, d in jpeg_cases.cases(sizes=((37, 53), (16, 16), (9, 4)), qualities=(85,))]
+    decoded = refused = 0
+    for it in range(6000):
+        src = bytearray(seeds[it % len(seeds)])
+        mode = it % 4
+        if mode == 0:
+            for _ in range(rng.integers(1, 6)):
+                src[rng.integers(2, len(src))] = rng.integers(0, 256)
+        elif mode == 1:
+            src = src[:rng.integers(4, len(src))]
+        elif mode == 2:
+            off = jpegdec.read_header(bytes(src)).scan_offset
+            for _ in range(rng.integers(1, 20)):
+                src[rng.integers(off, len(src))] = rng.integers(0, 256)
+        else:
+            p = int(rng.integers(2, len(src)))
+            src[p:p] = bytes(rng.integers(0, 256, rng.integers(1, 8), dtype=np.uint8))
+        try:
+            jpegdec.decode_coefficients([bytes(src)], threads=1)
+            decoded += 1
+        except hip.HipLibraryError:
+            refused += 1
+    assert decoded + refused == 6000 and decoded > 500 and refused > 500
