@@ -286,6 +286,8 @@ _SIGS = {
     "cris_jpeg_decode_coefficients": (I, [P, C.c_size_t, P, P]),
     "cris_jpeg_decode_coefficients_batch": (I, [I, P, P, P, P, I]),
     "cris_jpeg_reconstruct": (I, [P, I, I, L, P]),
+    "cris_png_gray8_size": (I, [P, C.c_size_t, P, P]),
+    "cris_png_decode_gray8": (I, [P, C.c_size_t, P, I, I]),
     "cris_comm_rccl_path": (C.c_char_p, []),
     "cris_comm_unique_id": (I, [P]),
     "cris_comm_init": (I, [I, I, P, P]),

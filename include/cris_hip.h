@@ -500,6 +500,14 @@ typedef struct {
 /* dev_table: DEVICE array of n images; max_blocks / max_pixels: the largest info.total_blocks / width*height in the batch */
 int cris_jpeg_reconstruct(const cris_jpeg_image* dev_table, int n, int max_blocks, long max_pixels, void* stream);
 
+/* ---- PNG masks (csrc/png.hip; host only) -----------------------------------------------------------------------------------
+ * Replaces `cv2.imdecode(np.frombuffer(ref['mask'], np.uint8), cv2.IMREAD_GRAYSCALE)` (utils/dataset.py:148-149) for the
+ * files tools/data_process.py:115-117 writes (`cv2.imwrite(.., mask * 255)`: 8-bit grayscale, non-interlaced): chunk walk,
+ * zlib + DEFLATE, row filters.  Lossless, so "parity" = equality with any PNG decoder (pinned against Pillow's).  Other PNG
+ * flavours (colour, palette, 1/2/4/16-bit, interlaced) are refused. */
+int cris_png_gray8_size(const unsigned char* data, size_t nbytes, int* width, int* height);
+int cris_png_decode_gray8(const unsigned char* data, size_t nbytes, unsigned char* out, int width, int height);   /* out: HOST [height][width] */
+
 #ifdef __cplusplus
 }
 #endif

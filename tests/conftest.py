@@ -15,7 +15,7 @@ def pytest_configure(config):
 
 # GPU run order: deterministic per-kernel parity first, then the whole-network comparisons, then the statistical ones
 # (loss trajectories, multi-process runs) - under `-x` a failure in a late, noise-sensitive test must not hide the kernel tests.
-_GPU_ORDER = ["test_hip_ops", "test_engine_gpu", "test_module_gpu", "test_dist_gpu", "test_ref_loop_gpu", "test_eval_post", "test_input_pipe", "test_jpeg_gpu", "test_p2p_gpu", "test_comm_gpu"]
+_GPU_ORDER = ["test_hip_ops", "test_engine_gpu", "test_module_gpu", "test_dist_gpu", "test_ref_loop_gpu", "test_eval_post", "test_input_pipe", "test_jpeg_gpu", "test_records_gpu", "test_p2p_gpu", "test_comm_gpu"]
 
 
 def _gpu_rank(item):
