@@ -29,7 +29,7 @@ def recorder(monkeypatch):
     return log
 
 
-@pytest.mark.parametrize("spec,batch,size,word_len", [("tiny", 3, 96, 9), ("r50", 1, 416, 17)])
+@pytest.mark.parametrize("spec,batch,size,word_len", [("tiny", 3, 96, 9), ("r50", 1, 416, 17), ("r101", 2, 480, 22)])
 def test_folded_schedule(recorder, spec, batch, size, word_len):
     clip, head = arch.specs_by_name(spec)
     head = dataclasses.replace(head, word_len=word_len)
