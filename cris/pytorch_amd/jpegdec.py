@@ -6,7 +6,8 @@ without the pixels ever visiting the host.
 Hybrid split (include/cris_hip.h, csrc/jpeg.hip): Huffman decoding into quantised coefficients on host threads (bit-serial),
 inverse DCT + chroma upsampling + colour conversion as two launches over the whole ragged batch.  The coefficients cross
 PCIe as int16: 3 bytes per pixel at 4:2:0, the same as the decoded image would.  Bit-exact with libjpeg(-turbo) at its
-default settings (oracle/jpeg_baseline.py, pinned against Pillow's libjpeg-turbo).  Sequential and progressive Huffman files
+default settings (oracle/jpeg_baseline.py, pinned against Pillow's libjpeg-turbo); an EXIF orientation tag is honoured the way
+cv2.imdecode honours it (the turned array is returned).  Sequential and progressive Huffman files
 are decoded; unsupported ones (arithmetic-coded, lossless, CMYK, other samplings) raise hip.HipLibraryError: there is no CPU
 decoder in here.
 """
@@ -18,6 +19,62 @@ import torch
 
 from . import hip
 from .hip import ptr
+
+
+def exif_orientation(data: bytes) -> int:
+    """EXIF orientation tag (0x0112) of a JPEG file, 1 (= upright) when there is none.  cv2.imdecode applies it for
+    IMREAD_COLOR (OpenCV >= 3.1; `IMREAD_IGNORE_ORIENTATION` is not among the reference's flags, utils/dataset.py:127-128), so
+    the decoded array the loader sees is already turned."""
+    pos, n = 2, len(data)
+    while pos + 4 <= n and data[pos] == 0xFF:
+        m = data[pos + 1]
+        if m == 0xDA or m == 0xD9:
+            break
+        if m == 0xFF:                                   # fill byte
+            pos += 1
+            continue
+        seg_len = (data[pos + 2] << 8) | data[pos + 3]
+        if m == 0xE1 and data[pos + 4:pos + 10] == b"Exif\x00\x00":
+            t = data[pos + 10:pos + 2 + seg_len]
+            if len(t) < 14 or t[:2] not in (b"II", b"MM"):
+                return 1
+            big = t[:2] == b"MM"
+            u16 = lambda o: int.from_bytes(t[o:o + 2], "big" if big else "little")      # noqa: E731
+            u32 = lambda o: int.from_bytes(t[o:o + 4], "big" if big else "little")      # noqa: E731
+            if u16(2) != 42:
+                return 1
+            ifd = u32(4)
+            if ifd + 2 > len(t):
+                return 1
+            for k in range(u16(ifd)):
+                e = ifd + 2 + 12 * k
+                if e + 12 > len(t):
+                    break
+                if u16(e) == 0x0112:
+                    v = u16(e + 8)
+                    return v if 1 <= v <= 8 else 1
+            return 1
+        pos += 2 + seg_len
+    return 1
+
+
+def apply_orientation(img: torch.Tensor, orientation: int) -> torch.Tensor:
+    """[H, W, C] turned the way OpenCV's ExifTransform / PIL's exif_transpose turn it (pure data movement)"""
+    if orientation == 2:
+        return img.flip(1)
+    if orientation == 3:
+        return img.flip(0, 1)
+    if orientation == 4:
+        return img.flip(0)
+    if orientation == 5:
+        return img.transpose(0, 1)
+    if orientation == 6:
+        return img.transpose(0, 1).flip(1)
+    if orientation == 7:
+        return img.transpose(0, 1).flip(0, 1)
+    if orientation == 8:
+        return img.transpose(0, 1).flip(0)
+    return img
 
 
 def read_header(data: bytes) -> hip.JpegInfo:
@@ -52,8 +109,9 @@ def decode_coefficients(files: Sequence[bytes], infos=None, threads: Optional[in
     return infos, coef, offs
 
 
-def decode_batch(files: Sequence[bytes], device, threads: Optional[int] = None) -> List[torch.Tensor]:
-    """JPEG files -> list of uint8 [H, W, 3] RGB tensors on `device` (views of one buffer)"""
+def decode_batch(files: Sequence[bytes], device, threads: Optional[int] = None, apply_exif: bool = True) -> List[torch.Tensor]:
+    """JPEG files -> list of uint8 [H, W, 3] RGB tensors on `device` (views of one buffer; files that carry an EXIF orientation
+    other than 1 come back turned, as cv2.imdecode returns them - apply_exif=False = IMREAD_IGNORE_ORIENTATION)"""
     if torch.device(device).type != "cuda":
         raise RuntimeError("jpegdec reconstructs on the GPU only (no CPU fallback)")
     lib = hip.load()
@@ -81,7 +139,9 @@ def decode_batch(files: Sequence[bytes], device, threads: Optional[int] = None) 
     out = []
     for i in range(n):
         h, w = infos[i].height, infos[i].width
-        out.append(rgb[r_off[i]:r_off[i] + h * w * 3].view(h, w, 3))
+        t = rgb[r_off[i]:r_off[i] + h * w * 3].view(h, w, 3)
+        o = exif_orientation(files[i]) if apply_exif else 1
+        out.append(t if o == 1 else apply_orientation(t, o).contiguous())
     # keep the operands alive until the stream has consumed them
     for t in (dcoef, planes, dtab):
         t.record_stream(torch.cuda.current_stream())

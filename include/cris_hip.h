@@ -469,7 +469,8 @@ int cris_comm_broadcast(cris_comm* c, void* buf, size_t nbytes, int root, void* 
  *          YCbCr -> RGB -> uint8 [H][W][3], a whole ragged batch in two launches; the result is what cris_preprocess_batch reads.
  * Bit-exact with libjpeg(-turbo) at its default settings (JDCT_ISLOW, do_fancy_upsampling) - pinned against Pillow's
  * libjpeg-turbo through oracle/jpeg_baseline.py.  Anything else (arithmetic coding, lossless, 12-bit, CMYK, other samplings)
- * is refused with an error: the caller keeps such a file on its CPU decoder.  EXIF orientation is not applied. */
+ * is refused with an error: the caller keeps such a file on its CPU decoder.  The EXIF orientation is the host mirror's job
+ * (cris/pytorch_amd/jpegdec.py turns the decoded image like cv2.imdecode does). */
 typedef struct {
     int width, height, ncomp;            /* ncomp 1 (gray) or 3 (YCbCr) */
     int hmax, vmax;                      /* luma sampling factors: (1,1) 4:4:4, (2,1) 4:2:2, (2,2) 4:2:0 */

@@ -154,3 +154,37 @@ def test_corrupted_files_never_crash_the_host_decoder():
         except hip.HipLibraryError:
             refused += 1
     assert decoded + refused == 6000 and decoded > 500 and refused > 500
+
+
+def test_exif_orientation_is_read_and_applied_like_pillow():
+    """cv2.imdecode turns the decoded array by the EXIF orientation (all eight values); the tag is found in both TIFF byte orders,
+    absent / damaged EXIF means upright.  Reference for the turn: PIL.ImageOps.exif_transpose (the same table as OpenCV's)."""
+    pytest.importorskip("PIL")
+    import io
+    import torch
+    from PIL import Image, ImageOps
+    rng = np.random.default_rng(3)
+    img = jpeg_cases._smooth(rng, 24, 40)
+    plain = jpeg_cases.encode(img, quality=90, subsampling=0)
+    assert jpegdec.exif_orientation(plain) == 1
+    base = torch.from_numpy(np.array(jpeg_cases.pil_decode(plain)))
+    for o in range(1, 9):
+        ex = Image.Exif()
+        ex[0x0112] = o
+        b = io.BytesIO()
+        Image.fromarray(img).save(b, "JPEG", quality=90, subsampling=0, exif=ex.tobytes())
+        data = b.getvalue()
+        assert jpegdec.exif_orientation(data) == o
+        want = np.asarray(ImageOps.exif_transpose(Image.open(io.BytesIO(data))).convert("RGB"))
+        got = jpegdec.apply_orientation(base, o).contiguous().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), o
+        # the other byte order: rewrite the TIFF block by hand
+        i = data.index(b"Exif\x00\x00") + 6
+        tiff = data[i:]
+        big = tiff[:2] == b"MM"
+        other = (b"II*\x00\x08\x00\x00\x00\x01\x00\x12\x01\x03\x00\x01\x00\x00\x00" + bytes([o, 0, 0, 0]) + b"\x00\x00\x00\x00") if big else \
+                (b"MM\x00*\x00\x00\x00\x08\x00\x01\x01\x12\x00\x03\x00\x00\x00\x01" + bytes([0, o, 0, 0]) + b"\x00\x00\x00\x00")
+        seg = b"Exif\x00\x00" + other
+        swapped = data[:2] + b"\xff\xe1" + (len(seg) + 2).to_bytes(2, "big") + seg + plain[2:]
+        assert jpegdec.exif_orientation(swapped) == o
+    assert jpegdec.exif_orientation(plain[:2] + b"\xff\xe1\x00\x0aExif\x00\x00zz" + plain[2:]) == 1      # damaged block
