@@ -12,7 +12,8 @@ tests/test_jpeg_oracle.py checks this file bit for bit against PIL's decoder on 
 odd sizes, optimised Huffman tables and restart intervals, and against the committed vectors under tests/golden/jpeg/.
 Progressive files (SOF2: spectral selection + successive approximation, T.81 Annex G / jdphuff.c) and sequential files with
 one scan per component are restated too (entropy_decode_general).  Not restated (the product rejects them too): arithmetic
-coding / 12-bit / lossless / CMYK files, EXIF orientation (OpenCV >= 4.5 rotates on IMREAD_COLOR; COCO's train2014 files carry none).
+coding / 12-bit / lossless / CMYK files.  The EXIF orientation (OpenCV turns the decoded array on IMREAD_COLOR) is handled
+and tested outside this file (jpegdec.apply_orientation against PIL.ImageOps.exif_transpose).
 
 Only tests/, bench.py's cpu_baseline and selfcheck may import this module.  Pure Python / numpy: use small images.
 """
