@@ -8,7 +8,7 @@ decoder at its DEFAULT settings, which is what cv2.imdecode uses: sequential Huf
 dct_method JDCT_ISLOW (jidctint.c: Loeffler-Ligtenberg-Moschytz, CONST_BITS 13, PASS1_BITS 2), do_fancy_upsampling (jdsample.c:
 h2v1 / h2v2 triangle filters), YCbCr -> RGB with the 16-bit fixed-point tables of jdcolor.c.
 PARITY PIN: cv2 is not installed here, but libjpeg-turbo itself is - inside Pillow (PIL 12.2.0, libjpeg-turbo, API 6.2):
-tests/test_jpeg_oracle.py checks this file bit for bit against PIL's decoder on JPEGs of all supported samplings, qualities,
+tests/test_jpeg_host.py checks this file bit for bit against PIL's decoder on JPEGs of all supported samplings, qualities,
 odd sizes, optimised Huffman tables and restart intervals, and against the committed vectors under tests/golden/jpeg/.
 Progressive files (SOF2: spectral selection + successive approximation, T.81 Annex G / jdphuff.c) and sequential files with
 one scan per component are restated too (entropy_decode_general).  Not restated (the product rejects them too): arithmetic
