@@ -116,6 +116,8 @@ def decode_batch(files: Sequence[bytes], device, threads: Optional[int] = None, 
         raise RuntimeError("jpegdec reconstructs on the GPU only (no CPU fallback)")
     lib = hip.load()
     n = len(files)
+    if n == 0:
+        return []
     infos, coef, offs = decode_coefficients(files, threads=threads, pin=True)
     dcoef = coef.to(device, non_blocking=True)
     p_off, r_off, ptot, rtot = [], [], 0, 0

@@ -185,15 +185,14 @@ class CRIS(nn.Module):
         see optimizer steps and load_state_dict, `_steps` sees the running statistics the HIP training forward updates."""
         from ..infer import InferenceRunner
         eng = self._engine
-        tensors = list(eng.P.values()) + list(eng.Bf.values())
-        named = dict(self.named_parameters())
-        named.update(dict(self.named_buffers()))
-        sig = (self._engine_key, self._steps, sum(t._version for t in named.values()))
+        if getattr(self, "_ver_key", None) != self._engine_key:          # (the tensor objects change with .cuda() / .to())
+            self._ver_tensors = list(self.parameters()) + list(self.buffers())
+            self._ver_key = self._engine_key
+        sig = (self._engine_key, self._steps, sum(t._version for t in self._ver_tensors))
         if getattr(self, "_infer", None) is None or self._infer_key != self._engine_key:
             self._infer = InferenceRunner(self.clip_spec, self.head_spec, None, img.device, tensors=(eng.P, eng.Bf))
             self._infer_key, self._infer_sig = self._engine_key, sig
         elif sig != self._infer_sig:
             self._infer.invalidate()
             self._infer_sig = sig
-        _ = tensors
         return self._infer(img.float().contiguous(), word).clone()           # (the runner's buffer is overwritten by its next call)
