@@ -98,3 +98,18 @@ def test_without_ftfy_non_ascii_is_refused_not_mangled():
         assert t.tokenize("a plain ascii sentence", 17, True).shape == (1, 17)
         with pytest.raises(RuntimeError, match="ftfy"):
             t.tokenize("café", 17, True)
+
+
+def test_property_any_text_tokenizes_like_the_reference(tok, ref_tokenize):
+    """hypothesis: arbitrary unicode text (control characters, surrogates excluded), any context length"""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    @settings(max_examples=400, deadline=None, derandomize=True)
+    @given(st.text(alphabet=st.characters(blacklist_categories=("Cs",)), max_size=60), st.sampled_from([8, 17, 22, 77]))
+    def check(text, L):
+        ref = ref_tokenize.tokenize(text, L, True)
+        got = tok.tokenize(text, L, True)
+        assert torch.equal(ref, got), (text, ref.tolist(), got.tolist())
+
+    check()
