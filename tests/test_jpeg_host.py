@@ -188,3 +188,27 @@ def test_exif_orientation_is_read_and_applied_like_pillow():
         swapped = data[:2] + b"\xff\xe1" + (len(seg) + 2).to_bytes(2, "big") + seg + plain[2:]
         assert jpegdec.exif_orientation(swapped) == o
     assert jpegdec.exif_orientation(plain[:2] + b"\xff\xe1\x00\x0aExif\x00\x00zz" + plain[2:]) == 1      # damaged block
+
+
+def test_property_random_files_decode_like_pillow(probe):
+    """hypothesis: random content, size, quality, sampling, sequential / progressive, optimised tables - host half + the device
+    arithmetic (jpeg_core.h via the g++ probe) == Pillow's libjpeg-turbo"""
+    pytest.importorskip("PIL")
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=120, deadline=None, derandomize=True)
+    @given(hnp.arrays(np.uint8, st.tuples(st.integers(1, 40), st.integers(1, 40), st.just(3))), st.integers(1, 100), st.sampled_from([0, 1, 2]),
+           st.booleans(), st.booleans())
+    def check(img, quality, sub, progressive, optimize):
+        data = jpeg_cases.encode(img, quality=quality, subsampling=sub, progressive=progressive, optimize=optimize)
+        infos, coef, offs = jpegdec.decode_coefficients([data], threads=1)
+        with tempfile.TemporaryDirectory() as td:
+            open(os.path.join(td, "i.bin"), "wb").write(bytes(infos[0]))
+            coef[offs[0]:offs[0] + infos[0].coef_count].numpy().tofile(os.path.join(td, "c.bin"))
+            subprocess.check_call([probe, os.path.join(td, "i.bin"), os.path.join(td, "c.bin"), os.path.join(td, "o.rgb")])
+            got = np.fromfile(os.path.join(td, "o.rgb"), dtype=np.uint8).reshape(infos[0].height, infos[0].width, 3)
+        assert np.array_equal(got, jpeg_cases.pil_decode(data))
+
+    check()

@@ -69,3 +69,19 @@ def test_other_flavours_and_damage_are_refused():
     assert refused > 200                                                         # Adler-32 / DEFLATE structure catch damage
     with pytest.raises(hip.HipLibraryError):
         pngdec.decode_gray(bytes(good[:60]))
+
+
+def test_property_round_trip():
+    """hypothesis: any 8-bit gray image, any zlib level -> the encoder's input comes back"""
+    pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+    from hypothesis.extra import numpy as hnp
+
+    @settings(max_examples=150, deadline=None, derandomize=True)
+    @given(hnp.arrays(np.uint8, st.tuples(st.integers(1, 40), st.integers(1, 70))), st.integers(0, 9))
+    def check(img, level):
+        b = io.BytesIO()
+        Image.fromarray(img, "L").save(b, "PNG", compress_level=level)
+        assert np.array_equal(pngdec.decode_gray(b.getvalue()).numpy(), img)
+
+    check()
