@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """CRIS-R50 train-step throughput on MI355X (BASELINE.json metric: train-step samples/sec, CRIS-R50 416x416).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Started under torch.distributed.run (RANK / WORLD_SIZE in the environment) the process IS a rank;
+started plainly (`python bench.py --gpus 8`, no WORLD_SIZE) it re-launches itself under torch.distributed.run with N ranks on
+127.0.0.1 and a free port, and relays rank 0's JSON line.
 
 One step = the whole hot path on one synthetic RefCOCO-shaped batch already resident in HBM: weight repack, forward,
 BCE loss, backward, (N > 1: SyncBN exchanges + overlapped gradient all-reduce over RCCL), fused Adam, train metric.
@@ -59,6 +63,43 @@ def cpu_baseline(spec, batch, size, word_len, threads):
             "eval_forward_bs1_ms": eval_ms}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run this very command line under torch.distributed.run, one rank per GPU
+    (the driver's form for N > 1 is exactly this command); rank 0 prints the JSON line, its stdout is ours."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(rank, world, args):
+    """The launch protocol alone (CPU, gloo): rendezvous, barrier on both sides of a 'timed region', MAX over ranks, one line."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0, float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "max_rank_seen": int(t[1]), "seconds": float(t[0])}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -74,13 +115,26 @@ def main():
     ap.add_argument("--launch", default=None, choices=["graph", "cmdlist", "eager"], help="default: graph (N > 1: falls back to cmdlist if the capture fails on any rank)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     ap.add_argument("--shape-table", default=None, help="write the per-shape GEMM timing table (tsv) here")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="exercise only the multi-rank launch protocol (spawn, rendezvous, barrier, max-over-ranks, one JSON "
+                         "line from rank 0) without touching a GPU - what tests/test_bench_launch.py runs on the CPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    local = local % torch.cuda.device_count()          # (ranks may share a GPU only with --backend gloo)
+    if world != args.gpus:
+        sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d (torch.distributed.run --nproc-per-node must equal --gpus)" % (world, args.gpus))
+    if args.launch_check:
+        return launch_check(rank, world, args)
+    ngpu = torch.cuda.device_count()
+    if ngpu == 0:
+        sys.exit("bench.py: no GPU visible - the HIP path has no CPU fallback")
+    if world > ngpu and args.backend == "nccl":
+        sys.exit("bench.py: %d ranks but %d GPUs: RCCL needs one GPU per rank (ranks may share a GPU only with --backend gloo)" % (world, ngpu))
+    local = local % ngpu
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     comm = None

@@ -29,7 +29,18 @@ from .arch import ClipSpec, HeadSpec
 from .engine import Engine
 
 
+def strip_ddp_prefix(sd):
+    """The reference saves `model.state_dict()` of the DistributedDataParallel-wrapped model (train.py:192-204), so every key
+    of its checkpoints starts with `module.`, and test.py:74-78 loads them strictly into a DataParallel wrapper.  Accept
+    both spellings: a state_dict whose keys ALL carry the prefix is returned without it, anything else unchanged."""
+    keys = list(sd.keys())
+    if keys and all(k.startswith("module.") for k in keys):
+        return {k[len("module."):]: v for k, v in sd.items()}
+    return sd
+
+
 def split_state_dict(sd, device):
+    sd = strip_ddp_prefix(sd)
     params = {k: v.to(device).contiguous() for k, v in sd.items()
               if v.is_floating_point() and not k.endswith(("running_mean", "running_var"))}
     buffers = {k: v.to(device).contiguous() for k, v in sd.items() if k.endswith(("running_mean", "running_var"))}
@@ -252,20 +263,33 @@ class NativeTrainer:
         g1 = [n for n in names if n not in set(g0)]
         return g0, g1
 
-    def model_state_dict(self):
-        """the reference module's `state_dict()` (parameters + BatchNorm buffers; clones, on the CPU)"""
+    def model_state_dict(self, ddp_prefix=False):
+        """the reference module's `state_dict()` (parameters + BatchNorm buffers; clones, on the CPU).  `ddp_prefix=True`:
+        keys spelled `module.<name>` like the checkpoints the reference writes from its DDP-wrapped model
+        (train.py:192-204) - what its `--resume` (train.py:159-174) and test.py:74-78 load strictly."""
         e = self.engine
         out = {k: v.detach().cpu().clone() for k, v in e.P.items()}
         out.update({k: v.detach().cpu().clone() for k, v in e.Bf.items()})
         steps = self.step_idx
         for pfx in e.bn_prefixes:
             out[pfx + ".num_batches_tracked"] = torch.tensor(steps, dtype=torch.int64)
+        # reference key order (module order), not "parameters then buffers"
+        from .arch import build_param_tree
+        order = list(build_param_tree(e.clip, e.head).state_dict().keys())
+        assert set(order) == set(out.keys())
+        out = {k: out[k] for k in order}
+        if ddp_prefix:
+            out = {"module." + k: v for k, v in out.items()}
         return out
 
     def load_model_state_dict(self, sd):
         """parameters and BatchNorm buffers from a reference-keyed state_dict; the bf16 operand copies are re-packed on the
-        next forward"""
+        next forward.  Keys may carry DDP's `module.` prefix (reference checkpoints do)."""
         e = self.engine
+        sd = strip_ddp_prefix(sd)
+        missing = [k for k in list(e.P) + list(e.Bf) if k not in sd]
+        if missing:
+            raise KeyError("state_dict lacks %d keys, e.g. %s" % (len(missing), missing[:3]))
         for k, t in list(e.P.items()) + list(e.Bf.items()):
             t.copy_(sd[k].to(self.device))
         e.packs_current = False

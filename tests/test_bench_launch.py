@@ -1,0 +1,66 @@
+"""`python bench.py --gpus N` must start its own ranks when no launcher did (the driver's N = 1 form of the command with
+N > 1), and must run unchanged under torch.distributed.run.  CPU: the launch protocol only (`--launch-check`: spawn,
+rendezvous on 127.0.0.1, barriers, MAX over ranks, ONE JSON line from rank 0).  GPU: the real two-rank step with two ranks
+sharing the box's one GPU (gloo carries the collectives)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    return env
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith("{")]
+
+
+def test_plain_command_spawns_its_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--launch-check"], env=_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    assert lines[0]["n_gpus"] == 2 and lines[0]["max_rank_seen"] == 1 and lines[0]["steps"] == 3
+
+
+def test_under_torch_distributed_run():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", "2", "--launch-check"], env=_env(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 2
+
+
+def test_world_size_mismatch_is_refused():
+    env = _env()
+    env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="1")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--launch-check"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=120, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_end_to_end():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--backend", "gloo", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--no-kernel-timer"], env=_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]          # not NaN

@@ -1,4 +1,4 @@
-"""EXPERIMENTAL (not part of the default GPU suite: set CRIS_TEST_P2P=1): the peer-mailbox SyncBN exchange
+"""The peer-mailbox SyncBN exchange
 (csrc/p2p.hip, dist.PeerMailboxes) with two ranks sharing the one GPU of the test box - the mailboxes travel through HIP
 IPC exactly as between two GPUs.  (1) the primitive: sums over ranks, slot / generation reuse, device generation counter;
 (2) the whole trainer with CRIS_SYNCBN_P2P=1 equals the run that exchanges through torch.distributed."""
@@ -11,8 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("CRIS_TEST_P2P") != "1", reason="experimental path: CRIS_TEST_P2P=1 runs it")]
+pytestmark = [pytest.mark.gpu]
 
 
 def _free_port():
