@@ -1,23 +1,15 @@
-// Implicit-GEMM convolution / linear (forward and input-gradient) and weight-gradient kernels for gfx950.
+// Implicit-GEMM convolution / linear kernels (forward and input gradient) for gfx950: the 4-wave tile family and the skinny
+// kernel.  (The 8-wave ping-pong tiles for the largest layers are in gemm8.hip, the weight-gradient kernels in wgrad.hip.)
 //
-// Forward: out[M,N] = A_im2col[M,K] * Wt[N,K]^T, bf16 operands, v_mfma_f32_16x16x32_bf16, fp32 accumulate.
-//   tiles 128x128 / 64x128 / 128x64 (x 64 in K), 256 threads; operands go HBM/L2 -> LDS by LDS-DMA
-//   (global_load_lds_dwordx4; the im2col gather and the zero fill are per-lane SOURCE addresses, the LDS image stays
-//   lane-linear) through a 3-4 deep ring with counted vmcnt + one raw barrier per K-step; LDS rows of 128 B with the
-//   16-byte chunk index XOR-swizzled by (row>>1)&7 so that ds_read_b128 fragment reads of 16 consecutive rows hit 16
-//   distinct 16-B slots (conflict free, see MI355X_MICROARCH.md section LDS); XCD-aware tile order (consecutive tiles
-//   of one XCD share the A panel).  M <= 144 linear problems (text encoder, per-sample vectors) take a latency-oriented
-//   kernel: no staging, K split over the waves.
-// Wgrad: dW[N,K] = dY[M,N]^T * X_im2col[M,K]; the reduction dim (pixels) is the strided one for both
-//   operands, so each thread loads 8 rows x 16 B, transposes the 8x8 bf16 block in registers and writes
-//   m-contiguous 16-B chunks to LDS ([n][128 m] / [k][128 m], chunk XOR (row&15)); the gradient is kept in the GEMM
-//   layout [n][tap*C + c] (coalesced 64-B runs; the optimizer / cris_unpack_grads map it back to [n][c][tap]);
-//   split over m only as far as needed to fill the chip, fp32 atomics when split, plain stores otherwise.
-#include "common.h"
-#include "../../../include/cris_hip.h"
-#include <type_traits>
-
-#define BK 64
+// out[M,N] = A_im2col[M,K] * Wt[N,K]^T, bf16 operands, v_mfma_f32_32x32x16_bf16, fp32 accumulate.
+//   tiles 128x128 / 64x128 / 128x64 / 64x64 (x 64 in K), 256 threads; operands go HBM/L2 -> LDS by LDS-DMA
+//   (buffer_load_dwordx4 ... lds; the im2col gather and the zero fill are per-lane SOURCE offsets, the LDS image stays
+//   lane-linear) through a 2-3 deep ring with counted vmcnt + one raw barrier per K-step; LDS rows of 128 B with the
+//   16-byte chunk index XOR-swizzled by (row>>1)&7 so that ds_read_b128 fragment reads hit distinct 16-B slots
+//   (conflict free, see MI355X_MICROARCH.md section LDS); XCD-aware tile order (consecutive tiles of one XCD share a
+//   panel).  M <= 144 linear problems (text encoder, per-sample vectors) take a latency-oriented kernel: no staging, K
+//   split over the waves, deterministic LDS reduction.  No atomics anywhere.
+#include "gemm_common.h"
 // LDS-DMA ring depth per tile variant (K-steps in flight = depth - 1); -D switches for the A/B in profiles/r02_ab_experiments.md
 #ifndef ST_64x64
 #define ST_64x64 3
@@ -35,140 +27,8 @@
 
 
 // ------------------------------------------------------------------------------------------------
-// forward / dgrad
+// forward / dgrad (4-wave tiles; lds_off and gemm_epilogue live in gemm_common.h)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; rows are 128 B (64 bf16)
-    return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
-}
-
-// Epilogue of one wave tile (FM x FN fragments of 16x16, C/D layout col = lane&15, row = (lane>>4)*4 + r) whose first
-// row / column are row0 / col0: bias, activation, dropout, residual, bf16|fp32 store, head-split transposed copy and the
-// BatchNorm statistics partial `part` (sum, M2 about the part mean over the FM*16 rows of this wave tile).
-// EPI 1 ("lean"): compile-time promise of the plain conv / dgrad case (bf16 output, optional bf16 residual, optional
-// statistics; no bias, activation, dropout, transposed copy or fp32 I/O) - the epilogue every block of the ~190
-// convolution GEMMs per training step runs; the general form (EPI 0) costs thousands of instructions per wave.
-// EPI 2: the lean case plus a per-column bias and ReLU before (act 1) or after (act 3) the residual - the convolutions of
-// the inference path, whose BatchNorms are folded into weights and bias (cris/pytorch_amd/infer.py).
-template <int EPI, int MT, int FM, int FN, typename ACC>
-__device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, ACC (&acc)[FM][FN], int row0, int col0, int part,
-                                              int lane) {
-    // MT = 16: v_mfma_f32_16x16x32 C/D layout  col = lane&15, row = (lane>>4)*4 + r            (r = 0..3)
-    // MT = 32: v_mfma_f32_32x32x16 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (reg = 0..15)
-    // both: per lane NG groups of 4 consecutive rows of one column
-    constexpr bool LEAN = EPI != 0;
-    constexpr bool BIAS_ACT = EPI != 1;                        // bias / activation compiled in
-    constexpr int NG = MT == 16 ? 1 : 4;
-    const int fr = lane & (MT - 1), fg = lane / MT;
-    const bool has_drop = !LEAN && p.drop_thresh > 0u;
-    const uint32_t dkey = LEAN ? 0u : cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
-    const uint32_t dthr = p.drop_thresh;
-    const float dscale = has_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
-    const int Hh = (!LEAN && p.outT) ? p.T_E / 64 : 1;
-    const int part_cnt = max(0, min(FM * MT, p.M - row0));
-    // residual reads and output writes go through raw buffer descriptors: an element outside the problem (row >= M,
-    // column >= N) is an out-of-range offset - reads return 0, writes are dropped - so the epilogue has no per-element
-    // branches and its residual loads are issued together instead of one wait per element
-    const bool has_res = p.resid != nullptr, has_out = p.out != nullptr;
-    const bool res_f32 = !LEAN && p.resid_f32, out_f32 = !LEAN && p.out_f32;
-    const int act = BIAS_ACT ? p.act : 0;
-    const unsigned res_es = res_f32 ? 4u : 2u, out_es = out_f32 ? 4u : 2u;
-    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.resid), 0, has_res ? (int)((size_t)p.M * p.ldr * res_es) : 0, CRIS_BUF_FLAGS);
-    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, has_out ? (int)((size_t)p.M * p.ldc * out_es) : 0,
-                                                                        CRIS_BUF_FLAGS);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int col = col0 + j * MT + fr;
-        const bool cvalid = col < p.N;
-        const float bias = (BIAS_ACT && p.bias) ? p.bias[cvalid ? col : 0] : 0.f;
-        float vals[FM * NG][4];
-#pragma unroll
-        for (int ig = 0; ig < FM * NG; ++ig) {
-            const int i = ig / NG, g = ig % NG;
-            const int rowb = row0 + i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4);
-            float v[4], rres[4] = {0.f, 0.f, 0.f, 0.f};
-            if (has_res) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = rowb + r;
-                    const unsigned off = (cvalid && m < p.M) ? ((unsigned)m * (unsigned)p.ldr + (unsigned)(p.r_coff + col)) * res_es : CRIS_OOB;
-                    if (res_f32) rres[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
-                    else rres[r] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsR, off, 0, 0));
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = rowb + r;
-                float x = acc[i][j][g * 4 + r] + bias;
-                if (act == 1) x = fmaxf(x, 0.f);
-                else if (!LEAN && act == 2) x = x / (1.0f + __expf(-1.702f * x));
-                if (has_drop) x = cris_keep(dkey, (uint32_t)m * (uint32_t)p.N + (uint32_t)col, dthr) ? x * dscale : 0.f;
-                const bool valid = cvalid && m < p.M;
-                x += rres[r];
-                if (act == 3) x = fmaxf(x, 0.f);
-                if (!valid) x = 0.f;
-                v[r] = x;
-                vals[ig][r] = x;
-                if (has_out) {
-                    const unsigned off = valid ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(p.c_coff + col)) * out_es : CRIS_OOB;
-                    if (out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(x), rsO, off, 0, 0);
-                }
-            }
-            if (!LEAN && p.outT && cvalid && rowb < p.M) {
-                const int sec = col / p.T_E;
-                const int e = col - sec * p.T_E;
-                const int h = e >> 6, d = e & 63;
-                bf16_t* base = p.outT + (size_t)sec * p.T_sec_stride;
-                if ((p.T_L & 3) == 0 && rowb + 3 < p.M) {
-                    const int b = rowb / p.T_L, l = rowb - b * p.T_L;
-                    uint2 w;
-                    w.x = pack2bf(v[0], v[1]);
-                    w.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(base + ((size_t)(b * Hh + h) * 64 + d) * p.T_Lpad + l) = w;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = rowb + r;
-                        if (m < p.M) {
-                            const int b = m / p.T_L, l = m - b * p.T_L;
-                            base[((size_t)(b * Hh + h) * 64 + d) * p.T_Lpad + l] = f2bf(v[r]);
-                        }
-                    }
-                }
-            }
-        }
-        if (p.colsum) {
-            // BatchNorm statistics, robust + deterministic: per wave row-block (sum, M2 about the block mean);
-            // cris_bn_finalize merges the blocks with Chan's formula.  No atomics, no E[x^2]-E[x]^2 cancellation.
-            float s1 = 0.f;
-#pragma unroll
-            for (int ig = 0; ig < FM * NG; ++ig)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s1 += vals[ig][r];                // invalid rows hold 0
-            if (MT == 16) s1 += __shfl_xor(s1, 16, 64);                       // lanes sharing this column
-            s1 += __shfl_xor(s1, 32, 64);
-            const float mu = part_cnt > 0 ? s1 / (float)part_cnt : 0.f;
-            float q = 0.f;
-#pragma unroll
-            for (int ig = 0; ig < FM * NG; ++ig)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int i = ig / NG, g = ig % NG;
-                    const int m = row0 + i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4) + r;
-                    const float d = vals[ig][r] - mu;
-                    q += (m < p.M) ? d * d : 0.f;
-                }
-            if (MT == 16) q += __shfl_xor(q, 16, 64);
-            q += __shfl_xor(q, 32, 64);
-            if (fg == 0 && cvalid && part_cnt > 0) {          // parts = ceil(M / rows-per-part): none beyond the last row
-                p.colsum[(size_t)part * p.N + col] = s1;
-                p.colsq[(size_t)part * p.N + col] = q;
-            }
-        }
-    }
-}
-
 // Main kernel: BM x BN x 64 tiles, 4 waves, operands staged by LDS-DMA (global_load_lds_dwordx4, 1 KB per wave
 // instruction = 8 tile rows of 128 B) into a ring of STAGES LDS buffers with STAGES-1 K-steps in flight: one counted
 // s_waitcnt vmcnt + one raw s_barrier per K-step, never a full drain inside the loop.  The LDS image is lane-linear
@@ -473,12 +333,38 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
     }
 }
 
-// tile selection (host).  Returns the rows per BatchNorm-statistics partial of the chosen variant.
-enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128 };
+// tile selection (host)
+enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_COUNT };
+int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s);       // gemm8.hip
+
+static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
+    const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
+    switch (v) {
+        case V_SKINNY1: return lin && p.M <= 16;
+        case V_SKINNY9: return lin && p.M <= SKINNY_MAX_M;
+        case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: return (p.C & 63) == 0;
+        default: return v >= 0 && v < V_COUNT;
+    }
+}
+
 static int pick_variant(const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
     if (lin && p.M <= 16) return V_SKINNY1;
     if (lin && p.M <= SKINNY_MAX_M) return V_SKINNY9;
+    // 8-wave ping-pong tiles (gemm8.hip) for the largest problems: one block per CU, so they need a few hundred tiles and a
+    // reduction long enough to amortise the 5-piece prologue.  CRIS_GEMM8_MIN_TILES = least number of tiles (0 = never).
+    static const int g8_min = cris_env_int("CRIS_GEMM8_MIN_TILES", 0);
+    static const int g8_min_k = cris_env_int("CRIS_GEMM8_MIN_K", 1024);
+    if (g8_min > 0 && (p.C & 63) == 0 && p.K >= g8_min_k) {
+        if (p.N > 128) {
+            const long t256 = (long)cris_cdiv(p.M, 256) * cris_cdiv(p.N, 256);
+            // a grid of 1.0 .. 1.5 waves of 256x256 tiles idles half the chip in its second round: halve the rows instead
+            if (t256 >= g8_min && !(t256 > 256 && t256 <= 400)) return V_8W_256x256;
+            if ((long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 256) >= g8_min) return V_8W_128x256;
+        } else if (p.N > 64) {
+            if ((long)cris_cdiv(p.M, 256) >= g8_min) return V_8W_256x128;
+        }
+    }
     if (p.N <= 64) return V_128x64;
     // too few 128x128 tiles to occupy the chip: halve the tile (2 blocks of 72 KB LDS fit a CU).  Mid-size problems
     // (M <= 8192 rows: layers 3-4, neck, decoder) never take the 128x128 tile even when N is wide: measured on the decoder FFN
@@ -496,21 +382,39 @@ static int pick_variant(const cris_conv_gemm_params& p) {
     }
     return V_128x128;
 }
+// rows per BatchNorm-statistics partial of a variant (= rows of its wave tile)
 static int variant_stat_rows(int v) {
     switch (v) {
         case V_SKINNY1: return 16;
         case V_SKINNY9: return 16;
         case V_128x128: return 64;
+        case V_8W_256x256: case V_8W_256x128: return 128;
+        case V_8W_128x256: return 64;
         default: return 32;
     }
 }
+static int resolve_variant(const cris_conv_gemm_params& p, int variant) {
+    if (variant < 0) return pick_variant(p);
+    return variant_applicable(variant, p) ? variant : -1;
+}
 extern "C" int cris_conv_gemm_stat_rows(const cris_conv_gemm_params* p) { return variant_stat_rows(pick_variant(*p)); }
+extern "C" int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, int variant) {
+    const int v = resolve_variant(*p, variant);
+    return v < 0 ? -1 : variant_stat_rows(v);
+}
+extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
+extern "C" const char* cris_conv_gemm_variant_name(int v) {
+    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256"};
+    return (v >= 0 && v < V_COUNT) ? names[v] : "?";
+}
 
 static int set_lds(const void* kern, int bytes) {
     return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
+extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) { return cris_conv_gemm_variant(pp, -1, stream); }
+
+extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int variant, void* stream) {
     const cris_conv_gemm_params& p = *pp;
     CRIS_CHECK_ARG(p.A && p.Wt, "null operand");
     CRIS_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty problem");
@@ -555,7 +459,11 @@ extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) {
     }
     const bool plain = p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32);
     const int lean = !plain ? 0 : (!p.bias && p.act == 0) ? 1 : (p.act == 0 || p.act == 1 || p.act == 3) ? 2 : 0;
-    switch (pick_variant(p)) {
+    const int v = resolve_variant(p, variant);
+    CRIS_CHECK_ARG(v >= 0, "tile variant not applicable to this problem");
+    switch (v) {
+        case V_8W_256x256: case V_8W_256x128: case V_8W_128x256:
+            return cris_launch_gemm8(v - V_8W_256x256, p, lean, s);
         case V_SKINNY1:
             hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);
             break;

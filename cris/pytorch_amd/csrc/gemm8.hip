@@ -1,0 +1,329 @@
+// 8-wave "ping-pong" implicit-GEMM tiles for the largest convolution / linear problems (forward and input gradient) on gfx950.
+//
+// Why a second kernel family: the 4-wave tiles of gemm.hip top out near 0.9 PFLOP/s - every block re-fetches its operand
+// panels through the L2 -> LDS path, whose delivered rate (~11-14 TB/s over the chip) caps a BM x BN tile at roughly
+// BM*BN/(BM+BN) flop per byte, and their one-barrier-per-K-step loop leaves the matrix pipe idle while a wave reads its
+// fragments.  Here a block is 512 threads = 8 waves = TWO wave groups of four (wave w and w+4 share a SIMD) on a 256x256,
+// 256x128 or 128x256 tile (one block per CU, 128-144 KB of LDS):
+//   * each group owns half of the tile's rows; a K-tile (64 deep) is worked off in phases of 8 v_mfma_f32_32x32x16_bf16
+//     (a 64x32 sub-block of the wave tile x K 64); a phase = MEM segment {issue the LDS-DMAs of one staging piece, read
+//     this phase's fragments from LDS, counted wait} - s_barrier - MFMA segment {8 MFMAs at raised priority} - s_barrier;
+//   * group 1 runs ONE barrier behind group 0, so on every SIMD one wave is in its MFMA segment while its partner is in
+//     its MEM segment: the matrix pipe always has an owner and the fragment reads / DMA issue of one wave hide under the
+//     MFMAs of the other (MI355X_MICROARCH.md "Two waves per SIMD": alternate matrix-heavy with memory segments);
+//   * operands travel HBM/L2 -> LDS by LDS-DMA exactly as in gemm.hip (im2col gather and zero fill as per-lane SOURCE
+//     offsets through a raw buffer descriptor, lane-linear LDS image, XOR swizzle on the source side), but in PIECES of
+//     128 tile rows (the rows the next phases need first), issued 3-4 phases ahead of their first read; waits are counted
+//     (s_waitcnt vmcnt(6) / (8): three or four pieces stay in flight across the barriers), never a drain in the loop.
+// Hazards, by construction (ticks = barrier intervals; group 0 runs MEM_p at tick 2p, group 1 at tick 2p+1):
+//   RAW  a piece read in phase p is waited for (own vmcnt) at the END of MEM_{p-1} by every wave: both groups have passed
+//        that wait before the barrier in front of group 0's MEM_p;
+//   WAR  every wave's LDS reads are complete (lgkmcnt(0)) before the barrier that ends its MEM segment, and the DMA that
+//        overwrites a slot is issued at least one phase after the slot's last reading phase.
+// Only convolutions with C % 64 == 0 (a 64-wide K-tile lies in one tap; every large layer of the networks) come here.
+#include "gemm_common.h"
+
+#define CRIS_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | ((((N) >> 4) & 3) << 14) | (0x7 << 4))
+#define CRIS_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xF | (3 << 14) | (0x7 << 4))
+#define CRIS_BARRIER()                              \
+    do {                                            \
+        __builtin_amdgcn_sched_barrier(0);          \
+        __builtin_amdgcn_s_barrier();               \
+        __builtin_amdgcn_sched_barrier(0);          \
+    } while (0)
+
+// PA x PB sub-blocks of 64 x 32 per wave tile; wave grid 2 (M) x 4 (N):
+//   (2,2): 256x256 tile, 4 phases per K-tile, 2 K-tile buffers (128 KB);  (2,1): 256x128;  (1,2): 128x256 - 2 phases per
+//   K-tile, 3 K-tile buffers (144 KB)
+template <int PA, int PB, int EPI>
+__global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_params p) {
+    constexpr int WTM = PA * 64, WTN = PB * 32;
+    constexpr int BM = 2 * WTM, BN = 4 * WTN;
+    constexpr int FM = PA * 2, FN = PB;
+    constexpr bool S4 = PA == 2 && PB == 2;
+    constexpr int NBUF = S4 ? 2 : 3;
+    constexpr int A_BYTES = BM * 128, TILE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // XCD-aware tile order, as in gemm.hip
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tile_m, tile_n;
+    if ((long)p.N * p.K > (1L << 20)) {
+        tile_n = bid / tiles_m;
+        tile_m = bid - tile_n * tiles_m;
+    } else {
+        tile_m = bid / tiles_n;
+        tile_n = bid - tile_m * tiles_n;
+    }
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- DMA roles.  A piece a (a < PA) = tile rows g*WTM + a*64 + [0,64) of both groups g: two 64-row units, this wave
+    // moves rows +wave*8 .. +8 of each (lane>>3 = row, lane&7 = 16-B slot).  B piece b = tile columns c*WTN + b*32 + [0,32)
+    // of the four wave columns c: unit v covers c = 2v, 2v+1; this wave's rows: c = 2v + wave/4, + (wave%4)*8.
+    const int rsub = lane >> 3;
+    const int kc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);       // logical K-chunk of this lane's slot: slot ^ ((row>>1)&7)
+    const unsigned lane_k = (unsigned)kc * 16u;
+    const int OHW = p.OH * p.OW;
+    int a_pix[PA * 2], a_ih[PA * 2], a_iw[PA * 2];
+#pragma unroll
+    for (int i = 0; i < PA * 2; ++i) {
+        const int m = m0 + (i & 1) * WTM + (i >> 1) * 64 + wave * 8 + rsub;          // i = a*2 + g
+        if (m < p.M) {
+            const int b = m / OHW;
+            const int r = m - b * OHW;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            a_pix[i] = b * p.H * p.W;
+            a_ih[i] = oh * p.stride - p.pad;
+            a_iw[i] = ow * p.stride - p.pad;
+        } else {
+            a_pix[i] = 0; a_ih[i] = -(1 << 28); a_iw[i] = 0;
+        }
+    }
+    unsigned b_off[PB * 2];
+#pragma unroll
+    for (int i = 0; i < PB * 2; ++i) {                                                 // i = b*2 + v
+        const int n = n0 + (2 * (i & 1) + (wave >> 2)) * WTN + (i >> 1) * 32 + (wave & 3) * 8 + rsub;
+        b_off[i] = (unsigned)n * (unsigned)p.ldb * 2u;
+    }
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.A), 0, (int)((size_t)p.Bn * p.H * p.W * p.lda * 2), CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.Wt), 0, (int)((size_t)p.N * p.ldb * 2), CRIS_BUF_FLAGS);
+
+    // per piece stream: K position (tap, channel) of the next K-tile to stage and the ring buffer it goes to (wave-uniform)
+    int sa_c[PA], sa_kh[PA], sa_kw[PA], sa_k[PA], sa_buf[PA], sb_k[PB], sb_buf[PB];
+#pragma unroll
+    for (int a = 0; a < PA; ++a) { sa_c[a] = 0; sa_kh[a] = 0; sa_kw[a] = 0; sa_k[a] = 0; sa_buf[a] = 0; }
+#pragma unroll
+    for (int b = 0; b < PB; ++b) { sb_k[b] = 0; sb_buf[b] = 0; }
+    unsigned a_base[PA * 2];
+
+    auto issue_A = [&](int a) {
+        if (sa_c[a] == 0) {                                       // tap changed: new pixel offsets / padding validity
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int i = a * 2 + g;
+                const int ih = a_ih[i] + sa_kh[a], iw = a_iw[i] + sa_kw[a];
+                const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                a_base[i] = ok ? ((unsigned)(a_pix[i] + ih * p.W + iw) * (unsigned)p.lda + (unsigned)p.a_coff) * 2u + lane_k : CRIS_OOB;
+            }
+        }
+        const unsigned kvm = sa_k[a] < p.K ? 0u : CRIS_OOB;      // K-tiles beyond K read zeros (uniform vmcnt arithmetic)
+        const unsigned ca = (unsigned)sa_c[a] * 2u;
+        unsigned char* dst = smem + sa_buf[a] + (a * 64 + wave * 8) * 128;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const unsigned off = (a_base[a * 2 + g] + ca) | kvm;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(dst + g * WTM * 128), 16, off, 0, 0, 0);
+        }
+        sa_k[a] += BK;
+        sa_c[a] += BK;
+        if (sa_c[a] >= p.C) {
+            sa_c[a] = 0;
+            if (++sa_kw[a] == p.KW) { sa_kw[a] = 0; ++sa_kh[a]; }
+        }
+        sa_buf[a] += TILE_BYTES;
+        if (sa_buf[a] == NBUF * TILE_BYTES) sa_buf[a] = 0;
+    };
+    auto issue_B = [&](int b) {
+        const unsigned kvm = sb_k[b] < p.K ? 0u : CRIS_OOB;
+        const unsigned kb = (unsigned)sb_k[b] * 2u + lane_k;
+        unsigned char* dst = smem + sb_buf[b] + A_BYTES + ((wave >> 2) * WTN + b * 32 + (wave & 3) * 8) * 128;
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            const unsigned off = (b_off[b * 2 + v] + kb) | kvm;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(dst + v * 2 * WTN * 128), 16, off, 0, 0, 0);
+        }
+        sb_k[b] += BK;
+        sb_buf[b] += TILE_BYTES;
+        if (sb_buf[b] == NBUF * TILE_BYTES) sb_buf[b] = 0;
+    };
+
+    // ---- fragment reads (v_mfma_f32_32x32x16_bf16 A/B layout: row = lane&31, k = (lane>>5)*8 .. +8 of a 16-deep slice)
+    const int fr = lane & 31, fh = lane >> 5;
+    const int swz = (fr >> 1) & 7;                    // rows differ from fr by multiples of 32: same swizzle term
+    int cx[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) cx[ks] = (((ks * 2 + fh) ^ swz) & 7) << 4;
+    const int rowA = (wm * WTM + fr) * 128, rowB = A_BYTES + (wn * WTN + fr) * 128;
+    int rbuf = 0;                                     // ring buffer of the K-tile being computed
+    bf16x8 af[2][4], bfr[4];
+    auto read_A = [&](int a) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                af[i][ks] = *reinterpret_cast<const bf16x8*>(smem + rbuf + rowA + (a * 64 + i * 32) * 128 + cx[ks]);
+            }
+        }
+    };
+    auto read_B = [&](int b) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bfr[ks] = *reinterpret_cast<const bf16x8*>(smem + rbuf + rowB + b * 32 * 128 + cx[ks]);
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // one 64x32 sub-block x K 64: two accumulators, interleaved so that dependent MFMAs are one instruction apart.  The empty
+    // asm statements pin the MFMAs to their segment: an MFMA is a pure register operation, and without them hipcc sinks the
+    // MFMAs of one phase across the barriers into the next phase's segment (seen in the disassembly) - which would put the
+    // two wave groups' matrix work back to back on the same SIMD instead of alternating it with their memory segments.
+#define CRIS_MFMA_SEG(a, b)                                                                                             \
+    do {                                                                                                                \
+        asm volatile("" : "+v"(acc[(a) * 2 + 0][b]), "+v"(acc[(a) * 2 + 1][b]));                                        \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
+            acc[(a) * 2 + 0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ks], bfr[ks], acc[(a) * 2 + 0][b], 0, 0, 0); \
+            acc[(a) * 2 + 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ks], bfr[ks], acc[(a) * 2 + 1][b], 0, 0, 0); \
+        }                                                                                                               \
+        asm volatile("" : "+v"(acc[(a) * 2 + 0][b]), "+v"(acc[(a) * 2 + 1][b]));                                        \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+    } while (0)
+
+    const int nk = p.K / BK;
+    if constexpr (S4) {
+        // piece order of the stream: A0 B0 B1 A1 | A0 B0 B1 A1 ...; phase q of K-tile t issues B0(t+1), B1(t+1), A1(t+1), A0(t+2)
+        issue_A(0); issue_B(0); issue_B(1); issue_A(1); issue_A(0);
+        CRIS_WAIT_VM_LGKM0(6);                      // A0(0), B0(0) of this wave have landed
+        CRIS_BARRIER();
+        if (wm == 1) CRIS_BARRIER();                // group 1 runs one barrier behind from here on
+        for (int kt = 0; kt < nk; ++kt) {
+            // q1: sub-block (0,0)
+            issue_B(0);
+            read_A(0);
+            read_B(0);
+            CRIS_WAIT_VM_LGKM0(6);                  // fragments in registers; B1(kt) landed (3 pieces stay in flight)
+            CRIS_BARRIER();
+            CRIS_MFMA_SEG(0, 0);
+            CRIS_BARRIER();
+            // q2: (0,1)
+            issue_B(1);
+            read_B(1);
+            CRIS_WAIT_VM_LGKM0(6);                  // A1(kt) landed
+            CRIS_BARRIER();
+            CRIS_MFMA_SEG(0, 1);
+            CRIS_BARRIER();
+            // q3: (1,1)
+            issue_A(1);
+            read_A(1);
+            CRIS_WAIT_LGKM0();
+            CRIS_BARRIER();
+            CRIS_MFMA_SEG(1, 1);
+            CRIS_BARRIER();
+            // q4: (1,0)
+            issue_A(0);
+            read_B(0);
+            CRIS_WAIT_VM_LGKM0(6);                  // A0(kt+1), B0(kt+1) landed
+            CRIS_BARRIER();
+            CRIS_MFMA_SEG(1, 0);
+            CRIS_BARRIER();
+            rbuf = rbuf == 0 ? TILE_BYTES : 0;
+        }
+    } else if constexpr (PA == 2) {
+        // 256x128: pieces A0 B A1 | A0 B A1 ...; q1 issues A1(t+1), A0(t+2); q2 issues B(t+2)
+        issue_A(0); issue_B(0); issue_A(1); issue_A(0); issue_B(0);
+        CRIS_WAIT_VM_LGKM0(6);
+        CRIS_BARRIER();
+        if (wm == 1) CRIS_BARRIER();
+        for (int kt = 0; kt < nk; ++kt) {
+            issue_A(1);
+            issue_A(0);
+            read_A(0);
+            read_B(0);
+            CRIS_WAIT_VM_LGKM0(8);                  // A1(kt) landed (4 pieces stay in flight)
+            CRIS_BARRIER();
+            CRIS_MFMA_SEG(0, 0);
+            CRIS_BARRIER();
+            issue_B(0);
+            read_A(1);
+            CRIS_WAIT_VM_LGKM0(6);                  // A0(kt+1), B(kt+1) landed
+            CRIS_BARRIER();
+            CRIS_MFMA_SEG(1, 0);
+            CRIS_BARRIER();
+            rbuf += TILE_BYTES;
+            if (rbuf == NBUF * TILE_BYTES) rbuf = 0;
+        }
+    } else {
+        // 128x256: pieces B0 A B1 | B0 A B1 ...; q1 issues B1(t+1), B0(t+2); q2 issues A(t+2)
+        issue_B(0); issue_A(0); issue_B(1); issue_B(0); issue_A(0);
+        CRIS_WAIT_VM_LGKM0(6);
+        CRIS_BARRIER();
+        if (wm == 1) CRIS_BARRIER();
+        for (int kt = 0; kt < nk; ++kt) {
+            issue_B(1);
+            issue_B(0);
+            read_A(0);
+            read_B(0);
+            CRIS_WAIT_VM_LGKM0(8);
+            CRIS_BARRIER();
+            CRIS_MFMA_SEG(0, 0);
+            CRIS_BARRIER();
+            issue_A(0);
+            read_B(1);
+            CRIS_WAIT_VM_LGKM0(6);
+            CRIS_BARRIER();
+            CRIS_MFMA_SEG(0, 1);
+            CRIS_BARRIER();
+            rbuf += TILE_BYTES;
+            if (rbuf == NBUF * TILE_BYTES) rbuf = 0;
+        }
+    }
+    if (wm == 0) CRIS_BARRIER();                    // same number of barriers for every wave
+    CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
+#undef CRIS_MFMA_SEG
+
+    gemm_epilogue<EPI, 32, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * 2 + wm, lane);
+}
+
+static int set_lds8(const void* kern, int bytes) {
+    return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+// launcher used by cris_conv_gemm (gemm.hip): variant 0 = 256x256, 1 = 256x128, 2 = 128x256; epi as in gemm.hip
+int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s) {
+    typedef void (*kern_t)(const cris_conv_gemm_params);
+    static const kern_t k[3][3] = {
+        {conv_gemm8_kernel<2, 2, 0>, conv_gemm8_kernel<2, 2, 1>, conv_gemm8_kernel<2, 2, 2>},
+        {conv_gemm8_kernel<2, 1, 0>, conv_gemm8_kernel<2, 1, 1>, conv_gemm8_kernel<2, 1, 2>},
+        {conv_gemm8_kernel<1, 2, 0>, conv_gemm8_kernel<1, 2, 1>, conv_gemm8_kernel<1, 2, 2>}};
+    static const int lds[3] = {2 * (256 + 256) * 128, 3 * (256 + 128) * 128, 3 * (128 + 256) * 128};
+    static const int bm[3] = {256, 256, 128}, bn[3] = {256, 128, 256};
+    static const int ready = [&]() {
+        int rc = 0;
+        for (int v = 0; v < 3; ++v)
+            for (int e = 0; e < 3; ++e) rc |= set_lds8((const void*)k[v][e], lds[v]);
+        return rc;
+    }();
+    if (ready != 0) {
+        cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, ready);
+        return ready;
+    }
+    CRIS_CHECK_ARG(variant >= 0 && variant < 3, "unknown 8-wave variant");
+    CRIS_CHECK_ARG((p.C & 63) == 0, "8-wave tiles need C % 64 == 0");
+    hipLaunchKernelGGL(k[variant][epi], dim3(cris_cdiv(p.M, bm[variant]) * cris_cdiv(p.N, bn[variant])), dim3(512), lds[variant], s, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}

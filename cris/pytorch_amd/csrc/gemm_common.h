@@ -1,0 +1,141 @@
+// Pieces shared by the implicit-GEMM kernels (gemm.hip: 4-wave tiles, skinny kernel; gemm8.hip: 8-wave ping-pong tiles):
+// the XOR-swizzled LDS row layout and the epilogue of one wave tile.
+#pragma once
+#include "common.h"
+#include "../../../include/cris_hip.h"
+#include <type_traits>
+
+#define BK 64
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; rows are 128 B (64 bf16)
+    return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
+}
+
+// Epilogue of one wave tile (FM x FN fragments of 16x16, C/D layout col = lane&15, row = (lane>>4)*4 + r) whose first
+// row / column are row0 / col0: bias, activation, dropout, residual, bf16|fp32 store, head-split transposed copy and the
+// BatchNorm statistics partial `part` (sum, M2 about the part mean over the FM*16 rows of this wave tile).
+// EPI 1 ("lean"): compile-time promise of the plain conv / dgrad case (bf16 output, optional bf16 residual, optional
+// statistics; no bias, activation, dropout, transposed copy or fp32 I/O) - the epilogue every block of the ~190
+// convolution GEMMs per training step runs; the general form (EPI 0) costs thousands of instructions per wave.
+// EPI 2: the lean case plus a per-column bias and ReLU before (act 1) or after (act 3) the residual - the convolutions of
+// the inference path, whose BatchNorms are folded into weights and bias (cris/pytorch_amd/infer.py).
+template <int EPI, int MT, int FM, int FN, typename ACC>
+__device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, ACC (&acc)[FM][FN], int row0, int col0, int part,
+                                              int lane) {
+    // MT = 16: v_mfma_f32_16x16x32 C/D layout  col = lane&15, row = (lane>>4)*4 + r            (r = 0..3)
+    // MT = 32: v_mfma_f32_32x32x16 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (reg = 0..15)
+    // both: per lane NG groups of 4 consecutive rows of one column
+    constexpr bool LEAN = EPI != 0;
+    constexpr bool BIAS_ACT = EPI != 1;                        // bias / activation compiled in
+    constexpr int NG = MT == 16 ? 1 : 4;
+    const int fr = lane & (MT - 1), fg = lane / MT;
+    const bool has_drop = !LEAN && p.drop_thresh > 0u;
+    const uint32_t dkey = LEAN ? 0u : cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
+    const uint32_t dthr = p.drop_thresh;
+    const float dscale = has_drop ? 1.0f / (1.0f - p.drop_p) : 1.0f;
+    const int Hh = (!LEAN && p.outT) ? p.T_E / 64 : 1;
+    const int part_cnt = max(0, min(FM * MT, p.M - row0));
+    // residual reads and output writes go through raw buffer descriptors: an element outside the problem (row >= M,
+    // column >= N) is an out-of-range offset - reads return 0, writes are dropped - so the epilogue has no per-element
+    // branches and its residual loads are issued together instead of one wait per element
+    const bool has_res = p.resid != nullptr, has_out = p.out != nullptr;
+    const bool res_f32 = !LEAN && p.resid_f32, out_f32 = !LEAN && p.out_f32;
+    const int act = BIAS_ACT ? p.act : 0;
+    const unsigned res_es = res_f32 ? 4u : 2u, out_es = out_f32 ? 4u : 2u;
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.resid), 0, has_res ? (int)((size_t)p.M * p.ldr * res_es) : 0, CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, has_out ? (int)((size_t)p.M * p.ldc * out_es) : 0,
+                                                                        CRIS_BUF_FLAGS);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = col0 + j * MT + fr;
+        const bool cvalid = col < p.N;
+        const float bias = (BIAS_ACT && p.bias) ? p.bias[cvalid ? col : 0] : 0.f;
+        float vals[FM * NG][4];
+#pragma unroll
+        for (int ig = 0; ig < FM * NG; ++ig) {
+            const int i = ig / NG, g = ig % NG;
+            const int rowb = row0 + i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4);
+            float v[4], rres[4] = {0.f, 0.f, 0.f, 0.f};
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = rowb + r;
+                    const unsigned off = (cvalid && m < p.M) ? ((unsigned)m * (unsigned)p.ldr + (unsigned)(p.r_coff + col)) * res_es : CRIS_OOB;
+                    if (res_f32) rres[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
+                    else rres[r] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsR, off, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = rowb + r;
+                float x = acc[i][j][g * 4 + r] + bias;
+                if (act == 1) x = fmaxf(x, 0.f);
+                else if (!LEAN && act == 2) x = x / (1.0f + __expf(-1.702f * x));
+                if (has_drop) x = cris_keep(dkey, (uint32_t)m * (uint32_t)p.N + (uint32_t)col, dthr) ? x * dscale : 0.f;
+                const bool valid = cvalid && m < p.M;
+                x += rres[r];
+                if (act == 3) x = fmaxf(x, 0.f);
+                if (!valid) x = 0.f;
+                v[r] = x;
+                vals[ig][r] = x;
+                if (has_out) {
+                    const unsigned off = valid ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(p.c_coff + col)) * out_es : CRIS_OOB;
+                    if (out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(x), rsO, off, 0, 0);
+                }
+            }
+            if (!LEAN && p.outT && cvalid && rowb < p.M) {
+                const int sec = col / p.T_E;
+                const int e = col - sec * p.T_E;
+                const int h = e >> 6, d = e & 63;
+                bf16_t* base = p.outT + (size_t)sec * p.T_sec_stride;
+                if ((p.T_L & 3) == 0 && rowb + 3 < p.M) {
+                    const int b = rowb / p.T_L, l = rowb - b * p.T_L;
+                    uint2 w;
+                    w.x = pack2bf(v[0], v[1]);
+                    w.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(base + ((size_t)(b * Hh + h) * 64 + d) * p.T_Lpad + l) = w;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = rowb + r;
+                        if (m < p.M) {
+                            const int b = m / p.T_L, l = m - b * p.T_L;
+                            base[((size_t)(b * Hh + h) * 64 + d) * p.T_Lpad + l] = f2bf(v[r]);
+                        }
+                    }
+                }
+            }
+        }
+        if (p.colsum) {
+            // BatchNorm statistics, robust + deterministic: per wave row-block (sum, M2 about the block mean);
+            // cris_bn_finalize merges the blocks with Chan's formula.  No atomics, no E[x^2]-E[x]^2 cancellation.
+            float s1 = 0.f;
+#pragma unroll
+            for (int ig = 0; ig < FM * NG; ++ig)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s1 += vals[ig][r];                // invalid rows hold 0
+            if (MT == 16) s1 += __shfl_xor(s1, 16, 64);                       // lanes sharing this column
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mu = part_cnt > 0 ? s1 / (float)part_cnt : 0.f;
+            float q = 0.f;
+#pragma unroll
+            for (int ig = 0; ig < FM * NG; ++ig)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = ig / NG, g = ig % NG;
+                    const int m = row0 + i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4) + r;
+                    const float d = vals[ig][r] - mu;
+                    q += (m < p.M) ? d * d : 0.f;
+                }
+            if (MT == 16) q += __shfl_xor(q, 16, 64);
+            q += __shfl_xor(q, 32, 64);
+            if (fg == 0 && cvalid && part_cnt > 0) {          // parts = ceil(M / rows-per-part): none beyond the last row
+                p.colsum[(size_t)part * p.N + col] = s1;
+                p.colsq[(size_t)part * p.N + col] = q;
+            }
+        }
+    }
+}
+

@@ -216,6 +216,10 @@ _SIGS = {
     "cris_pack_blocks": (I, [P]),
     "cris_pack_block_elems": (I, []),
     "cris_conv_gemm_stat_rows": (I, [P]),
+    "cris_conv_gemm_variant": (I, [P, I, P]),
+    "cris_conv_gemm_variant_stat_rows": (I, [P, I]),
+    "cris_conv_gemm_num_variants": (I, []),
+    "cris_conv_gemm_variant_name": (C.c_char_p, [I]),
     "cris_bn_partials_rows": (I, [I]),
     "cris_bn_finalize": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P, P]),
     "cris_bn_sync_pack": (I, [P, P, P, F, I, P]),

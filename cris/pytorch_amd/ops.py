@@ -80,9 +80,10 @@ NO_DROP = Drop(0.0, 0, 0)
 
 def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None, act=0, resid=None, ldr=None, r_coff=0,
               out=None, ldc=None, c_coff=0, outT=None, T_L=0, T_Lpad=0, T_E=0, T_sec_stride=0, stats=False,
-              drop: Drop = NO_DROP):
+              drop: Drop = NO_DROP, variant: int = -1):
     """out[M,N] = epi(A_im2col @ Wt^T).  A bf16 NHWC buffer (row stride lda), Wt bf16 [N][ldb].
-    stats=True: also returns the BatchNorm statistics partials (Stats) of the output columns."""
+    stats=True: also returns the BatchNorm statistics partials (Stats) of the output columns.
+    variant: tile variant (index or name, see gemm_variants()); -1 = the library's choice for the problem size."""
     p = hip.ConvGemmParams()
     p.A, p.Wt, p.bias = ptr(A), ptr(Wt), ptr(bias)
     p.lda = lda if lda is not None else A.shape[-1]
@@ -108,18 +109,27 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     p.drop_p, p.drop_thresh, p.drop_seed, p.drop_stream = drop.p, drop.thresh, drop.seed & 0xFFFFFFFF, drop.stream
     p.drop_seed_dev = ptr(drop.dev)
     st = None
+    if isinstance(variant, str):
+        variant = gemm_variants().index(variant)
+    rows = hip.load().cris_conv_gemm_variant_stat_rows(C.byref(p), variant)   # depends on the tile variant that will run
+    if rows < 0:
+        raise ValueError("GEMM tile variant %r cannot run this problem" % (variant,))
     if stats:
-        rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))          # depends on the tile variant the library picks
         st = Stats((g.M + rows - 1) // rows, N, rows, A.device)
         p.colsum, p.colsq = ptr(st[0]), ptr(st[1])
     if KERNEL_TIMER is not None:
-        rows = hip.load().cris_conv_gemm_stat_rows(C.byref(p))
         KERNEL_TIMER.launch("skinny_gemm" if rows == 16 else "conv_gemm", 2.0 * g.M * N * g.K,
-                            2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm", C.byref(p),
+                            2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm_variant", C.byref(p), variant,
                             tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
         return st
-    hip.call("cris_conv_gemm", C.byref(p), _stream())
+    hip.call("cris_conv_gemm_variant", C.byref(p), variant, _stream())
     return st
+
+
+def gemm_variants():
+    """names of the conv_gemm tile variants, by index (cris_conv_gemm_variant)"""
+    lib = hip.load()
+    return [lib.cris_conv_gemm_variant_name(i).decode() for i in range(lib.cris_conv_gemm_num_variants())]
 
 
 class KernelTimer:

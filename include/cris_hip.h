@@ -68,6 +68,16 @@ typedef struct {
 int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
 /* rows per BatchNorm-statistics partial written for this problem (depends on the tile variant chosen; host only) */
 int cris_conv_gemm_stat_rows(const cris_conv_gemm_params* p);
+/* The same launch with the tile variant named by the caller instead of chosen from the problem size (tests and the
+ * per-shape tuning tool tools/gemm_variants.py; `variant` < 0 = automatic = cris_conv_gemm).  Variants: the 4-wave tiles
+ * 128x64 / 64x64 / 64x128 / 128x128, the two skinny kernels, the 8-wave ping-pong tiles 256x256 / 256x128 / 128x256
+ * (csrc/gemm8.hip; C % 64 == 0 only).  Returns -1 when the variant cannot run the problem.  Results of different variants
+ * differ only by fp32 summation order inside a K-tile (none: every variant adds k in the same order) - the outputs are
+ * bit-identical; the BatchNorm partials differ in their row grouping (cris_conv_gemm_variant_stat_rows). */
+int cris_conv_gemm_variant(const cris_conv_gemm_params* p, int variant, void* stream);
+int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, int variant);
+int cris_conv_gemm_num_variants(void);
+const char* cris_conv_gemm_variant_name(int variant);
 
 /* Weight gradient in the GEMM layout: dW[n][tap*C + c] = sum_m dY[m, n] * X_im2col[m, tap*C + c]  (csrc/wgrad.hip).
  * Deterministic, no atomics: splits == 1 stores the whole reduction; splits > 1 stores one partial tile per split into the

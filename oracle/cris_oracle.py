@@ -2,6 +2,10 @@
 
 This is the oracle the HIP path is checked against (tests/, __graft_entry__.smoke(), and the
 `cpu_baseline` leg of bench.py).  Nothing in the product path (cris/pytorch_amd/) may import it.
+It is device-generic functional torch: the pinned form is fp32 on the CPU; the same code on the GPU
+(fp32 - checked equal to the CPU run in tests/test_oracle_device.py - or under torch.autocast, the
+reference's own precision policy engine/engine.py:48) is what tools/parity_study.py and the
+teacher-forced trajectory test use as "stock PyTorch on this hardware".
 
 It restates, function by function, what the reference computes on the training hot path
 (reference = DerrickWang005/CRIS.pytorch; citations are file:line in that repo), as plain
@@ -49,8 +53,10 @@ class DropCtx:
         """x is already laid out in the HIP path's element order (row-major, contiguous)."""
         if not self.active:
             return x
-        keep = dropout_hash.keep_mask(self.seed, stream, x.numel(), self.p)
-        m = torch.from_numpy(keep).view(x.shape).to(x.dtype)
+        if x.device.type == "cpu":
+            m = torch.from_numpy(dropout_hash.keep_mask(self.seed, stream, x.numel(), self.p)).view(x.shape).to(x.dtype)
+        else:
+            m = dropout_hash.keep_mask_torch(self.seed, stream, x.numel(), self.p, x.device).view(x.shape).to(x.dtype)
         return x * m * (1.0 / (1.0 - self.p))
 
 
@@ -63,10 +69,24 @@ def drop_stream(layer: int, site: int) -> int:
 # ----------------------------------------------------------------------------------------------
 # primitives
 # ----------------------------------------------------------------------------------------------
+# NATIVE_NORMS = True: BatchNorm / LayerNorm through torch's own F.batch_norm / F.layer_norm instead of the spelled-out forms
+# below - the operators the reference's nn.BatchNorm2d / nn.LayerNorm modules call, so that under torch.autocast they follow
+# autocast's own per-operator policy (tools/parity_study.py: "what does stock PyTorch autocast do on this network").
+NATIVE_NORMS = False
+
+
 def batch_norm(x, sd, prefix, training, bn_updates=None):
     """torch BatchNorm (eps 1e-5, momentum 0.1, biased var for normalisation, unbiased for the
     running estimate).  x: [B,C,H,W] or [B,C]."""
     w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    if NATIVE_NORMS:
+        rm = rv = None
+        if bn_updates is not None or not training:
+            rm, rv = sd[prefix + ".running_mean"].detach().clone(), sd[prefix + ".running_var"].detach().clone()
+        y = F.batch_norm(x, rm, rv, w, b, training, BN_MOM, BN_EPS)
+        if training and bn_updates is not None:
+            bn_updates[prefix] = (rm, rv)
+        return y
     dims = [0] + list(range(2, x.dim()))
     shape = [1, -1] + [1] * (x.dim() - 2)
     if training:
@@ -85,6 +105,8 @@ def batch_norm(x, sd, prefix, training, bn_updates=None):
 
 def layer_norm(x, sd, prefix):
     w, b = sd[prefix + ".weight"], sd[prefix + ".bias"]
+    if NATIVE_NORMS:
+        return F.layer_norm(x, (x.shape[-1],), w, b, LN_EPS)
     mu = x.mean(-1, keepdim=True)
     var = ((x - mu) ** 2).mean(-1, keepdim=True)
     return (x - mu) * torch.rsqrt(var + LN_EPS) * w + b
@@ -177,7 +199,7 @@ def encode_image(img, sd, clip, training, bnu, taps=None):
 def encode_text(word, sd, clip, taps=None):
     B, L = word.shape
     x = sd["backbone.token_embedding.weight"][word] + sd["backbone.positional_embedding"][:L]
-    causal = torch.full((L, L), float("-inf"), dtype=x.dtype).triu_(1)               # clip.py:424-430
+    causal = torch.full((L, L), float("-inf"), dtype=x.dtype, device=x.device).triu_(1)               # clip.py:424-430
     for i in range(clip.txt_layers):
         p = "backbone.transformer.resblocks.%d" % i
         h = layer_norm(x, sd, p + ".ln_1")
@@ -191,7 +213,7 @@ def encode_text(word, sd, clip, taps=None):
         x = x + F.linear(h, sd[p + ".mlp.c_proj.weight"], sd[p + ".mlp.c_proj.bias"])
     x = layer_norm(x, sd, "backbone.ln_final")
     eot = word.argmax(dim=-1)                                           # first max wins
-    state = x[torch.arange(B), eot] @ sd["backbone.text_projection"]
+    state = x[torch.arange(B, device=x.device), eot] @ sd["backbone.text_projection"]
     if taps is not None:
         taps["word"], taps["state"] = x, state
     return x, state
@@ -226,8 +248,8 @@ def fpn(v3, v4, v5, state, sd, training, bnu, taps=None):
         taps["f5"], taps["f4"], taps["f3"], taps["aggr"] = f5, f4, f3, fq
     # CoordConv (layers.py:30-39): x varies along W, y along H, both linspace(-1,1)
     B, _, H, W = fq.shape
-    xr = torch.linspace(-1, 1, W).to(fq.dtype).view(1, 1, 1, W).expand(B, 1, H, W)
-    yr = torch.linspace(-1, 1, H).to(fq.dtype).view(1, 1, H, 1).expand(B, 1, H, W)
+    xr = torch.linspace(-1, 1, W).to(fq.dtype).to(fq.device).view(1, 1, 1, W).expand(B, 1, H, W)
+    yr = torch.linspace(-1, 1, H).to(fq.dtype).to(fq.device).view(1, 1, H, 1).expand(B, 1, H, W)
     fq = torch.cat([fq, xr, yr], 1)
     fq = conv_bn_relu(fq, sd, n + ".coordconv.0.conv1", 1, training, bnu)
     fq = conv_bn_relu(fq, sd, n + ".coordconv.1", 1, training, bnu)
@@ -272,8 +294,8 @@ def decoder(fq, word, pad_mask, sd, head, drop: DropCtx, taps=None):
     # reference model/layers.py:154-188, 224-250 ; batch-first internally ([B,T,C] == permuted [T,B,C])
     B, C, H, W = fq.shape
     L, D = word.shape[1], word.shape[2]
-    vpos = pos2d(C, H, W)[None].to(fq.dtype)                      # [1, HW, C]
-    tpos = pos1d(D, L)[None].to(fq.dtype)                         # [1, L, D]
+    vpos = pos2d(C, H, W)[None].to(fq.dtype).to(fq.device)        # [1, HW, C]
+    tpos = pos1d(D, L)[None].to(fq.dtype).to(fq.device)           # [1, L, D]
     vis = fq.reshape(B, C, H * W).permute(0, 2, 1)   # [B, HW, C]
     txt = word
     for i in range(head.num_layers):
@@ -319,8 +341,8 @@ def nearest_resize_mask(mask, oh, ow):
     """F.interpolate(mode='nearest') index rule: src = min(floor(dst * in/out), in-1)
     (reference model/segmenter.py:56-58)."""
     ih, iw = mask.shape[-2:]
-    ys = torch.clamp((torch.arange(oh, dtype=torch.float32) * (ih / oh)).floor().long(), max=ih - 1)
-    xs = torch.clamp((torch.arange(ow, dtype=torch.float32) * (iw / ow)).floor().long(), max=iw - 1)
+    ys = torch.clamp((torch.arange(oh, dtype=torch.float32) * (ih / oh)).floor().long(), max=ih - 1).to(mask.device)
+    xs = torch.clamp((torch.arange(ow, dtype=torch.float32) * (iw / ow)).floor().long(), max=iw - 1).to(mask.device)
     return mask[..., ys[:, None], xs[None, :]]
 
 

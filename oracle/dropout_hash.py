@@ -41,3 +41,18 @@ def keep_mask(seed: int, stream: int, n: int, p: float) -> np.ndarray:
     h = np.uint32((seed ^ ((stream * 0x9E3779B9) & 0xFFFFFFFF)) & 0xFFFFFFFF)
     v = ((idx * np.uint64(0x9E3779B1) + np.uint64(h)) & _M32).astype(np.uint32)
     return fmix32(v) >= np.uint32(threshold(p))
+
+
+def keep_mask_torch(seed: int, stream: int, n: int, p: float, device):
+    """keep_mask() with torch int64 arithmetic on `device` (bit-identical; tests/test_oracle_device.py): lets the oracle run on
+    the GPU, where 30 M decisions per attention site and step through numpy would dominate a 100-step trajectory"""
+    import torch
+    M = 0xFFFFFFFF
+    h = (seed ^ ((stream * 0x9E3779B9) & M)) & M
+    v = (torch.arange(n, dtype=torch.int64, device=device) * 0x9E3779B1 + h) & M
+    v = v ^ (v >> 16)
+    v = (v * 0x85EBCA6B) & M
+    v = v ^ (v >> 13)
+    v = (v * 0xC2B2AE35) & M
+    v = v ^ (v >> 16)
+    return v >= threshold(p)

@@ -185,6 +185,87 @@ def test_conv_gemm_general_epilogue_large_tiles():
     check(outs[3], torch.rsqrt(ref.var(0, unbiased=False) + 1e-5), 3e-3, "invstd from 128x128 partials")
 
 
+G8 = ("8w256x256", "8w256x128", "8w128x256")
+
+
+@pytest.mark.parametrize("variant", G8)
+@pytest.mark.parametrize("case", [
+    dict(B=2, H=24, W=24, C=64, N=256, k=1),          # M 1152 = 4.5 row tiles: M tail; one K-tile: prologue == whole pipeline
+    dict(B=3, H=20, W=20, C=128, N=320, k=3),         # 3x3 with padding, tap changes every 2 K-tiles, N tail (320 = 256 + 64)
+    dict(B=1, H=30, W=30, C=192, N=136, k=3),         # K = 27 K-tiles (odd: both ring parities end the loop), N tail < 32
+    dict(B=8, H=52, W=52, C=512, N=512, k=3),         # benchmark shape M 21632 N 512 K 4608
+    dict(B=8, H=104, W=104, C=256, N=128, k=1),       # M 86528 N 128 K 256
+    dict(B=2, H=16, W=16, C=64, N=512, k=3, stride=2),  # strided gather
+])
+def test_conv_gemm_8wave_tiles(variant, case):
+    """the 8-wave ping-pong tiles (csrc/gemm8.hip), each forced by name: against conv2d in fp32, against the 4-wave tile
+    bit for bit (every variant adds the K-tiles in the same order), BatchNorm partials, and run-to-run identity (the
+    schedule's RAW / WAR distances are by construction; a violated one shows as rare differing tiles)"""
+    B, H, W, C_, N, k = case["B"], case["H"], case["W"], case["C"], case["N"], case["k"]
+    stride = case.get("stride", 1)
+    pad = k // 2
+    x = rnd(B, H, W, C_).to(BF).float()
+    w = (rnd(N, C_, k, k, seed=1) / math.sqrt(C_ * k * k)).to(BF).float()
+    g = Geom(B, H, W, C_, k, k, stride, pad)
+    xd, wd = bf(x), bf(pack_F(w))
+    out = torch.empty(g.M, N, dtype=BF, device=DEV)
+    st = ops.conv_gemm(xd, wd, g, N, out=out, stats=True, variant=variant)
+    ref = conv_ref(x, w, stride, pad)
+    check(out, ref, 6e-3, "%s %s" % (variant, case))
+    base = torch.empty(g.M, N, dtype=BF, device=DEV)
+    ops.conv_gemm(xd, wd, g, N, out=base, variant="128x128")
+    assert torch.equal(out, base), "%s differs from the 128x128 tile" % variant
+    rows = st.rows_per_part
+    assert rows == (64 if variant == "8w128x256" else 128)
+    y = ref                                            # (statistics are taken from the fp32 accumulators)
+    for part in (0, (g.M - 1) // rows):
+        blk = y[part * rows:(part + 1) * rows]
+        check(st[0][part], blk.sum(0), 3e-3, "part sum")
+        check(st[1][part], ((blk - blk.mean(0)) ** 2).sum(0), 6e-3, "part M2")
+    for _ in range(6):
+        again = torch.empty(g.M, N, dtype=BF, device=DEV)
+        ops.conv_gemm(xd, wd, g, N, out=again, variant=variant)
+        assert torch.equal(out, again), "%s is not reproducible" % variant
+
+
+@pytest.mark.parametrize("variant", G8)
+def test_conv_gemm_8wave_epilogues(variant):
+    """general epilogue (bias, QuickGELU, fp32 residual / output, dropout) and the residual of the lean one on the 8-wave tiles"""
+    M, K, N = 700, 320, 328                           # C = 320 = 5 K-tiles; N tail
+    x = rnd(M, K).to(BF).float()
+    w = (rnd(N, K, seed=1) / math.sqrt(K)).to(BF).float()
+    bias, res32 = rnd(N, seed=2), rnd(M, N, seed=3)
+    resbf = rnd(M, N, seed=4).to(BF).float()
+    g = Geom.linear(M, K)
+    base = x @ w.t()
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=2, resid=res32.to(DEV), out=out, variant=variant)
+    b2 = base + bias
+    check(out, b2 * torch.sigmoid(1.702 * b2) + res32, 3e-3, "quickgelu+resid f32")
+    wide = torch.zeros(M, N + 64, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, resid=bf(resbf), out=wide, ldc=N + 64, c_coff=64, variant=variant)
+    check(wide[:, 64:], base + resbf, 6e-3, "lean + bf16 residual into a slice")
+    assert float(wide[:, :64].float().abs().max()) == 0.0
+    out2 = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=3, resid=bf(resbf), out=out2, variant=variant)
+    check(out2, torch.relu(b2 + resbf), 6e-3, "EPI 2: bias + residual + relu")
+    p, seed, stream = 0.1, 99, 3
+    out3 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), out=out3, drop=Drop(p, seed, stream), variant=variant)
+    km = keep_mask(seed, stream, (M, N), p).cpu()
+    check(out3, b2 * km / (1 - p), 3e-3, "dropout epilogue")
+
+
+def test_conv_gemm_variant_refused_when_not_applicable():
+    x, w = bf(rnd(64, 72)), bf(rnd(64, 72, seed=1))
+    out = torch.empty(64, 64, dtype=BF, device=DEV)
+    with pytest.raises(ValueError):
+        ops.conv_gemm(x, w, Geom.linear(64, 72), 64, out=out, variant="8w256x256")      # C % 64 != 0
+    with pytest.raises(ValueError):
+        ops.conv_gemm(bf(rnd(300, 64)), bf(rnd(64, 64)), Geom.linear(300, 64), 64, out=torch.empty(300, 64, dtype=BF, device=DEV),
+                      variant="skinny9")                                                # M > 144
+
+
 @pytest.mark.parametrize("L,B", [(24, 3), (17, 2)])
 def test_conv_gemm_transposed_store(L, B):
     """head-split transposed copy written by the epilogue: outT[sec][(b*H+h)*64+d][l]"""
