@@ -23,6 +23,15 @@
 // Only convolutions with C % 64 == 0 (a 64-wide K-tile lies in one tap; every large layer of the networks) come here.
 #include "gemm_common.h"
 
+// Diagnostic build switch of tools/probe/gemm8_probe.hip (ablations: which unit bounds the loop).  0 in the library: every
+// `if constexpr` below folds away.  bit 0: no fragment reads in the loop; 1: no DMA issue in the loop; 2: no MFMAs;
+// 3: no barriers in the loop; 4: lgkmcnt(0) after the barrier instead of before; 5: no s_setprio; 6: no group stagger;
+// 7 (candidate, results stay correct): the phase's DMAs are issued inside the MFMA segment (after the second MFMA) instead of
+// in front of the fragment reads.
+#ifndef G8_ABL
+#define G8_ABL 0
+#endif
+
 #define CRIS_WAIT_VM_LGKM0(N) __builtin_amdgcn_s_waitcnt(((N) & 0xF) | ((((N) >> 4) & 3) << 14) | (0x7 << 4))
 #define CRIS_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xF | (3 << 14) | (0x7 << 4))
 #define CRIS_BARRIER()                              \
@@ -30,6 +39,20 @@
         __builtin_amdgcn_sched_barrier(0);          \
         __builtin_amdgcn_s_barrier();               \
         __builtin_amdgcn_sched_barrier(0);          \
+    } while (0)
+// barrier / waits of the main loop (the ablation switches act on these only)
+#define LOOP_BARRIER()                              \
+    do {                                            \
+        if constexpr (!(G8_ABL & 8)) CRIS_BARRIER(); \
+        else __builtin_amdgcn_sched_barrier(0);     \
+    } while (0)
+/* N: DMAs that may stay in flight at the wait; N7: the same when the phase's own pieces are issued later (bit 7) */
+#define G8_VM(N, N7) ((G8_ABL & 128) ? (N7) : (N))
+#define LOOP_WAIT(N, N7)                                                                      \
+    do {                                                                                  \
+        if constexpr (G8_ABL & 2) { if constexpr (!(G8_ABL & 16)) CRIS_WAIT_LGKM0(); }    \
+        else if constexpr (G8_ABL & 16) CRIS_VMCNT(G8_VM(N, N7));                             \
+        else CRIS_WAIT_VM_LGKM0(G8_VM(N, N7));                                                \
     } while (0)
 
 // PA x PB sub-blocks of 64 x 32 per wave tile; wave grid 2 (M) x 4 (N):
@@ -191,55 +214,64 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
     // asm statements pin the MFMAs to their segment: an MFMA is a pure register operation, and without them hipcc sinks the
     // MFMAs of one phase across the barriers into the next phase's segment (seen in the disassembly) - which would put the
     // two wave groups' matrix work back to back on the same SIMD instead of alternating it with their memory segments.
-#define CRIS_MFMA_SEG(a, b)                                                                                             \
+#define CRIS_MFMA_SEG(a, b, ISSUE)                                                                                           \
     do {                                                                                                                \
+        if constexpr ((G8_ABL & 16) != 0) CRIS_WAIT_LGKM0();                                                            \
         asm volatile("" : "+v"(acc[(a) * 2 + 0][b]), "+v"(acc[(a) * 2 + 1][b]));                                        \
-        __builtin_amdgcn_s_setprio(1);                                                                                  \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                              \
+        if constexpr (!(G8_ABL & 32)) __builtin_amdgcn_s_setprio(1);                                                    \
+        if constexpr (!(G8_ABL & 4)) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                 \
             acc[(a) * 2 + 0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ks], bfr[ks], acc[(a) * 2 + 0][b], 0, 0, 0); \
             acc[(a) * 2 + 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ks], bfr[ks], acc[(a) * 2 + 1][b], 0, 0, 0); \
+            if (ks == 0) { ISSUE; }                                                                                     \
         }                                                                                                               \
         asm volatile("" : "+v"(acc[(a) * 2 + 0][b]), "+v"(acc[(a) * 2 + 1][b]));                                        \
-        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        if constexpr (!(G8_ABL & 32)) __builtin_amdgcn_s_setprio(0);                                                                                  \
     } while (0)
 
+#define LI_A(a) do { if constexpr (!(G8_ABL & 2) && !(G8_ABL & 128)) issue_A(a); } while (0)
+#define LI_B(b) do { if constexpr (!(G8_ABL & 2) && !(G8_ABL & 128)) issue_B(b); } while (0)
+#define MI_A(a) do { if constexpr (!(G8_ABL & 2) && (G8_ABL & 128)) issue_A(a); } while (0)
+#define MI_B(b) do { if constexpr (!(G8_ABL & 2) && (G8_ABL & 128)) issue_B(b); } while (0)
+#define LR_A(a) do { if constexpr (!(G8_ABL & 1)) read_A(a); } while (0)
+#define LR_B(b) do { if constexpr (!(G8_ABL & 1)) read_B(b); } while (0)
     const int nk = p.K / BK;
+    if constexpr ((G8_ABL & 1) != 0) { read_A(0); read_B(0); }
     if constexpr (S4) {
         // piece order of the stream: A0 B0 B1 A1 | A0 B0 B1 A1 ...; phase q of K-tile t issues B0(t+1), B1(t+1), A1(t+1), A0(t+2)
         issue_A(0); issue_B(0); issue_B(1); issue_A(1); issue_A(0);
         CRIS_WAIT_VM_LGKM0(6);                      // A0(0), B0(0) of this wave have landed
         CRIS_BARRIER();
-        if (wm == 1) CRIS_BARRIER();                // group 1 runs one barrier behind from here on
+        if ((G8_ABL & 64) == 0 && wm == 1) CRIS_BARRIER();                // group 1 runs one barrier behind from here on
         for (int kt = 0; kt < nk; ++kt) {
             // q1: sub-block (0,0)
-            issue_B(0);
-            read_A(0);
-            read_B(0);
-            CRIS_WAIT_VM_LGKM0(6);                  // fragments in registers; B1(kt) landed (3 pieces stay in flight)
-            CRIS_BARRIER();
-            CRIS_MFMA_SEG(0, 0);
-            CRIS_BARRIER();
+            LI_B(0);
+            LR_A(0);
+            LR_B(0);
+            LOOP_WAIT(6, 4);                  // fragments in registers; B1(kt) landed (3 pieces stay in flight)
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG(0, 0, MI_B(0));
+            LOOP_BARRIER();
             // q2: (0,1)
-            issue_B(1);
-            read_B(1);
-            CRIS_WAIT_VM_LGKM0(6);                  // A1(kt) landed
-            CRIS_BARRIER();
-            CRIS_MFMA_SEG(0, 1);
-            CRIS_BARRIER();
+            LI_B(1);
+            LR_B(1);
+            LOOP_WAIT(6, 4);                  // A1(kt) landed
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG(0, 1, MI_B(1));
+            LOOP_BARRIER();
             // q3: (1,1)
-            issue_A(1);
-            read_A(1);
-            CRIS_WAIT_LGKM0();
-            CRIS_BARRIER();
-            CRIS_MFMA_SEG(1, 1);
-            CRIS_BARRIER();
+            LI_A(1);
+            LR_A(1);
+            LOOP_WAIT(63, 63);
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG(1, 1, MI_A(1));
+            LOOP_BARRIER();
             // q4: (1,0)
-            issue_A(0);
-            read_B(0);
-            CRIS_WAIT_VM_LGKM0(6);                  // A0(kt+1), B0(kt+1) landed
-            CRIS_BARRIER();
-            CRIS_MFMA_SEG(1, 0);
-            CRIS_BARRIER();
+            LI_A(0);
+            LR_B(0);
+            LOOP_WAIT(6, 4);                  // A0(kt+1), B0(kt+1) landed
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG(1, 0, MI_A(0));
+            LOOP_BARRIER();
             rbuf = rbuf == 0 ? TILE_BYTES : 0;
         }
     } else if constexpr (PA == 2) {
@@ -247,22 +279,22 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
         issue_A(0); issue_B(0); issue_A(1); issue_A(0); issue_B(0);
         CRIS_WAIT_VM_LGKM0(6);
         CRIS_BARRIER();
-        if (wm == 1) CRIS_BARRIER();
+        if ((G8_ABL & 64) == 0 && wm == 1) CRIS_BARRIER();
         for (int kt = 0; kt < nk; ++kt) {
-            issue_A(1);
-            issue_A(0);
-            read_A(0);
-            read_B(0);
-            CRIS_WAIT_VM_LGKM0(8);                  // A1(kt) landed (4 pieces stay in flight)
-            CRIS_BARRIER();
-            CRIS_MFMA_SEG(0, 0);
-            CRIS_BARRIER();
-            issue_B(0);
-            read_A(1);
-            CRIS_WAIT_VM_LGKM0(6);                  // A0(kt+1), B(kt+1) landed
-            CRIS_BARRIER();
-            CRIS_MFMA_SEG(1, 0);
-            CRIS_BARRIER();
+            LI_A(1);
+            LI_A(0);
+            LR_A(0);
+            LR_B(0);
+            LOOP_WAIT(8, 4);                  // A1(kt) landed (4 pieces stay in flight)
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG(0, 0, MI_A(1); MI_A(0));
+            LOOP_BARRIER();
+            LI_B(0);
+            LR_A(1);
+            LOOP_WAIT(6, 4);                  // A0(kt+1), B(kt+1) landed
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG(1, 0, MI_B(0));
+            LOOP_BARRIER();
             rbuf += TILE_BYTES;
             if (rbuf == NBUF * TILE_BYTES) rbuf = 0;
         }
@@ -271,29 +303,35 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
         issue_B(0); issue_A(0); issue_B(1); issue_B(0); issue_A(0);
         CRIS_WAIT_VM_LGKM0(6);
         CRIS_BARRIER();
-        if (wm == 1) CRIS_BARRIER();
+        if ((G8_ABL & 64) == 0 && wm == 1) CRIS_BARRIER();
         for (int kt = 0; kt < nk; ++kt) {
-            issue_B(1);
-            issue_B(0);
-            read_A(0);
-            read_B(0);
-            CRIS_WAIT_VM_LGKM0(8);
-            CRIS_BARRIER();
-            CRIS_MFMA_SEG(0, 0);
-            CRIS_BARRIER();
-            issue_A(0);
-            read_B(1);
-            CRIS_WAIT_VM_LGKM0(6);
-            CRIS_BARRIER();
-            CRIS_MFMA_SEG(0, 1);
-            CRIS_BARRIER();
+            LI_B(1);
+            LI_B(0);
+            LR_A(0);
+            LR_B(0);
+            LOOP_WAIT(8, 4);
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG(0, 0, MI_B(1); MI_B(0));
+            LOOP_BARRIER();
+            LI_A(0);
+            LR_B(1);
+            LOOP_WAIT(6, 4);
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG(0, 1, MI_A(0));
+            LOOP_BARRIER();
             rbuf += TILE_BYTES;
             if (rbuf == NBUF * TILE_BYTES) rbuf = 0;
         }
     }
-    if (wm == 0) CRIS_BARRIER();                    // same number of barriers for every wave
+    if ((G8_ABL & 64) == 0 && wm == 0) CRIS_BARRIER();    // same number of barriers for every wave
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 #undef CRIS_MFMA_SEG
+#undef LI_A
+#undef MI_A
+#undef MI_B
+#undef LI_B
+#undef LR_A
+#undef LR_B
 
     gemm_epilogue<EPI, 32, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * 2 + wm, lane);
 }
