@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
 }
 
 // tile selection (host)
-enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_COUNT };
+enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_COUNT };
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s);       // gemm8.hip
 
 static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
@@ -342,7 +342,7 @@ static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
     switch (v) {
         case V_SKINNY1: return lin && p.M <= 16;
         case V_SKINNY9: return lin && p.M <= SKINNY_MAX_M;
-        case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: return (p.C & 63) == 0;
+        case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128: return (p.C & 63) == 0;
         default: return v >= 0 && v < V_COUNT;
     }
 }
@@ -389,7 +389,7 @@ static int variant_stat_rows(int v) {
         case V_SKINNY9: return 16;
         case V_128x128: return 64;
         case V_8W_256x256: case V_8W_256x128: return 128;
-        case V_8W_128x256: return 64;
+        case V_8W_128x256: case V_8W_128x128: return 64;
         default: return 32;
     }
 }
@@ -404,7 +404,7 @@ extern "C" int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, 
 }
 extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
 extern "C" const char* cris_conv_gemm_variant_name(int v) {
-    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256"};
+    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128"};
     return (v >= 0 && v < V_COUNT) ? names[v] : "?";
 }
 
@@ -462,7 +462,7 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     const int v = resolve_variant(p, variant);
     CRIS_CHECK_ARG(v >= 0, "tile variant not applicable to this problem");
     switch (v) {
-        case V_8W_256x256: case V_8W_256x128: case V_8W_128x256:
+        case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128:
             return cris_launch_gemm8(v - V_8W_256x256, p, lean, s);
         case V_SKINNY1:
             hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);

@@ -26,8 +26,8 @@
 // Diagnostic build switch of tools/probe/gemm8_probe.hip (ablations: which unit bounds the loop).  0 in the library: every
 // `if constexpr` below folds away.  bit 0: no fragment reads in the loop; 1: no DMA issue in the loop; 2: no MFMAs;
 // 3: no barriers in the loop; 4: lgkmcnt(0) after the barrier instead of before; 5: no s_setprio; 6: no group stagger;
-// 7 (candidate, results stay correct): the phase's DMAs are issued inside the MFMA segment (after the second MFMA) instead of
-// in front of the fragment reads.
+// 7 (results stay correct): flips where a phase's DMAs are issued - in front of the fragment reads (default of the 256x256
+// tile) or inside the MFMA segment after the first MFMAs (default of the 256x128 / 128x256 tiles; each default measured).
 #ifndef G8_ABL
 #define G8_ABL 0
 #endif
@@ -47,7 +47,7 @@
         else __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 /* N: DMAs that may stay in flight at the wait; N7: the same when the phase's own pieces are issued later (bit 7) */
-#define G8_VM(N, N7) ((G8_ABL & 128) ? (N7) : (N))
+#define G8_VM(N, N7) (DMA_IN_MFMA ? (N7) : (N))
 #define LOOP_WAIT(N, N7)                                                                      \
     do {                                                                                  \
         if constexpr (G8_ABL & 2) { if constexpr (!(G8_ABL & 16)) CRIS_WAIT_LGKM0(); }    \
@@ -56,15 +56,19 @@
     } while (0)
 
 // PA x PB sub-blocks of 64 x 32 per wave tile; wave grid 2 (M) x 4 (N):
-//   (2,2): 256x256 tile, 4 phases per K-tile, 2 K-tile buffers (128 KB);  (2,1): 256x128;  (1,2): 128x256 - 2 phases per
-//   K-tile, 3 K-tile buffers (144 KB)
+//   (2,2): 256x256 tile, 2 phases of 16 MFMAs per K-tile, 2 K-tile buffers (128 KB);  (2,1): 256x128;  (1,2): 128x256 - 2 phases
+//   of 8 MFMAs per K-tile, 3 K-tile buffers (144 KB);  (1,1): 128x128, one phase of 8 MFMAs per K-tile, FIVE K-tile buffers
+//   (160 KB): the variant for problems of at most ~one tile per CU (mid-size layers), whose loop is bound by the operand
+//   latency - three K-tiles (96 KB) stay in flight per CU against one or two with the 4-wave tiles' rings
 template <int PA, int PB, int EPI>
 __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_params p) {
     constexpr int WTM = PA * 64, WTN = PB * 32;
     constexpr int BM = 2 * WTM, BN = 4 * WTN;
     constexpr int FM = PA * 2, FN = PB;
     constexpr bool S4 = PA == 2 && PB == 2;
-    constexpr int NBUF = S4 ? 2 : 3;
+    constexpr bool S1 = PA == 1 && PB == 1;
+    constexpr int NBUF = S4 ? 2 : S1 ? 5 : 3;
+    constexpr bool DMA_IN_MFMA = (!S4) != ((G8_ABL & 128) != 0);      // where a phase issues its LDS-DMAs (see G8_ABL bit 7)
     constexpr int A_BYTES = BM * 128, TILE_BYTES = (BM + BN) * 128;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -84,7 +88,10 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     int tile_m, tile_n;
-    if ((long)p.N * p.K > (1L << 20)) {
+#ifndef G8_ORDER
+#define G8_ORDER 0                                  // probe A/B: 1 = n fastest always, 2 = m fastest always
+#endif
+    if (G8_ORDER == 2 || (G8_ORDER == 0 && (long)p.N * p.K > (1L << 20))) {
         tile_n = bid / tiles_m;
         tile_m = bid - tile_n * tiles_m;
     } else {
@@ -185,7 +192,7 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
     for (int ks = 0; ks < 4; ++ks) cx[ks] = (((ks * 2 + fh) ^ swz) & 7) << 4;
     const int rowA = (wm * WTM + fr) * 128, rowB = A_BYTES + (wn * WTN + fr) * 128;
     int rbuf = 0;                                     // ring buffer of the K-tile being computed
-    bf16x8 af[2][4], bfr[4];
+    bf16x8 af[2][4], bfr[PB][4];
     auto read_A = [&](int a) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
     auto read_B = [&](int b) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            bfr[ks] = *reinterpret_cast<const bf16x8*>(smem + rbuf + rowB + b * 32 * 128 + cx[ks]);
+            bfr[b][ks] = *reinterpret_cast<const bf16x8*>(smem + rbuf + rowB + b * 32 * 128 + cx[ks]);
         }
     };
 
@@ -220,59 +227,90 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
         asm volatile("" : "+v"(acc[(a) * 2 + 0][b]), "+v"(acc[(a) * 2 + 1][b]));                                        \
         if constexpr (!(G8_ABL & 32)) __builtin_amdgcn_s_setprio(1);                                                    \
         if constexpr (!(G8_ABL & 4)) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                 \
-            acc[(a) * 2 + 0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ks], bfr[ks], acc[(a) * 2 + 0][b], 0, 0, 0); \
-            acc[(a) * 2 + 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ks], bfr[ks], acc[(a) * 2 + 1][b], 0, 0, 0); \
+            acc[(a) * 2 + 0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ks], bfr[b][ks], acc[(a) * 2 + 0][b], 0, 0, 0); \
+            acc[(a) * 2 + 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ks], bfr[b][ks], acc[(a) * 2 + 1][b], 0, 0, 0); \
             if (ks == 0) { ISSUE; }                                                                                     \
         }                                                                                                               \
         asm volatile("" : "+v"(acc[(a) * 2 + 0][b]), "+v"(acc[(a) * 2 + 1][b]));                                        \
         if constexpr (!(G8_ABL & 32)) __builtin_amdgcn_s_setprio(0);                                                                                  \
     } while (0)
 
-#define LI_A(a) do { if constexpr (!(G8_ABL & 2) && !(G8_ABL & 128)) issue_A(a); } while (0)
-#define LI_B(b) do { if constexpr (!(G8_ABL & 2) && !(G8_ABL & 128)) issue_B(b); } while (0)
-#define MI_A(a) do { if constexpr (!(G8_ABL & 2) && (G8_ABL & 128)) issue_A(a); } while (0)
-#define MI_B(b) do { if constexpr (!(G8_ABL & 2) && (G8_ABL & 128)) issue_B(b); } while (0)
+    // a 64-row half of the wave tile x both 32-column halves x K 64: 16 MFMAs on four accumulators (256x256 tile)
+#define CRIS_MFMA_SEG16(a, ISSUE)                                                                                       \
+    do {                                                                                                                \
+        if constexpr ((G8_ABL & 16) != 0) CRIS_WAIT_LGKM0();                                                            \
+        asm volatile("" : "+v"(acc[(a) * 2][0]), "+v"(acc[(a) * 2 + 1][0]), "+v"(acc[(a) * 2][1]), "+v"(acc[(a) * 2 + 1][1])); \
+        if constexpr (!(G8_ABL & 32)) __builtin_amdgcn_s_setprio(1);                                                    \
+        if constexpr (!(G8_ABL & 4)) _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                 \
+            _Pragma("unroll") for (int b = 0; b < 2; ++b) {                                                             \
+                acc[(a) * 2 + 0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ks], bfr[b][ks], acc[(a) * 2 + 0][b], 0, 0, 0); \
+                acc[(a) * 2 + 1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ks], bfr[b][ks], acc[(a) * 2 + 1][b], 0, 0, 0); \
+            }                                                                                                           \
+            if (ks == 0) { ISSUE; }                                                                                     \
+        }                                                                                                               \
+        asm volatile("" : "+v"(acc[(a) * 2][0]), "+v"(acc[(a) * 2 + 1][0]), "+v"(acc[(a) * 2][1]), "+v"(acc[(a) * 2 + 1][1])); \
+        if constexpr (!(G8_ABL & 32)) __builtin_amdgcn_s_setprio(0);                                                    \
+    } while (0)
+
+#define LI_A(a) do { if constexpr (!(G8_ABL & 2) && !DMA_IN_MFMA) issue_A(a); } while (0)
+#define LI_B(b) do { if constexpr (!(G8_ABL & 2) && !DMA_IN_MFMA) issue_B(b); } while (0)
+#define MI_A(a) do { if constexpr (!(G8_ABL & 2) && DMA_IN_MFMA) issue_A(a); } while (0)
+#define MI_B(b) do { if constexpr (!(G8_ABL & 2) && DMA_IN_MFMA) issue_B(b); } while (0)
 #define LR_A(a) do { if constexpr (!(G8_ABL & 1)) read_A(a); } while (0)
 #define LR_B(b) do { if constexpr (!(G8_ABL & 1)) read_B(b); } while (0)
     const int nk = p.K / BK;
-    if constexpr ((G8_ABL & 1) != 0) { read_A(0); read_B(0); }
+    if constexpr ((G8_ABL & 1) != 0) {
+        read_A(0);
+#pragma unroll
+        for (int b = 0; b < PB; ++b) read_B(b);
+    }
     if constexpr (S4) {
-        // piece order of the stream: A0 B0 B1 A1 | A0 B0 B1 A1 ...; phase q of K-tile t issues B0(t+1), B1(t+1), A1(t+1), A0(t+2)
-        issue_A(0); issue_B(0); issue_B(1); issue_A(1); issue_A(0);
-        CRIS_WAIT_VM_LGKM0(6);                      // A0(0), B0(0) of this wave have landed
+        // 256x256: two phases of 16 MFMAs per K-tile.  Piece stream: A0 B0 B1 A1 | A0 B0 B1 A1 ...; phase 1 of K-tile t issues
+        // A1(t+1), phase 2 issues A0(t+2) B0(t+2) B1(t+2) (every piece as early as its ring slot allows: two phases ahead)
+        issue_A(0); issue_B(0); issue_B(1); issue_A(1); issue_A(0); issue_B(0); issue_B(1);
+        CRIS_WAIT_VM_LGKM0(8);                      // A0(0), B0(0), B1(0) of this wave have landed
         CRIS_BARRIER();
         if ((G8_ABL & 64) == 0 && wm == 1) CRIS_BARRIER();                // group 1 runs one barrier behind from here on
         for (int kt = 0; kt < nk; ++kt) {
-            // q1: sub-block (0,0)
+            // phase 1: rows 0..63 of the wave tile
+            LI_A(1);
+            LR_A(0);
+            LR_B(0);
+            LR_B(1);
+            LOOP_WAIT(8, 6);               // fragments in registers; A1(kt) landed (4 pieces stay in flight)
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG16(0, MI_A(1));
+            LOOP_BARRIER();
+            // phase 2: rows 64..127
+            LI_A(0);
+            LI_B(0);
+            LI_B(1);
+            LR_A(1);
+            LOOP_WAIT(8, 2);               // A0(kt+1), B0(kt+1), B1(kt+1) landed
+            LOOP_BARRIER();
+            CRIS_MFMA_SEG16(1, MI_A(0); MI_B(0); MI_B(1));
+            LOOP_BARRIER();
+            rbuf = rbuf == 0 ? TILE_BYTES : 0;
+        }
+    } else if constexpr (S1) {
+        // 128x128: K-tile t+4 is issued while K-tile t is computed
+        constexpr int D = NBUF - 1;
+#pragma unroll
+        for (int d = 0; d < D; ++d) { issue_A(0); issue_B(0); }
+        CRIS_WAIT_VM_LGKM0((D - 1) * 4);            // K-tile 0 of this wave has landed
+        CRIS_BARRIER();
+        if ((G8_ABL & 64) == 0 && wm == 1) CRIS_BARRIER();
+        for (int kt = 0; kt < nk; ++kt) {
+            LI_A(0);
             LI_B(0);
             LR_A(0);
             LR_B(0);
-            LOOP_WAIT(6, 4);                  // fragments in registers; B1(kt) landed (3 pieces stay in flight)
+            LOOP_WAIT((D - 1) * 4, (D - 2) * 4);     // K-tile kt+1 landed
             LOOP_BARRIER();
-            CRIS_MFMA_SEG(0, 0, MI_B(0));
+            CRIS_MFMA_SEG(0, 0, MI_A(0); MI_B(0));
             LOOP_BARRIER();
-            // q2: (0,1)
-            LI_B(1);
-            LR_B(1);
-            LOOP_WAIT(6, 4);                  // A1(kt) landed
-            LOOP_BARRIER();
-            CRIS_MFMA_SEG(0, 1, MI_B(1));
-            LOOP_BARRIER();
-            // q3: (1,1)
-            LI_A(1);
-            LR_A(1);
-            LOOP_WAIT(63, 63);
-            LOOP_BARRIER();
-            CRIS_MFMA_SEG(1, 1, MI_A(1));
-            LOOP_BARRIER();
-            // q4: (1,0)
-            LI_A(0);
-            LR_B(0);
-            LOOP_WAIT(6, 4);                  // A0(kt+1), B0(kt+1) landed
-            LOOP_BARRIER();
-            CRIS_MFMA_SEG(1, 0, MI_A(0));
-            LOOP_BARRIER();
-            rbuf = rbuf == 0 ? TILE_BYTES : 0;
+            rbuf += TILE_BYTES;
+            if (rbuf == NBUF * TILE_BYTES) rbuf = 0;
         }
     } else if constexpr (PA == 2) {
         // 256x128: pieces A0 B A1 | A0 B A1 ...; q1 issues A1(t+1), A0(t+2); q2 issues B(t+2)
@@ -326,6 +364,7 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
     if ((G8_ABL & 64) == 0 && wm == 0) CRIS_BARRIER();    // same number of barriers for every wave
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 #undef CRIS_MFMA_SEG
+#undef CRIS_MFMA_SEG16
 #undef LI_A
 #undef MI_A
 #undef MI_B
@@ -333,6 +372,9 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
 #undef LR_A
 #undef LR_B
 
+    // (An epilogue staged through LDS - DPP pair exchange, 16-byte row stores instead of 2-byte stores in the C/D layout - was
+    // measured on the probe: no difference, 193.8 against 194.8 us at M 86528 / N 512 / K 2304; the fixed ~16 us per 256x256
+    // tile are launch + prologue latency + statistics + store issue in about equal parts, not the store width.)
     gemm_epilogue<EPI, 32, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * 2 + wm, lane);
 }
 
@@ -340,18 +382,19 @@ static int set_lds8(const void* kern, int bytes) {
     return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-// launcher used by cris_conv_gemm (gemm.hip): variant 0 = 256x256, 1 = 256x128, 2 = 128x256; epi as in gemm.hip
+// launcher used by cris_conv_gemm (gemm.hip): variant 0 = 256x256, 1 = 256x128, 2 = 128x256, 3 = 128x128; epi as in gemm.hip
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s) {
     typedef void (*kern_t)(const cris_conv_gemm_params);
-    static const kern_t k[3][3] = {
+    static const kern_t k[4][3] = {
         {conv_gemm8_kernel<2, 2, 0>, conv_gemm8_kernel<2, 2, 1>, conv_gemm8_kernel<2, 2, 2>},
         {conv_gemm8_kernel<2, 1, 0>, conv_gemm8_kernel<2, 1, 1>, conv_gemm8_kernel<2, 1, 2>},
-        {conv_gemm8_kernel<1, 2, 0>, conv_gemm8_kernel<1, 2, 1>, conv_gemm8_kernel<1, 2, 2>}};
-    static const int lds[3] = {2 * (256 + 256) * 128, 3 * (256 + 128) * 128, 3 * (128 + 256) * 128};
-    static const int bm[3] = {256, 256, 128}, bn[3] = {256, 128, 256};
+        {conv_gemm8_kernel<1, 2, 0>, conv_gemm8_kernel<1, 2, 1>, conv_gemm8_kernel<1, 2, 2>},
+        {conv_gemm8_kernel<1, 1, 0>, conv_gemm8_kernel<1, 1, 1>, conv_gemm8_kernel<1, 1, 2>}};
+    static const int lds[4] = {2 * (256 + 256) * 128, 3 * (256 + 128) * 128, 3 * (128 + 256) * 128, 5 * (128 + 128) * 128};
+    static const int bm[4] = {256, 256, 128, 128}, bn[4] = {256, 128, 256, 128};
     static const int ready = [&]() {
         int rc = 0;
-        for (int v = 0; v < 3; ++v)
+        for (int v = 0; v < 4; ++v)
             for (int e = 0; e < 3; ++e) rc |= set_lds8((const void*)k[v][e], lds[v]);
         return rc;
     }();
@@ -359,7 +402,7 @@ int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipS
         cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, ready);
         return ready;
     }
-    CRIS_CHECK_ARG(variant >= 0 && variant < 3, "unknown 8-wave variant");
+    CRIS_CHECK_ARG(variant >= 0 && variant < 4, "unknown 8-wave variant");
     CRIS_CHECK_ARG((p.C & 63) == 0, "8-wave tiles need C % 64 == 0");
     hipLaunchKernelGGL(k[variant][epi], dim3(cris_cdiv(p.M, bm[variant]) * cris_cdiv(p.N, bn[variant])), dim3(512), lds[variant], s, p);
     CRIS_LAUNCH_CHECK();

@@ -185,7 +185,7 @@ def test_conv_gemm_general_epilogue_large_tiles():
     check(outs[3], torch.rsqrt(ref.var(0, unbiased=False) + 1e-5), 3e-3, "invstd from 128x128 partials")
 
 
-G8 = ("8w256x256", "8w256x128", "8w128x256")
+G8 = ("8w256x256", "8w256x128", "8w128x256", "8w128x128")
 
 
 @pytest.mark.parametrize("variant", G8)
@@ -216,7 +216,7 @@ def test_conv_gemm_8wave_tiles(variant, case):
     ops.conv_gemm(xd, wd, g, N, out=base, variant="128x128")
     assert torch.equal(out, base), "%s differs from the 128x128 tile" % variant
     rows = st.rows_per_part
-    assert rows == (64 if variant == "8w128x256" else 128)
+    assert rows == (64 if variant in ("8w128x256", "8w128x128") else 128)
     y = ref                                            # (statistics are taken from the fp32 accumulators)
     for part in (0, (g.M - 1) // rows):
         blk = y[part * rows:(part + 1) * rows]

@@ -82,7 +82,9 @@ def main():
         for v in ["auto"] + want:
             if v != "auto" and v.startswith("8w") and C % 64:
                 continue
-            if v != "auto" and v.startswith("8w") and (M < 5000 or (v != "8w256x128" and N <= 128) or (v == "8w256x128" and N > 256)):
+            if v != "auto" and v.startswith("8w") and v != "8w128x128" and (M < 5000 or (v != "8w256x128" and N <= 128) or (v == "8w256x128" and N > 256)):
+                continue
+            if v == "8w128x128" and (M > 30000 or N <= 64):
                 continue
             try:
                 runners[v] = make_runner(M, N, K, k, -1 if v == "auto" else v, True, args.reps)

@@ -40,7 +40,7 @@ int main(int argc, char** argv) {
     void *dA, *dW, *dO;
     float *cs, *cq;
     hipMalloc(&dA, na * 2); hipMalloc(&dW, nw * 2); hipMalloc(&dO, no * 2);
-    const int rows = variant == 2 ? 64 : 128;
+    const int rows = variant >= 2 ? 64 : 128;
     const size_t nst = (size_t)((p.M + rows - 1) / rows) * N;
     hipMalloc((void**)&cs, nst * 4); hipMalloc((void**)&cq, nst * 4);
     hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
