@@ -351,18 +351,21 @@ static int pick_variant(const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
     if (lin && p.M <= 16) return V_SKINNY1;
     if (lin && p.M <= SKINNY_MAX_M) return V_SKINNY9;
-    // 8-wave ping-pong tiles (gemm8.hip) for the largest problems: one block per CU, so they need a few hundred tiles and a
-    // reduction long enough to amortise the 5-piece prologue.  CRIS_GEMM8_MIN_TILES = least number of tiles (0 = never).
-    static const int g8_min = cris_env_int("CRIS_GEMM8_MIN_TILES", 0);
-    static const int g8_min_k = cris_env_int("CRIS_GEMM8_MIN_K", 1024);
-    if (g8_min > 0 && (p.C & 63) == 0 && p.K >= g8_min_k) {
-        if (p.N > 128) {
+    // 8-wave ping-pong tiles (gemm8.hip; one block per CU): chosen from the per-shape A/B of tools/gemm_variants.py
+    // (profiles/r03_gemm_variants.tsv).  CRIS_GEMM8=0 switches the family off.
+    static const int g8 = cris_env_int("CRIS_GEMM8", 1);
+    static const int g8_min = cris_env_int("CRIS_GEMM8_MIN_TILES", 150);
+    static const int g8_min_k = cris_env_int("CRIS_GEMM8_MIN_K", 256);
+    static const int g8_t128_lo = cris_env_int("CRIS_GEMM8_T128_LO", 0), g8_t128_hi = cris_env_int("CRIS_GEMM8_T128_HI", 0);
+    if (g8 && (p.C & 63) == 0 && p.N > 128) {
+        const long t128 = (long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128);
+        // 128x128 with a five-deep ring: problems of about one tile per CU whose loop is latency-bound (mid-size layers)
+        if (p.K >= 512 && t128 >= g8_t128_lo && t128 <= g8_t128_hi) return V_8W_128x128;
+        if (p.K >= g8_min_k) {
             const long t256 = (long)cris_cdiv(p.M, 256) * cris_cdiv(p.N, 256);
-            // a grid of 1.0 .. 1.5 waves of 256x256 tiles idles half the chip in its second round: halve the rows instead
+            // (a grid of 1.0 .. 1.5 waves of 256x256 tiles idles half the chip in its second round: halve the rows instead)
             if (t256 >= g8_min && !(t256 > 256 && t256 <= 400)) return V_8W_256x256;
             if ((long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 256) >= g8_min) return V_8W_128x256;
-        } else if (p.N > 64) {
-            if ((long)cris_cdiv(p.M, 256) >= g8_min) return V_8W_256x128;
         }
     }
     if (p.N <= 64) return V_128x64;
