@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
 }
 
 // tile selection (host)
-enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_COUNT };
+enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_64x64D, V_64x128D, V_COUNT };
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s);       // gemm8.hip
 
 static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
@@ -356,19 +356,30 @@ static int pick_variant(const cris_conv_gemm_params& p) {
     static const int g8 = cris_env_int("CRIS_GEMM8", 1);
     static const int g8_min = cris_env_int("CRIS_GEMM8_MIN_TILES", 150);
     static const int g8_min_k = cris_env_int("CRIS_GEMM8_MIN_K", 256);
-    static const int g8_t128_lo = cris_env_int("CRIS_GEMM8_T128_LO", 0), g8_t128_hi = cris_env_int("CRIS_GEMM8_T128_HI", 0);
-    if (g8 && (p.C & 63) == 0 && p.N > 128) {
+    static const int g8_t128_lo = cris_env_int("CRIS_GEMM8_T128_LO", 100), g8_t128_hi = cris_env_int("CRIS_GEMM8_T128_HI", 200);
+    if (g8 && (p.C & 63) == 0 && p.N >= 128) {
         const long t128 = (long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128);
-        // 128x128 with a five-deep ring: problems of about one tile per CU whose loop is latency-bound (mid-size layers)
+        // 128x128 with a five-deep ring: problems of 0.4 - 0.8 tiles per CU whose loop is bound by operand latency (mid-size
+        // layers: M 5408 x N 512, M 1352 x N 2048, M 21632 x N 128): 36 against 51 us at M 5408 / N 512 / K 4608
         if (p.K >= 512 && t128 >= g8_t128_lo && t128 <= g8_t128_hi) return V_8W_128x128;
-        if (p.K >= g8_min_k) {
+        if (p.N > 128 && p.K >= g8_min_k) {
             const long t256 = (long)cris_cdiv(p.M, 256) * cris_cdiv(p.N, 256);
             // (a grid of 1.0 .. 1.5 waves of 256x256 tiles idles half the chip in its second round: halve the rows instead)
             if (t256 >= g8_min && !(t256 > 256 && t256 <= 400)) return V_8W_256x256;
-            if ((long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 256) >= g8_min) return V_8W_128x256;
+            const long t128x256 = (long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 256);
+            if (t128x256 >= g8_min && !(t128x256 > 256 && t128x256 <= 400)) return V_8W_128x256;
         }
     }
-    if (p.N <= 64) return V_128x64;
+    // deep-ring small tiles: at most one tile per CU and a reduction long enough to fill the ring
+    static const int deep_k = cris_env_int("CRIS_GEMM_DEEP_MIN_K", 0);
+    if (deep_k > 0 && p.K >= deep_k) {
+        if ((long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64) <= 256) return V_64x64D;
+        if (p.N >= 128 && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128) <= 256) return V_64x128D;
+    }
+    // N <= 64: the 64x64 tile beats 128x64 on every such layer of the step (per-shape A/B: 20.8 against 23.8 us at M 86528 /
+    // N 64 / K 576, 47.8 against 49.3 at M 346112 / N 32 / K 288); CRIS_GEMM_NARROW_128=1 brings the 128x64 tile back
+    static const int narrow128 = cris_env_int("CRIS_GEMM_NARROW_128", 0);
+    if (p.N <= 64) return narrow128 ? V_128x64 : V_64x64;
     // too few 128x128 tiles to occupy the chip: halve the tile (2 blocks of 72 KB LDS fit a CU).  Mid-size problems
     // (M <= 8192 rows: layers 3-4, neck, decoder) never take the 128x128 tile even when N is wide: measured on the decoder FFN
     // (M 5408, N 2048, K 512) 37 us with 64-row tiles against 48 us.
@@ -407,7 +418,7 @@ extern "C" int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, 
 }
 extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
 extern "C" const char* cris_conv_gemm_variant_name(int v) {
-    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128"};
+    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128", "64x64d", "64x128d"};
     return (v >= 0 && v < V_COUNT) ? names[v] : "?";
 }
 
@@ -449,10 +460,19 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     // with 5 blocks per CU 20.00 ms/step - neither helps)
     static const kern_t k_64x64[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 0>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 1>,
                                       conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 2>};
+    // the two small tiles again with a deep ring (8 x 16 KB / 6 x 24 KB: one block per CU, 5 - 7 K-steps in flight): problems of
+    // at most one tile per CU with a long reduction (M 1352 layers), whose loop waits for operands, not for the matrix pipe
+    constexpr int ST_64x64D = 8, ST_64x128D = 6;
+    constexpr int LDS_64x64D = ST_64x64D * (64 + 64) * 128, LDS_64x128D = ST_64x128D * (64 + 128) * 128;
+    static const kern_t k_64x64d[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64D, 0>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64D, 1>,
+                                       conv_gemm_kernel<64, 64, 2, 2, ST_64x64D, 2>};
+    static const kern_t k_64x128d[3] = {conv_gemm_kernel<64, 128, 2, 2, ST_64x128D, 0>, conv_gemm_kernel<64, 128, 2, 2, ST_64x128D, 1>,
+                                        conv_gemm_kernel<64, 128, 2, 2, ST_64x128D, 2>};
     static const int lds_ready = [&]() {
         int rc = 0;
         for (int e = 0; e < 3; ++e)
-            rc |= set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
+            rc |= set_lds((const void*)k_64x64d[e], LDS_64x64D) | set_lds((const void*)k_64x128d[e], LDS_64x128D) |
+                  set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
                   set_lds((const void*)k_128x128[e], LDS_128x128) | set_lds((const void*)k_64x64[e], LDS_64x64);
         return rc;
     }();
@@ -475,6 +495,12 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
             break;
         case V_128x64:
             hipLaunchKernelGGL(k_128x64[lean], dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256), LDS_128x64, s, p);
+            break;
+        case V_64x64D:
+            hipLaunchKernelGGL(k_64x64d[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64D, s, p);
+            break;
+        case V_64x128D:
+            hipLaunchKernelGGL(k_64x128d[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256), LDS_64x128D, s, p);
             break;
         case V_64x64:
             hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);

@@ -87,11 +87,16 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    // which index runs fastest inside an XCD's run of tiles (probe A/B, profiles/r03_gemm8_probe.md): the 256x256 tile keeps an
+    // A panel and sweeps the (few) column tiles - the two blocks that share an activation panel run side by side on one L2,
+    // 191 against 198 us at M 86528 / N 512 / K 2304; the 128x128 tile keeps a weight panel (35.5 against 39.8 us at
+    // M 5408 / N 512 / K 4608); the two 2-phase tiles follow gemm.hip's rule (weights beyond 2 MB: m fastest)
     int tile_m, tile_n;
 #ifndef G8_ORDER
-#define G8_ORDER 0                                  // probe A/B: 1 = n fastest always, 2 = m fastest always
+#define G8_ORDER 0                                  // probe: 1 = n fastest always, 2 = m fastest always
 #endif
-    if (G8_ORDER == 2 || (G8_ORDER == 0 && (long)p.N * p.K > (1L << 20))) {
+    const bool m_fastest = G8_ORDER == 2 || (G8_ORDER == 0 && (S1 || (!S4 && (long)p.N * p.K > (1L << 20))));
+    if (m_fastest) {
         tile_n = bid / tiles_m;
         tile_m = bid - tile_n * tiles_m;
     } else {

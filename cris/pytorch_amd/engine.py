@@ -19,7 +19,7 @@ from typing import Callable, Dict, List, Optional
 import torch
 from torch import nn
 
-from . import ops, tables
+from . import debug, ops, tables
 from .arch import ClipSpec, HeadSpec, build_param_tree
 from .ops import BF16, Drop, Geom, NO_DROP, pad8, pad32
 
@@ -93,8 +93,7 @@ class Engine:
         self.clip, self.head, self.dev = clip, head, device
         self.P, self.Bf = params, buffers
         self.comm = comm or Comm()
-        # (CRIS_FORCE_DIST=1: diagnostic - take the multi-rank code paths with a 1-rank communicator, tools/dist1_check.py)
-        self.sync_bn = sync_bn and (self.comm.world > 1 or os.environ.get("CRIS_FORCE_DIST", "0") == "1")
+        self.sync_bn = sync_bn and (self.comm.world > 1 or debug.HOOKS.force_dist)
         self.tape: List[Callable[[], None]] = []
         self.training = True
         self.seed = 0
@@ -102,13 +101,8 @@ class Engine:
         # the text encoder (12 layers of M = B*L ~ 136-row GEMMs: latency-bound, ~16 workgroups each) is independent of
         # the visual encoder until the neck: it runs on a second HIP stream, forward and backward, underneath the convs
         self.side = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
-        if os.environ.get("CRIS_NO_SIDE", "0") == "1":          # diagnostic: text encoder on the launch stream
+        if debug.HOOKS.no_side_stream:
             self.side = None
-        # diagnostics (tools/determinism_check.py): "sleep" holds the device back at the backward fork so that the two
-        # encoders' backward passes queue up and run fully concurrently; _dbg_taps (a list) collects stream-ordered copies
-        # of the gradient buffers after every text-backward closure
-        self._dbg = os.environ.get("CRIS_DEBUG", "")
-        self._dbg_taps = None
         # weight gradients of the mid-size layers are queued and launched together at arena-stage boundaries (ops.WgradQueue)
         self._wq, self._sq = ops.WgradQueue(self._flush_wgrads), ops.SumQueue()
         self._zslab, self._zcur, self._zneed, self._zneed_last = None, 0, 0, 0
@@ -220,7 +214,6 @@ class Engine:
                 a, b = zr.get(st, (lo, hi))
                 zr[st] = (min(a, lo), max(b, hi))
         self.zero_ranges = [self.grad_arena[a:b] for a, b in sorted(zr.values())]
-        self._zero_all = os.environ.get("CRIS_ZERO_ALL", "0") == "1"          # debugging aid: clear the whole arena
 
     def _add_pack(self, name, N, Cin, taps, Cpad=None, want_D=True, transposed=False):
         src = self.P[name]
@@ -295,30 +288,6 @@ class Engine:
 
     def _flush_wgrads(self):
         self._wq.flush()
-
-    def _tap(self, i, fn):
-        """diagnostic: copies (in stream order) of every gradient buffer the closure that just ran can see"""
-        objs = list(fn.__defaults__ or ()) + [c.cell_contents for c in (fn.__closure__ or ())]
-        rec = []
-        for k, o in enumerate(objs):
-            if isinstance(o, Act) and o.g is not None:
-                rec.append(("%d.g" % k, o.g.clone()))
-            elif isinstance(o, dict) and "buf" in o:
-                b = o["buf"]
-                for j, t in enumerate(b if isinstance(b, (tuple, list)) else (b,)):
-                    if torch.is_tensor(t):
-                        rec.append(("%d.buf%d" % (k, j), t.clone()))
-        extra = {}
-        if fn.__qualname__.startswith("Engine.ln."):                     # the closure's own inputs, by cell name
-            for nm, c in zip(fn.__code__.co_freevars, fn.__closure__ or ()):
-                o = c.cell_contents
-                if torch.is_tensor(o):
-                    extra[nm] = o.clone()
-                elif isinstance(o, Act):
-                    extra[nm + ".t"] = o.t.clone()
-                    if o.g is not None:
-                        extra[nm + ".g"] = o.g.clone()
-        self._dbg_taps.append((i, fn.__qualname__, rec, extra))
 
     def _flush_queues(self):
         """launch what backward has queued so far on the current stream: grouped weight gradients and the ordered sums of the
@@ -877,7 +846,7 @@ class Engine:
         self._zero_slab_begin()
         if training:
             self.comm.begin_step()
-            if self._zero_all:
+            if debug.HOOKS.zero_all:
                 ops.zero_(self.grad_arena)
             else:
                 ops.zero_ranges(self.zero_ranges)
@@ -966,7 +935,7 @@ class Engine:
             self.tape[i]()
             fire(i)
         self._flush_queues()
-        if "sleep" in self._dbg:
+        if debug.HOOKS.hold_backward_fork:
             torch.cuda._sleep(60000000)
         # the two encoders' backward passes are independent: text on the side stream, visual on the launch stream
         main = torch.cuda.current_stream()
@@ -974,8 +943,8 @@ class Engine:
         def text_section():
             for i in range(t1 - 1, t0 - 1, -1):
                 self.tape[i]()
-                if self._dbg_taps is not None:
-                    self._tap(i, self.tape[i])
+                if debug.HOOKS.taps is not None:
+                    debug.tap(i, self.tape[i])
             self._flush_queues()
             if on_stage_done is not None:
                 on_stage_done(4)                         # issued from the side stream: the exchange waits for it only

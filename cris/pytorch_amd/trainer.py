@@ -24,7 +24,7 @@ from typing import Optional
 
 import torch
 
-from . import ops
+from . import debug, ops
 from .arch import ClipSpec, HeadSpec
 from .engine import Engine
 
@@ -150,7 +150,7 @@ class NativeTrainer:
                 ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         else:
             ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
-        if self.comm.world > 1 or os.environ.get("CRIS_FORCE_DIST", "0") == "1":
+        if self.comm.world > 1 or debug.HOOKS.force_dist:
             def on_stage(st):
                 lo, hi = e.stage_ranges[st]
                 ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))

@@ -25,7 +25,7 @@ from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
-from cris.pytorch_amd import arch, selfcheck, synth  # noqa: E402
+from cris.pytorch_amd import arch, debug, selfcheck, synth  # noqa: E402
 from cris.pytorch_amd.trainer import NativeTrainer  # noqa: E402
 from oracle import cris_oracle as O  # noqa: E402
 
@@ -125,18 +125,17 @@ def test_training_step_is_deterministic():
         sd = arch.synthetic_state_dict(clip, head, 0)
         # the last run clears the WHOLE gradient arena every step instead of only the accumulated ranges: identical results
         # prove that every other gradient really is overwritten completely by its kernel (engine._build_grad_arena)
-        os.environ["CRIS_ZERO_ALL"] = "1" if rep == 3 else "0"
+        debug.HOOKS.zero_all = rep == 3
         try:
             tr = NativeTrainer(clip, head, sd, dev)
+            losses = []
+            for t in range(4):
+                img, word, mask = synth.make_batch(4, 64, head.word_len, 0, t)
+                loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
+                losses.append(float(loss))
+            torch.cuda.synchronize()
         finally:
-            os.environ.pop("CRIS_ZERO_ALL", None)
-        assert tr.engine._zero_all == (rep == 3)
-        losses = []
-        for t in range(4):
-            img, word, mask = synth.make_batch(4, 64, head.word_len, 0, t)
-            loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
-            losses.append(float(loss))
-        torch.cuda.synchronize()
+            debug.HOOKS.zero_all = False
         outs.append((losses, tr.engine.grad_arena.clone(), {k: v.clone() for k, v in tr.engine.P.items()}))
     for losses, arena, params in outs[1:]:
         assert losses == outs[0][0], (losses, outs[0][0])
@@ -159,13 +158,16 @@ def test_two_streams_do_not_disturb_each_other():
     outs = []
     for rep in range(2):
         tr = NativeTrainer(clip, head, arch.synthetic_state_dict(clip, head, 0), dev, launch="eager")
-        tr.engine._dbg = "sleep"
-        losses = []
-        for t in range(5):
-            img, word, mask = synth.make_batch(8, 416, head.word_len, 0, t % 4)
-            loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
-            losses.append(float(loss))
-        torch.cuda.synchronize()
+        debug.HOOKS.hold_backward_fork = True
+        try:
+            losses = []
+            for t in range(5):
+                img, word, mask = synth.make_batch(8, 416, head.word_len, 0, t % 4)
+                loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
+                losses.append(float(loss))
+            torch.cuda.synchronize()
+        finally:
+            debug.HOOKS.hold_backward_fork = False
         outs.append((losses, tr.engine.grad_arena.clone(), {k: v.clone() for k, v in tr.engine.P.items()}))
         del tr
     assert outs[0][0] == outs[1][0], (outs[0][0], outs[1][0])

@@ -51,7 +51,7 @@ def test_folded_schedule(recorder, spec, batch, size, word_len):
             continue
         assert len(e._fold) == n_bn - 2 and names["cris_bn_eval_coeffs"] == 2 and names["cris_bn_apply"] == 2
         assert names["cris_pack_weights"] == 0                     # frozen weights: nothing is packed again
-        gemms = [a[0]._obj for n, a in recorder if n == "cris_conv_gemm"]
+        gemms = [a[0]._obj for n, a in recorder if n == "cris_conv_gemm_variant"]
         shifts = {t[1].data_ptr() for t in e._fold.values()}
         fused = [p for p in gemms if p.bias in shifts]
         assert len(fused) == n_bn - 2                              # one fused launch per folded BatchNorm

@@ -60,7 +60,8 @@ def run(c, launch):
 
 la, launch_a, err_a, ms_a, sb = run(comm, "graph")
 lb, launch_b, err_b, ms_b, _ = run(comm, "eager")
-os.environ["CRIS_FORCE_DIST"] = "0"
+from cris.pytorch_amd import debug as _dbg
+_dbg.HOOKS.force_dist = False
 lc, _, _, ms_c, _ = run(None, "graph")
 out.update(sync_bn=sb, launch=launch_a, graph_error=err_a, losses_graph=la, losses_eager=lb, losses_local=lc,
            ms_graph=round(ms_a, 3), ms_eager=round(ms_b, 3), ms_local_graph=round(ms_c, 3))

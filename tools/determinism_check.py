@@ -8,7 +8,7 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from cris.pytorch_amd import arch, synth
+from cris.pytorch_amd import arch, debug, synth
 from cris.pytorch_amd.trainer import NativeTrainer
 
 spec, B, S, N = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
@@ -23,11 +23,11 @@ for r in range(2):
     for t in range(N):
         img, word, mask = synth.make_batch(B, S, head.word_len, 0, t % 4)
         if os.environ.get("TAPS") == "1":
-            tr.engine._dbg_taps = []
+            debug.HOOKS.taps = []
         loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
         torch.cuda.synchronize()
         if os.environ.get("TAPS") == "1":
-            taps.append(tr.engine._dbg_taps)
+            taps.append(debug.HOOKS.taps)
         losses.append(float(loss))
         if launch == "eager":
             arenas.append({k: v.clone() for k, v in tr.engine.G.items()})
