@@ -100,6 +100,87 @@ def launch_check(rank, world, args):
         dist.destroy_process_group()
 
 
+def module_path(args, rank, world, dev):
+    """The drop-in module under the reference's own recipe (train.py:96-111) and loop body (engine/engine.py:37-73), timed with the
+    same protocol as the native path.  What the unchanged engine imposes is inside the timed region: torch's Adam + GradScaler
+    (unscale / inf check over every gradient), DDP's bucket copies, the bf16 operand re-pack every step (a torch optimizer
+    changed the parameters), gradient export to `.grad`, trainMetricGPU with its three `.item()` host syncs.  Only the
+    logging (meters, wandb) and the DataLoader are left out: batches are resident in HBM."""
+    from types import SimpleNamespace as NS
+    from torch import nn
+    from cris.pytorch_amd import arch, synth
+    from cris.pytorch_amd.model import build_segmenter
+    assert args.spec == "r50", "--path module builds config/refcoco/cris_r50.yaml"
+    word_len = args.word_len if args.word_len is not None else (22 if args.size == 480 else 17)
+    cfg = NS(clip_pretrain="synthetic", word_len=word_len, fpn_in=[512, 1024, 1024], fpn_out=[256, 512, 1024], num_layers=3, vis_dim=512,
+             num_head=8, dim_ffn=2048, dropout=0.1, intermediate=False, word_dim=1024, base_lr=1e-4, lr_multi=0.1, sync_bn=True)
+    model, param_list = build_segmenter(cfg)                                              # train.py:96
+    if world > 1:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)                             # train.py:97-98
+        model = nn.parallel.DistributedDataParallel(model.cuda(), device_ids=[dev.index], find_unused_parameters=True)   # :100-102
+    else:
+        model = model.cuda()
+    optimizer = torch.optim.Adam(param_list, lr=cfg.base_lr, weight_decay=0.0)             # train.py:105-107
+    scaler = torch.amp.GradScaler("cuda")                                                 # train.py:111
+    nb = 4
+    batches = [tuple(t.to(dev) for t in synth.make_batch(args.batch, args.size, word_len, rank, s)) for s in range(nb)]
+
+    def step(i):
+        image, text, target = batches[i % nb]
+        target = target if target.dim() == 4 else target.unsqueeze(1)
+        with torch.autocast("cuda"):                                                      # engine/engine.py:48
+            pred, target, loss = model(image, text, target)
+        optimizer.zero_grad()
+        scaler.scale(loss).backward()
+        scaler.step(optimizer)
+        scaler.update()
+        o = (torch.sigmoid(pred.flatten(1)) >= 0.35)                                       # utils/misc.py:114-129
+        t = target.flatten(1).bool()
+        ious = (o & t).sum(1) / ((o | t).sum(1) + 1e-6)
+        iou, pr5 = 100.0 * ious.mean(), 100.0 * (ious > 0.5).float().mean()
+        l = loss.detach().clone()
+        if world > 1:
+            dist.all_reduce(l)
+            dist.all_reduce(iou)
+            dist.all_reduce(pr5)
+        return l.item() / world, iou.item() / world, pr5.item() / world                   # the meters' .item() syncs (:67-69)
+
+    model.train()
+    first = None
+    for i in range(max(args.warmup, 2)):
+        r = step(i)
+        first = first if first is not None else r[0]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        r = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    if rank == 0:
+        sps = world * args.batch * args.steps / dt
+        print(json.dumps({
+            "metric": "train-step samples/sec, CRIS-R50 416x416 bs=64; loss parity vs ref", "value": sps, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "drop-in module cris.pytorch_amd.model.CRIS under the reference's recipe and loop body (torch Adam, "
+                                   "GradScaler, fp16 autocast outside / bf16 HIP engine inside, trainMetricGPU + .item() syncs%s), "
+                                   "CRIS-R50 %dx%d, per-GPU bs=%d, %d-token text, batches resident in HBM"
+                                   % ("; SyncBatchNorm + DistributedDataParallel" if world > 1 else "", args.size, args.size, args.batch, word_len),
+                       "path": "module", "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first,
+                       "final_loss": r[0], "grad_scale": float(scaler.get_scale())},
+            "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12)}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -113,8 +194,17 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the Python schedule (no graph / command list)")
     ap.add_argument("--launch", default=None, choices=["graph", "cmdlist", "eager"], help="default: graph (N > 1: falls back to cmdlist if the capture fails on any rank)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
+                    help="N > 1: torch = torch.distributed process groups (RCCL through c10d; the default: the only one that has run on "
+                         "more than one rank - two ranks over gloo); native = dist.RcclComm, communicators owned by libcris_hip.so "
+                         "(cris_comm_*: exercised with one rank only so far)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     ap.add_argument("--shape-table", default=None, help="write the per-shape GEMM timing table (tsv) here")
+    ap.add_argument("--path", default="native", choices=["native", "module"],
+                    help="native: NativeTrainer (one captured HIP graph per step; the default bench line).  module: the path the north "
+                         "star names - build_segmenter(args) -> torch.optim.Adam over its two groups -> GradScaler, driven by the "
+                         "reference's loop body (engine/engine.py:37-73: fp16 autocast, scaled backward, scaler.step / update, "
+                         "trainMetricGPU + .item() syncs); N > 1: SyncBatchNorm + DistributedDataParallel as train.py:97-102")
     ap.add_argument("--launch-check", action="store_true",
                     help="exercise only the multi-rank launch protocol (spawn, rendezvous, barrier, max-over-ranks, one JSON "
                          "line from rank 0) without touching a GPU - what tests/test_bench_launch.py runs on the CPU")
@@ -144,13 +234,19 @@ def main():
             dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend=args.backend, rank=rank, world_size=world)
-        from cris.pytorch_amd.dist import TorchDistComm
-        comm = TorchDistComm(dev)
+        from cris.pytorch_amd.dist import RcclComm, TorchDistComm
+        if args.comm == "native" and args.backend == "nccl":
+            store = dist.distributed_c10d._get_default_store()
+            comm = RcclComm(rank, world, dev, store)
+        else:
+            comm = TorchDistComm(dev)
 
     import __graft_entry__ as g
     g.build()
     from cris.pytorch_amd import arch, synth, ops
     from cris.pytorch_amd.trainer import NativeTrainer
+    if args.path == "module":
+        return module_path(args, rank, world, dev)
 
     import dataclasses
     clip, head = arch.specs_by_name(args.spec)
@@ -213,7 +309,8 @@ def main():
                                    % (args.spec.upper(), args.size, args.size, args.batch, head.word_len,
                                       "" if world == 1 else "; x%d GPUs = configs[2] recipe: SyncBN + gradient all-reduce over RCCL" % world),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first_loss, "final_loss": loss_v,
-                       "launch": tr.launch, "graph_error": tr.graph_error},
+                       "launch": tr.launch, "graph_error": tr.graph_error, "syncbn_exchange": tr.syncbn_exchange,
+                       "comm": type(comm).__name__ if comm is not None else None},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12),
                               "hbm_frac_alg": (sps / world * ALG_BYTES_PER_SAMPLE + steps_s * ADAM_BYTES_PER_STEP) / (HBM_PEAK * 1e9)},
         }

@@ -233,11 +233,11 @@ struct BitReader {
             cnt -= e >> 8;
             return e & 255;
         }
-        int code = (int)peek(9), len = 9;
-        do {
-            ++len;
+        int code = 0, len;
+        for (len = 10; len <= 16; ++len) {           // (never peeks more than 16 bits: cnt >= 16 after fill())
             code = (int)peek(len);
-        } while (len <= 16 && code > t.maxcode[len]);
+            if (code <= t.maxcode[len]) break;
+        }
         if (len > 16) return -1;
         cnt -= len;
         return t.syms[(code + t.valoff[len]) & 255];

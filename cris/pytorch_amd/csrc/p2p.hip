@@ -1,4 +1,5 @@
-// Low-latency cross-rank sum of small fp32 vectors through peer-mapped mailboxes (EXPERIMENTAL; CRIS_SYNCBN_P2P=1).
+// Low-latency cross-rank sum of small fp32 vectors through peer-mapped mailboxes (the SyncBN exchange of the native trainer
+// when its start-up self-test passes on every rank; CRIS_SYNCBN_P2P=0 keeps the RCCL collectives).
 //
 // Why: with SyncBatchNorm (reference train.py:97-98) every BatchNorm layer exchanges 2C floats forward and 2C backward -
 // 142 collectives per CRIS-R50 step, each a few KB, strictly on the critical path.  Through torch.distributed / RCCL each one
@@ -135,9 +136,10 @@ __global__ __launch_bounds__(256) void p2p_allreduce_sum_kernel(const cris_p2p_p
     if ((int)threadIdx.x < p.world) {
         const int* flag = reinterpret_cast<const int*>(reinterpret_cast<float*>(p.boxes[p.rank]) + data_floats) + entry + threadIdx.x;
         long spins = 0;
+        const long limit = p.spin_limit > 0 ? (long)p.spin_limit : P2P_SPIN_LIMIT;
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gen) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > P2P_SPIN_LIMIT) {
+            if (++spins > limit) {
                 s_bad = 1;
                 break;
             }

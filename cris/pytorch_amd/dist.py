@@ -19,9 +19,10 @@ import torch.distributed as dist
 
 
 class PeerMailboxes:
-    """EXPERIMENTAL (CRIS_SYNCBN_P2P=1): the SyncBN exchange as one kernel over peer-mapped mailboxes instead of an RCCL
-    collective per BatchNorm layer (csrc/p2p.hip, include/cris_hip.h cris_p2p_*).  Every rank allocates a fine-grained
-    mailbox, the 64-byte IPC handles travel once through torch.distributed, every rank maps every peer's mailbox."""
+    """The SyncBN exchange as one kernel over peer-mapped mailboxes instead of an RCCL collective per BatchNorm layer
+    (csrc/p2p.hip, include/cris_hip.h cris_p2p_*).  Every rank allocates an uncached mailbox, the 64-byte IPC handles travel
+    once through torch.distributed, every rank maps every peer's mailbox.  `self_test()` runs a few exchanges with known data
+    and a short poll limit; the trainer switches to the mailboxes only when that passed on EVERY rank."""
 
     def __init__(self, rank, world, device, slots, max_floats):
         from . import hip
@@ -49,9 +50,26 @@ class PeerMailboxes:
         self.err = torch.zeros(1, dtype=torch.int32, device=device)
         dist.barrier()                              # nobody writes into a mailbox that is not mapped yet
 
-    def allreduce_sum(self, t, slot, gen_dev=None, gen_host=0):
+    def self_test(self, spin_limit=1 << 19):
+        """three generations of one exchange with known data (rank r contributes r + 1 + i/7): True when every sum is right and
+        no peer was reported missing.  The poll limit is short (a fraction of a second), so a mapping that does not
+        propagate stores fails here instead of stalling the first training step."""
+        n = min(self.max_floats, 1000)
+        idx = torch.arange(n, device=self.boxes.device, dtype=torch.float32) / 7.0
+        want = sum(float(q + 1) for q in range(self.world)) + self.world * idx
+        ok = True
+        for gen in range(3):
+            t = (float(self.rank + 1) + idx + float(gen)).contiguous()
+            self.allreduce_sum(t, self.slots - 1, gen_host=1000 + gen, spin_limit=spin_limit)
+            torch.cuda.synchronize()
+            ok = ok and bool(torch.allclose(t, want + self.world * float(gen), rtol=0, atol=1e-3)) and int(self.err.item()) == 0
+        self.err.zero_()
+        return ok
+
+    def allreduce_sum(self, t, slot, gen_dev=None, gen_host=0, spin_limit=0):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= self.max_floats and slot < self.slots
         prm = self.hip.P2PParams()
+        prm.spin_limit = spin_limit
         prm.data, prm.boxes, prm.err = t.data_ptr(), self.boxes.data_ptr(), self.err.data_ptr()
         prm.gen_dev = None if gen_dev is None else gen_dev.data_ptr()
         prm.n, prm.rank, prm.world = t.numel(), self.rank, self.world
@@ -85,9 +103,27 @@ class TorchDistComm:
         self.p2p, self._gen_dev, self._slot = None, None, 0
 
     def enable_p2p(self, slots, max_floats, gen_dev):
-        """Route allreduce_sum (the SyncBN exchanges) through peer mailboxes; `gen_dev` = the trainer's device step counter."""
-        self.p2p = PeerMailboxes(self.rank, self.world, self.device, slots, max_floats)
-        self._gen_dev = gen_dev
+        """Route allreduce_sum (the SyncBN exchanges) through peer mailboxes; `gen_dev` = the trainer's device step counter.
+        Collective.  Returns None when the mailboxes are in use, else the reason they are not (allocation / IPC mapping /
+        self-test failed on some rank: every rank then keeps the RCCL collectives)."""
+        err, box = None, None
+        try:
+            box = PeerMailboxes(self.rank, self.world, self.device, slots + 1, max_floats)     # (+1: the self-test's slot)
+        except Exception as ex:              # noqa: BLE001 - e.g. IPC handles not importable between these devices
+            err = "rank %d: %r" % (self.rank, ex)
+        errs = [e for e in self.all_gather_object(err) if e]
+        if not errs:
+            ok = box.self_test()
+            errs = ["rank %d: self-test failed" % q for q, o in enumerate(self.all_gather_object(ok)) if not o]
+        if errs:
+            if box is not None:
+                try:
+                    box.close()
+                except Exception:            # noqa: BLE001
+                    pass
+            return "; ".join(errs)[:300]
+        self.p2p, self._gen_dev = box, gen_dev
+        return None
 
     def begin_step(self):
         self._slot = 0

@@ -89,8 +89,11 @@ class Comm:
 
 class Engine:
     def __init__(self, clip: ClipSpec, head: HeadSpec, params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor],
-                 device, comm: Optional[Comm] = None, sync_bn: bool = False):
+                 device, comm: Optional[Comm] = None, sync_bn: bool = False, inference_only: bool = False):
         self.clip, self.head, self.dev = clip, head, device
+        # inference_only (infer.InferEngine): no gradient arena (587 MB fp32 at R50) and no input-gradient weight packs -
+        # a model that evaluates during training (engine/engine.py:90-123 `validate`) would otherwise hold both twice
+        self.inference_only = inference_only
         self.P, self.Bf = params, buffers
         self.comm = comm or Comm()
         self.sync_bn = sync_bn and (self.comm.world > 1 or debug.HOOKS.force_dist)
@@ -198,6 +201,10 @@ class Engine:
                 n *= d
             offs[name] = (total, n)
             total += (n + 3) // 4 * 4            # keep every view 16-byte aligned
+        if self.inference_only:
+            self.grad_arena, self.G = None, {name: None for name in offs}
+            self.grad_order, self.grad_offsets, self.bn_pairs, self.stage_ranges, self.zero_ranges = order, offs, pairs, {}, []
+            return
         self.grad_arena = torch.zeros(total, dtype=F32, device=self.dev)
         self.G = {name: self.grad_arena[o:o + n].view(shapes[name]) for name, (o, n) in offs.items()}
         self.grad_order = order
@@ -229,14 +236,15 @@ class Engine:
         self.packs = {st: ops.PackTable() for st in range(8)}
         self.packs_current = False
         self.WF, self.WD, self.pack_info = {}, {}, {}
+        wd = not self.inference_only
         for name, p in self.P.items():
             if p.dim() == 4:
                 N, Cin, taps, Cpad = self.gemm_layout(name)
-                self._add_pack(name, N, Cin, taps, Cpad=Cpad, want_D=name != "backbone.visual.conv1.weight")
+                self._add_pack(name, N, Cin, taps, Cpad=Cpad, want_D=wd and name != "backbone.visual.conv1.weight")
             elif name == "backbone.text_projection":
-                self._add_pack(name, p.shape[1], p.shape[0], 1, transposed=True)      # used as x @ P
+                self._add_pack(name, p.shape[1], p.shape[0], 1, want_D=wd, transposed=True)      # used as x @ P
             elif p.dim() == 2 and name.endswith(("weight", "in_proj_weight")) and "embedding" not in name:
-                self._add_pack(name, p.shape[0], p.shape[1], 1)
+                self._add_pack(name, p.shape[0], p.shape[1], 1, want_D=wd)
         for t in self.packs.values():
             if t.descs:
                 t.finalize(self.dev)
@@ -315,7 +323,7 @@ class Engine:
         if rows is not None:
             n0, n1 = rows
             Wf = Wf[n0:n1]
-            Gw = Gw[n0:n1]
+            Gw = Gw[n0:n1] if Gw is not None else None
         ldbF = self.WF[wname].shape[1]
         bias_t = None
         if bias is not None:

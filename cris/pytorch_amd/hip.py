@@ -191,7 +191,7 @@ class P2PParams(C.Structure):
                 ("slot", I), ("slots", I),
                 ("max_floats", I),
                 ("gen_host", I),
-                ("pad_", I)]
+                ("spin_limit", I)]
 
 
 STRUCTS = {

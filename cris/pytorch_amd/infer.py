@@ -40,11 +40,13 @@ class _Pending:
 class InferEngine(Engine):
     def __init__(self, clip: ClipSpec, head: HeadSpec, params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor], device,
                  fold_bn: bool = True):
-        super().__init__(clip, head, params, buffers, device)
+        super().__init__(clip, head, params, buffers, device, inference_only=True)
         self.fold_bn = fold_bn
         self._fold = {}                 # (conv weight name, BatchNorm prefix) -> (bf16 F pack of W * s, shift t, keep-alive)
 
     def forward(self, img, word, mask=None, training=False, **kw):
+        if training:
+            raise RuntimeError("InferEngine is built without a gradient arena: use Engine / NativeTrainer for training")
         out = super().forward(img, word, mask, training=training, **kw)
         if not training:
             self.packs_current = True       # frozen weights: the bf16 operand copies made by this forward stay valid

@@ -178,6 +178,15 @@ class CRIS(nn.Module):
                 return self._eval_forward_folded(img, word)
             return eng.forward(img, word, None, training=False).detach()
 
+    def invalidate_inference_cache(self):
+        """Forget the folded weights / captured graph of the eval path.  The cache notices optimizer steps, load_state_dict and
+        training forwards by itself (torch version counters, `_steps`); writes that bypass the version counter do NOT show
+        (`p.data.copy_()`, `p.data.mul_()` in EMA or weight-surgery code, another engine updating the shared tensors through
+        raw pointers) - call this after such a write, before the next `model.eval()` forward."""
+        if getattr(self, "_infer", None) is not None:
+            self._infer.invalidate()
+        self._infer_sig = None
+
     def _eval_forward_folded(self, img, word):
         """`model.eval()` forward (engine/engine.py:100,171; test.py; tools/latency.py:62) on the inference engine: BatchNorms
         folded into their convolutions, one HIP graph per input shape (infer.py).  The folded weights are a cache of the

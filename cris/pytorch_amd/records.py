@@ -24,7 +24,10 @@ from .tokenizer import BPETokenizer
 
 
 def load_record(value: bytes) -> dict:
-    """one LMDB value -> the record dict (tools/folder2lmdb.py:50-56)"""
+    """one LMDB value -> the record dict (tools/folder2lmdb.py:50-56).
+    TRUST: the reference's records are pickles, and unpickling executes whatever the file says - exactly as the reference's own
+    loader does (utils/dataset.py:92).  Only feed this datasets you built yourself (tools/folder2lmdb.py); the JPEG / PNG
+    parsers behind it are hardened against corrupt input, the pickle layer cannot be."""
     rec = pickle.loads(value)
     if not isinstance(rec, dict) or "img" not in rec:
         raise ValueError("not a CRIS record (expected a dict with 'img', 'mask', 'sents', ...)")

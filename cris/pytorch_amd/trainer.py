@@ -83,11 +83,15 @@ class NativeTrainer:
         # per-step device state: steps done (int32) and the dropout seed of the running step
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)
-        if (self.comm.world > 1 and e.sync_bn and os.environ.get("CRIS_SYNCBN_P2P", "0") == "1"
-                and torch.device(device).type == "cuda"):
-            # EXPERIMENTAL: SyncBN statistics through peer-mapped mailboxes, one kernel per exchange (dist.PeerMailboxes)
+        # SyncBN statistics: 142 exchanges of a few KB per step, all on the critical path.  Default: peer-mapped mailboxes, one
+        # kernel per exchange (dist.PeerMailboxes) - when allocation, IPC mapping and a self-test with known data succeed on
+        # EVERY rank; otherwise (and with CRIS_SYNCBN_P2P=0, or a communicator without mailboxes) the RCCL collectives.
+        self.syncbn_exchange = "none" if not (self.comm.world > 1 and e.sync_bn) else "collective"
+        if (self.comm.world > 1 and e.sync_bn and os.environ.get("CRIS_SYNCBN_P2P", "1") == "1"
+                and torch.device(device).type == "cuda" and hasattr(self.comm, "enable_p2p")):
             cmax = max(e.P[pfx + ".weight"].numel() for pfx in e.bn_prefixes)
-            self.comm.enable_p2p(slots=2 * len(e.bn_prefixes) + 8, max_floats=4 * cmax, gen_dev=self.step_dev)
+            why = self.comm.enable_p2p(slots=2 * len(e.bn_prefixes) + 8, max_floats=4 * cmax, gen_dev=self.step_dev)
+            self.syncbn_exchange = "p2p mailboxes" if why is None else "collective (mailboxes refused: %s)" % why
         if launch is None:
             launch = os.environ.get("CRIS_LAUNCH")
         if launch is None:

@@ -435,7 +435,7 @@ typedef struct {
     int slot, slots;          /* which exchange of the step this is; exchanges per step the mailbox was sized for */
     int max_floats;           /* vector capacity the mailbox was sized for */
     int gen_host;
-    int pad_;
+    int spin_limit;          /* polls before a missing peer is reported (err[0] = 1, NaN result); 0 = the default (~seconds) */
 } cris_p2p_params;
 int cris_p2p_allreduce_sum(const cris_p2p_params* p, void* stream);
 
