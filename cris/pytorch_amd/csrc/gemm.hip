@@ -334,7 +334,7 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
 }
 
 // tile selection (host)
-enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_64x64D, V_64x128D, V_COUNT };
+enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_COUNT };
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s);       // gemm8.hip
 
 static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
@@ -370,12 +370,9 @@ static int pick_variant(const cris_conv_gemm_params& p) {
             if (t128x256 >= g8_min && !(t128x256 > 256 && t128x256 <= 400)) return V_8W_128x256;
         }
     }
-    // deep-ring small tiles: at most one tile per CU and a reduction long enough to fill the ring
-    static const int deep_k = cris_env_int("CRIS_GEMM_DEEP_MIN_K", 0);
-    if (deep_k > 0 && p.K >= deep_k) {
-        if ((long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64) <= 256) return V_64x64D;
-        if (p.N >= 128 && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128) <= 256) return V_64x128D;
-    }
+    // (Measured and rejected, call r03e: the 64x64 / 64x128 tiles with an 8- / 6-deep ring and one block per CU for the M 1352
+    // layers - 30.1 against 29.3 us at M 1352 / N 512 / K 4608, the wider one 41 against 29: those layers are not short of
+    // operands in flight.)
     // N <= 64: the 64x64 tile beats 128x64 on every such layer of the step (per-shape A/B: 20.8 against 23.8 us at M 86528 /
     // N 64 / K 576, 47.8 against 49.3 at M 346112 / N 32 / K 288); CRIS_GEMM_NARROW_128=1 brings the 128x64 tile back
     static const int narrow128 = cris_env_int("CRIS_GEMM_NARROW_128", 0);
@@ -418,7 +415,7 @@ extern "C" int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, 
 }
 extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
 extern "C" const char* cris_conv_gemm_variant_name(int v) {
-    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128", "64x64d", "64x128d"};
+    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128"};
     return (v >= 0 && v < V_COUNT) ? names[v] : "?";
 }
 
@@ -460,19 +457,10 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     // with 5 blocks per CU 20.00 ms/step - neither helps)
     static const kern_t k_64x64[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 0>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 1>,
                                       conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 2>};
-    // the two small tiles again with a deep ring (8 x 16 KB / 6 x 24 KB: one block per CU, 5 - 7 K-steps in flight): problems of
-    // at most one tile per CU with a long reduction (M 1352 layers), whose loop waits for operands, not for the matrix pipe
-    constexpr int ST_64x64D = 8, ST_64x128D = 6;
-    constexpr int LDS_64x64D = ST_64x64D * (64 + 64) * 128, LDS_64x128D = ST_64x128D * (64 + 128) * 128;
-    static const kern_t k_64x64d[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64D, 0>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64D, 1>,
-                                       conv_gemm_kernel<64, 64, 2, 2, ST_64x64D, 2>};
-    static const kern_t k_64x128d[3] = {conv_gemm_kernel<64, 128, 2, 2, ST_64x128D, 0>, conv_gemm_kernel<64, 128, 2, 2, ST_64x128D, 1>,
-                                        conv_gemm_kernel<64, 128, 2, 2, ST_64x128D, 2>};
     static const int lds_ready = [&]() {
         int rc = 0;
         for (int e = 0; e < 3; ++e)
-            rc |= set_lds((const void*)k_64x64d[e], LDS_64x64D) | set_lds((const void*)k_64x128d[e], LDS_64x128D) |
-                  set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
+            rc |= set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
                   set_lds((const void*)k_128x128[e], LDS_128x128) | set_lds((const void*)k_64x64[e], LDS_64x64);
         return rc;
     }();
@@ -495,12 +483,6 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
             break;
         case V_128x64:
             hipLaunchKernelGGL(k_128x64[lean], dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 64)), dim3(256), LDS_128x64, s, p);
-            break;
-        case V_64x64D:
-            hipLaunchKernelGGL(k_64x64d[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64D, s, p);
-            break;
-        case V_64x128D:
-            hipLaunchKernelGGL(k_64x128d[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256), LDS_64x128D, s, p);
             break;
         case V_64x64:
             hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);

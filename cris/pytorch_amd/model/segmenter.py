@@ -72,8 +72,13 @@ class _CrisStep(torch.autograd.Function):
     @torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
     def forward(ctx, module, img, word, mask, seed, *params):
         eng = module._engine
-        pred, msk, loss = eng.forward(img, word, mask, training=True, seed=seed)
         ctx.module = module
+        st = module._graph_step(img, word, mask, seed)
+        ctx.graph = st
+        if st is not None:                       # replayed HIP graph: outputs are the capture's static buffers (fresh aliases)
+            pred, msk, loss = st["pred"].view_as(st["pred"]), st["msk"].view_as(st["msk"]), st["loss"].view(())
+        else:
+            pred, msk, loss = eng.forward(img, word, mask, training=True, seed=seed)
         ctx.mark_non_differentiable(pred, msk)
         return pred, msk, loss
 
@@ -83,8 +88,14 @@ class _CrisStep(torch.autograd.Function):
         module = ctx.module
         eng = module._engine
         gscale = gloss.detach().reshape(1).to(torch.float32).contiguous()        # GradScaler's factor arrives here
-        eng.backward(gscale=gscale)
-        grads = module._export_grads()
+        st = ctx.graph
+        if st is not None:
+            st["gscale"].copy_(gscale, non_blocking=True)
+            st["bwd"].replay()
+            grads = st["grads"]
+        else:
+            eng.backward(gscale=gscale)
+            grads = module._export_grads()
         return (None, None, None, None, None) + tuple(grads)
 
 
@@ -111,6 +122,7 @@ class CRIS(nn.Module):
         self.backbone.load_state_dict(load, strict=False)
         self._engine = None
         self._engine_key = None
+        self.graph_error = None
         self._steps = 0
         self._unpack = None
 
@@ -154,6 +166,69 @@ class CRIS(nn.Module):
         if self._unpack is not None:
             self._unpack.run()
         return [self._grad_out[n] for n, _ in self._grad_params()]
+
+    # ------------------------------------------------------------------------------------------------
+    # HIP-graph replay of the training step under torch's autograd.  The engine's schedule is ~1000 launches; issued from
+    # Python one by one it is host-bound (37.5 ms per R50 step against 13.8 for the native trainer, bench.py --path module,
+    # round 3).  So the module captures, per input shape, TWO graphs over one memory pool - forward + loss (incl. the re-pack
+    # of the bf16 operand copies: a torch optimizer changed the parameters) and backward + gradient export - and replays them
+    # from _CrisStep.forward / .backward.  Step-varying scalars live in device memory: the dropout seed (Engine.seed_dev) and
+    # GradScaler's factor (gscale).  First call of a shape runs eagerly (tables, allocator warm-up), the second captures.
+    # Eager launches remain for: CRIS_MODULE_GRAPH=0, more than MAX_GRAPH_SHAPES shapes, a communicator whose collectives
+    # cannot be captured (gloo), and any capture failure (reported once in `graph_error`).
+    MAX_GRAPH_SHAPES = 6
+
+    def _graph_step(self, img, word, mask, seed):
+        """replay (capturing first if needed) the forward graph for this step; None = run the eager schedule"""
+        if os.environ.get("CRIS_MODULE_GRAPH", "1") != "1":
+            return None
+        eng = self._engine
+        if eng.comm.world > 1 and not getattr(eng.comm, "capturable", False):
+            return None
+        if getattr(self, "_graphs_key", None) != self._engine_key:           # parameters moved (.cuda() / .to()): start over
+            self._graphs, self._graphs_key, self._graph_seen, self.graph_error = {}, self._engine_key, set(), None
+        key = (tuple(img.shape), tuple(word.shape), tuple(mask.shape), img.dtype, mask.dtype, word.dtype)
+        st = self._graphs.get(key)
+        if st is None:
+            if self.graph_error is not None or len(self._graphs) >= self.MAX_GRAPH_SHAPES:
+                return None
+            if key not in self._graph_seen:
+                self._graph_seen.add(key)
+                return None                                                  # first step with these shapes: eager
+            try:
+                st = self._capture_graphs(img, word, mask)
+            except Exception as ex:              # noqa: BLE001 - fall back to the eager schedule, say why once
+                self.graph_error = repr(ex)
+                torch.cuda.synchronize()
+                eng.seed_dev = None
+                return None
+            self._graphs[key] = st
+        st["img"].copy_(img, non_blocking=True)
+        st["word"].copy_(word, non_blocking=True)
+        st["mask"].copy_(mask, non_blocking=True)
+        st["seed"].fill_(((int(seed) & 0xFFFFFFFF) ^ 0x80000000) - 0x80000000)     # the uint32 seed's bit pattern in the int32 word
+        st["fwd"].replay()
+        return st
+
+    def _capture_graphs(self, img, word, mask):
+        eng = self._engine
+        st = dict(img=img.clone(), word=word.clone(), mask=mask.clone(),
+                  seed=torch.zeros(1, dtype=torch.int32, device=img.device), gscale=torch.ones(1, dtype=torch.float32, device=img.device))
+        torch.cuda.synchronize()
+        pool = torch.cuda.graph_pool_handle()
+        fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        eng.seed_dev = st["seed"]
+        try:
+            eng.packs_current = False                                        # the re-pack belongs to every replay
+            with torch.cuda.graph(fwd, pool=pool):
+                pred, msk, loss = eng.forward(st["img"], st["word"], st["mask"], training=True, seed=0)
+            with torch.cuda.graph(bwd, pool=pool):
+                eng.backward(gscale=st["gscale"])
+                grads = self._export_grads()
+        finally:
+            eng.seed_dev = None
+        st.update(fwd=fwd, bwd=bwd, pred=pred, msk=msk, loss=loss, grads=grads)
+        return st
 
     def forward(self, img, word, mask=None):
         """img: b, 3, h, w ; word: b, words ; mask: b, 1, h, w   (reference model/segmenter.py:29-35)"""

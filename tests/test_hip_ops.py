@@ -228,29 +228,6 @@ def test_conv_gemm_8wave_tiles(variant, case):
         assert torch.equal(out, again), "%s is not reproducible" % variant
 
 
-@pytest.mark.parametrize("variant", ["64x64d", "64x128d"])
-@pytest.mark.parametrize("case", [
-    dict(B=8, H=13, W=13, C=512, N=512, k=3),         # benchmark shape M 1352 N 512 K 4608: 72 K-steps through an 8- / 6-deep ring
-    dict(B=2, H=9, W=9, C=136, N=200, k=3),           # general K-step path (C % 64 != 0), ragged tails, fewer K-steps than ring slots
-    dict(B=3, H=7, W=7, C=64, N=136, k=1),            # ONE K-step: the prologue over-issues the whole ring
-])
-def test_conv_gemm_deep_ring_tiles(variant, case):
-    """the 64x64 / 64x128 tiles with a deep LDS-DMA ring (one block per CU): bit-identical with the standard ring"""
-    B, H, W, C_, N, k = case["B"], case["H"], case["W"], case["C"], case["N"], case["k"]
-    pad = k // 2
-    x = rnd(B, H, W, C_).to(BF).float()
-    w = (rnd(N, C_, k, k, seed=1) / math.sqrt(C_ * k * k)).to(BF).float()
-    g = Geom(B, H, W, C_, k, k, 1, pad)
-    xd, wd = bf(x), bf(pack_F(w))
-    out = torch.empty(g.M, N, dtype=BF, device=DEV)
-    st = ops.conv_gemm(xd, wd, g, N, out=out, stats=True, variant=variant)
-    check(out, conv_ref(x, w, 1, pad), 6e-3, "%s %s" % (variant, case))
-    base = torch.empty(g.M, N, dtype=BF, device=DEV)
-    st0 = ops.conv_gemm(xd, wd, g, N, out=base, stats=True, variant=variant[:-1])
-    assert torch.equal(out, base) and st.rows_per_part == st0.rows_per_part
-    assert torch.equal(st[0][:st.nparts], st0[0][:st0.nparts]) and torch.equal(st[1][:st.nparts], st0[1][:st0.nparts])
-
-
 @pytest.mark.parametrize("variant", G8)
 def test_conv_gemm_8wave_epilogues(variant):
     """general epilogue (bias, QuickGELU, fp32 residual / output, dropout) and the residual of the lean one on the 8-wave tiles"""

@@ -50,6 +50,48 @@ def test_module_train_loop_matches_native_trainer():
     assert int(model.backbone.visual.bn1.num_batches_tracked) == 4
 
 
+def _run_module(graph, steps=5, shapes=((4, 64),)):
+    import os
+    os.environ["CRIS_MODULE_GRAPH"] = "1" if graph else "0"
+    try:
+        dev = torch.device("cuda:0")
+        model, groups = build_segmenter(NS(**TINY))
+        clip, head = arch.specs_by_name("tiny")
+        model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+        model = model.to(dev).train()
+        opt = torch.optim.Adam(groups, lr=1e-4, weight_decay=0.0)
+        scaler = torch.amp.GradScaler("cuda")
+        losses = []
+        for step in range(steps):
+            b, s_ = shapes[step % len(shapes)]
+            img, word, mask = (t.to(dev) for t in synth.make_batch(b, s_, 9, 0, step))
+            with torch.autocast("cuda"):
+                pred, target, loss = model(img, word, mask)
+            opt.zero_grad()
+            scaler.scale(loss).backward()
+            scaler.step(opt)
+            scaler.update()
+            losses.append((float(loss), float(pred.float().abs().sum())))
+        torch.cuda.synchronize()
+        return losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, model
+    finally:
+        os.environ.pop("CRIS_MODULE_GRAPH", None)
+
+
+def test_module_graph_replay_equals_the_eager_schedule():
+    """the drop-in module replays two captured HIP graphs per step (forward + loss, backward + gradient export) from its
+    autograd node; the dropout seed and GradScaler's factor live in device memory.  Same kernels in the same order: losses,
+    logits and the parameters after five torch-Adam steps are bit-identical to the eager schedule - with one input shape
+    (steps 0 eager, 1 capture, 2.. replay) and with two alternating shapes (two graph pairs over separate pools)."""
+    for shapes in (((4, 64),), ((4, 64), (2, 96))):
+        steps = 5 if len(shapes) == 1 else 8
+        lg, sg, mg = _run_module(True, steps, shapes)
+        le, se, _ = _run_module(False, steps, shapes)
+        assert mg.graph_error is None and len(mg._graphs) == len(shapes), (mg.graph_error, len(mg._graphs))
+        assert lg == le, (lg, le)
+        assert all(torch.equal(sg[k], se[k]) for k in sg)
+
+
 def test_module_eval_and_checkpoint_reload():
     dev = torch.device("cuda:0")
     model, _ = build_segmenter(NS(**TINY))

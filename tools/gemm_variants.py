@@ -86,10 +86,6 @@ def main():
                 continue
             if v == "8w128x128" and (M > 30000 or N <= 64):
                 continue
-            if v == "64x64d" and -(-M // 64) * -(-N // 64) > 400:
-                continue
-            if v == "64x128d" and (-(-M // 64) * -(-N // 128) > 400 or N < 128):
-                continue
             try:
                 runners[v] = make_runner(M, N, K, k, -1 if v == "auto" else v, True, args.reps)
             except Exception as e:      # noqa: BLE001
