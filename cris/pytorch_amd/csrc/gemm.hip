@@ -334,8 +334,15 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
 }
 
 // tile selection (host)
-enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_COUNT };
+enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_STREAM128, V_STREAM64, V_COUNT };
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s);       // gemm8.hip
+int cris_launch_gemm_stream(int bn, const cris_conv_gemm_params& p, int epi, hipStream_t s);     // gemm_stream.hip
+
+// which epilogue instantiation a problem takes: 0 general, 1 lean, 2 lean + bias / ReLU (see gemm_epilogue)
+static int epilogue_kind(const cris_conv_gemm_params& p) {
+    const bool plain = p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32);
+    return !plain ? 0 : (!p.bias && p.act == 0) ? 1 : (p.act == 0 || p.act == 1 || p.act == 3) ? 2 : 0;
+}
 
 static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
@@ -343,6 +350,7 @@ static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
         case V_SKINNY1: return lin && p.M <= 16;
         case V_SKINNY9: return lin && p.M <= SKINNY_MAX_M;
         case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128: return (p.C & 63) == 0;
+        case V_STREAM128: case V_STREAM64: return lin && (p.C & 63) == 0 && p.K <= 256 && epilogue_kind(p) != 0;
         default: return v >= 0 && v < V_COUNT;
     }
 }
@@ -351,13 +359,19 @@ static int pick_variant(const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
     if (lin && p.M <= 16) return V_SKINNY1;
     if (lin && p.M <= SKINNY_MAX_M) return V_SKINNY9;
+    // streaming kernel (gemm_stream.hip) for the HBM-bound 1x1 convolutions of the large feature maps
+    static const int stream_min_m = cris_env_int("CRIS_GEMM_STREAM_MIN_M", 0);
+    if (stream_min_m > 0 && lin && p.M >= stream_min_m && (p.C & 63) == 0 && p.K <= 256 && epilogue_kind(p) != 0)
+        return p.N > 64 ? V_STREAM128 : V_STREAM64;
     // 8-wave ping-pong tiles (gemm8.hip; one block per CU): chosen from the per-shape A/B of tools/gemm_variants.py
     // (profiles/r03_gemm_variants.tsv).  CRIS_GEMM8=0 switches the family off.
     static const int g8 = cris_env_int("CRIS_GEMM8", 1);
     static const int g8_min = cris_env_int("CRIS_GEMM8_MIN_TILES", 150);
     static const int g8_min_k = cris_env_int("CRIS_GEMM8_MIN_K", 256);
     static const int g8_t128_lo = cris_env_int("CRIS_GEMM8_T128_LO", 100), g8_t128_hi = cris_env_int("CRIS_GEMM8_T128_HI", 200);
-    if (g8 && (p.C & 63) == 0 && p.N >= 128) {
+    // (lean epilogues only: the general epilogue on a 64x32 .. 128x64 wave tile spills and runs 1.3 - 1.6x longer than on the
+    // 4-wave tiles - 25.8 against 15.8 us for the decoder's M 5408 / N 512 / K 512 projections, in-step kernel trace of call r03f)
+    if (g8 && epilogue_kind(p) != 0 && (p.C & 63) == 0 && p.N >= 128) {
         const long t128 = (long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128);
         // 128x128 with a five-deep ring: problems of 0.4 - 0.8 tiles per CU whose loop is bound by operand latency (mid-size
         // layers: M 5408 x N 512, M 1352 x N 2048, M 21632 x N 128): 36 against 51 us at M 5408 / N 512 / K 4608
@@ -400,7 +414,7 @@ static int variant_stat_rows(int v) {
         case V_SKINNY9: return 16;
         case V_128x128: return 64;
         case V_8W_256x256: case V_8W_256x128: return 128;
-        case V_8W_128x256: case V_8W_128x128: return 64;
+        case V_8W_128x256: case V_8W_128x128: case V_STREAM128: return 64;
         default: return 32;
     }
 }
@@ -415,7 +429,7 @@ extern "C" int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, 
 }
 extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
 extern "C" const char* cris_conv_gemm_variant_name(int v) {
-    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128"};
+    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128", "stream128", "stream64"};
     return (v >= 0 && v < V_COUNT) ? names[v] : "?";
 }
 
@@ -468,11 +482,12 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
         cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, lds_ready);
         return lds_ready;
     }
-    const bool plain = p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32);
-    const int lean = !plain ? 0 : (!p.bias && p.act == 0) ? 1 : (p.act == 0 || p.act == 1 || p.act == 3) ? 2 : 0;
+    const int lean = epilogue_kind(p);
     const int v = resolve_variant(p, variant);
     CRIS_CHECK_ARG(v >= 0, "tile variant not applicable to this problem");
     switch (v) {
+        case V_STREAM128: case V_STREAM64:
+            return cris_launch_gemm_stream(v == V_STREAM128 ? 128 : 64, p, lean, s);
         case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128:
             return cris_launch_gemm8(v - V_8W_256x256, p, lean, s);
         case V_SKINNY1:

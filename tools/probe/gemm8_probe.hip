@@ -27,6 +27,7 @@ int main(int argc, char** argv) {
     if (argc < 7) { fprintf(stderr, "usage: %s variant Bn HW C N k [reps]\n", argv[0]); return 2; }
     const int variant = atoi(argv[1]), Bn = atoi(argv[2]), HW = atoi(argv[3]), C = atoi(argv[4]), N = atoi(argv[5]), k = atoi(argv[6]);
     const int reps = argc > 7 ? atoi(argv[7]) : 20;
+    const int mode = argc > 8 ? atoi(argv[8]) : 0;         // 1: no output stores (statistics only), 2: no statistics
     cris_conv_gemm_params p;
     memset(&p, 0, sizeof(p));
     p.Bn = Bn; p.H = p.W = p.OH = p.OW = HW; p.C = C; p.KH = p.KW = k; p.stride = 1; p.pad = k / 2;
@@ -46,6 +47,8 @@ int main(int argc, char** argv) {
     hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
     hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
     p.A = (const cris_bf16*)dA; p.Wt = (const cris_bf16*)dW; p.out = dO; p.colsum = cs; p.colsq = cq;
+    if (mode == 1) p.out = nullptr;
+    if (mode == 2) p.colsum = p.colsq = nullptr;
     hipStream_t st;
     hipStreamCreate(&st);
     for (int i = 0; i < 3; ++i)
@@ -69,7 +72,7 @@ int main(int argc, char** argv) {
     unsigned long long ck = 0;
     for (size_t i = 0; i < no; ++i) ck = ck * 1099511628211ull + ho[i];
     const double us = best * 1e3 / reps, fl = 2.0 * p.M * N * p.K;
-    printf("G8PROBE abl=%d variant=%d M=%d N=%d K=%d k=%d : %.1f us  %.0f TFLOP/s (best of 5 x %d launches; mean %.1f us) out checksum %016llx\n", G8_ABL,
+    printf("G8PROBE mode=%d abl=%d variant=%d M=%d N=%d K=%d k=%d : %.1f us  %.0f TFLOP/s (best of 5 x %d launches; mean %.1f us) out checksum %016llx\n", mode, G8_ABL,
            variant, p.M, N, p.K, k, us, fl / us / 1e6, reps, tot / 5 * 1e3 / reps, ck);
     return 0;
 }
