@@ -6,9 +6,94 @@
 #include <type_traits>
 
 #define BK 64
+#ifndef CRIS_FAST_EPILOGUE
+#define CRIS_FAST_EPILOGUE 1      // 0: always the general epilogue (A/B builds)
+#endif
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; rows are 128 B (64 bf16)
     return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
+}
+
+// hardware round-to-nearest-even conversion (v_cvt_pk_bf16_f32); equals f2bf() on every finite value
+__device__ __forceinline__ bf16_t f2bf_hw(float x) { return __builtin_bit_cast(bf16_t, (__bf16)x); }
+
+// Lean epilogue of an INTERIOR wave tile of 32x32 fragments (all FM*32 rows < M, all FN*32 columns < N; EPI 1 / 2): what every
+// block of a convolution GEMM runs.  The general form below spends ~25 VALU instructions per output element - a v_mul_lo_u32 for
+// the offset, bounds selects, bf16 rounding by hand, a branch around every store - so a 256x256 tile cost ~16 us of epilogue
+// and the K <= 256 layers were bound by it (probe, call r03g: 23.6 us of a 34.5 us launch remain with the main loop AND the
+// stores removed).  Here the byte offset of an element is (lane part, four VGPRs set up once) + (fragment part, an SGPR
+// expression handed to the buffer instruction as its scalar offset): no address arithmetic per element, no bounds tests,
+// v_cvt_pk_bf16_f32 for the rounding; the stored values are written back into the accumulator array for the second statistics
+// pass.  Values, rounding and BatchNorm partials are those of the general form.
+template <int EPI, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_fast32(const cris_conv_gemm_params& p, f32x16 (&acc)[FM][FN], int row0, int col0, int part,
+                                                     int lane) {
+    const int fr = lane & 31, fg = lane >> 5;
+    const bool has_res = p.resid != nullptr;
+    const int act = EPI == 2 ? p.act : 0;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.M * p.ldc * 2), CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.resid), 0,
+                                                                        has_res ? (int)((size_t)p.M * p.ldr * 2) : 0, CRIS_BUF_FLAGS);
+    unsigned vo[4], vr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        vo[r] = ((unsigned)(row0 + fg * 4 + r) * (unsigned)p.ldc + (unsigned)(p.c_coff + col0 + fr)) * 2u;
+        vr[r] = has_res ? ((unsigned)(row0 + fg * 4 + r) * (unsigned)p.ldr + (unsigned)(p.r_coff + col0 + fr)) * 2u : CRIS_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const float bias = (EPI == 2 && p.bias) ? p.bias[col0 + j * 32 + fr] : 0.f;
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            // the residual of a whole 32x32 fragment is requested before its first use: one memory round trip per fragment
+            // instead of one per 4-row group (a branch around the loads would put a wait behind each group)
+            float rres[16];
+            if (has_res) {                          // wave-uniform: ONE branch per fragment, all 16 loads in flight together
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int sr = ((i * 32 + (e >> 2) * 8) * p.ldr + j * 32) * 2;
+                    rres[e] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsR, vr[e & 3], sr, 0));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rres[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int so = ((i * 32 + (e >> 2) * 8) * p.ldc + j * 32) * 2;          // wave-uniform: scalar offset of this 4-row group
+                float x = acc[i][j][e];
+                if constexpr (EPI == 2) {
+                    x += bias;
+                    if (act == 1) x = fmaxf(x, 0.f);
+                }
+                x += rres[e];                       // (+ 0 without a residual: as the general form does)
+                if constexpr (EPI == 2) {
+                    if (act == 3) x = fmaxf(x, 0.f);
+                }
+                acc[i][j][e] = x;
+                s1 += x;
+                __builtin_amdgcn_raw_buffer_store_b16((short)f2bf_hw(x), rsO, vo[e & 3], so, 0);
+            }
+        }
+        if (p.colsum) {
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mu = s1 / (float)(FM * 32);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float d = acc[i][j][e] - mu;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 32, 64);
+            if (fg == 0) {
+                p.colsum[(size_t)part * p.N + col0 + j * 32 + fr] = s1;
+                p.colsq[(size_t)part * p.N + col0 + j * 32 + fr] = q;
+            }
+        }
+    }
 }
 
 // Epilogue of one wave tile (FM x FN fragments of 16x16, C/D layout col = lane&15, row = (lane>>4)*4 + r) whose first
@@ -25,6 +110,13 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
     // MT = 16: v_mfma_f32_16x16x32 C/D layout  col = lane&15, row = (lane>>4)*4 + r            (r = 0..3)
     // MT = 32: v_mfma_f32_32x32x16 C/D layout  col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)   (reg = 0..15)
     // both: per lane NG groups of 4 consecutive rows of one column
+    if constexpr (EPI != 0 && MT == 32 && std::is_same<ACC, f32x16>::value) {
+        // wave-uniform: the whole wave tile lies inside the problem -> the cheap form (same values)
+        if (p.out && row0 + FM * 32 <= p.M && col0 + FN * 32 <= p.N && CRIS_FAST_EPILOGUE) {
+            gemm_epilogue_fast32<EPI, FM, FN>(p, acc, row0, col0, part, lane);
+            return;
+        }
+    }
     constexpr bool LEAN = EPI != 0;
     constexpr bool BIAS_ACT = EPI != 1;                        // bias / activation compiled in
     constexpr int NG = MT == 16 ? 1 : 4;
