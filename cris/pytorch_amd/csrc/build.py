@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "gemm8.hip", "gemm_stream.hip", "wgrad.hip", "norm.hip", "attention.hip", "elementwise.hip", "evalpost.hip", "inputpipe.hip", "p2p.hip", "comm.hip", "jpeg.hip", "png.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm8.hip", "wgrad.hip", "norm.hip", "attention.hip", "elementwise.hip", "evalpost.hip", "inputpipe.hip", "p2p.hip", "comm.hip", "jpeg.hip", "png.hip"]
 LIB = os.path.join(HERE, "libcris_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
 # -fno-slp-vectorize -fno-vectorize: keep packed-FP32 VALU instructions (v_pk_mul/add/fma_f32) out of the code object.

@@ -334,9 +334,8 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
 }
 
 // tile selection (host)
-enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_STREAM128, V_STREAM64, V_COUNT };
+enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_COUNT };
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s);       // gemm8.hip
-int cris_launch_gemm_stream(int bn, const cris_conv_gemm_params& p, int epi, hipStream_t s);     // gemm_stream.hip
 
 // which epilogue instantiation a problem takes: 0 general, 1 lean, 2 lean + bias / ReLU (see gemm_epilogue)
 static int epilogue_kind(const cris_conv_gemm_params& p) {
@@ -350,7 +349,6 @@ static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
         case V_SKINNY1: return lin && p.M <= 16;
         case V_SKINNY9: return lin && p.M <= SKINNY_MAX_M;
         case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128: return (p.C & 63) == 0;
-        case V_STREAM128: case V_STREAM64: return lin && (p.C & 63) == 0 && p.K <= 256 && epilogue_kind(p) != 0;
         default: return v >= 0 && v < V_COUNT;
     }
 }
@@ -359,10 +357,10 @@ static int pick_variant(const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
     if (lin && p.M <= 16) return V_SKINNY1;
     if (lin && p.M <= SKINNY_MAX_M) return V_SKINNY9;
-    // streaming kernel (gemm_stream.hip) for the HBM-bound 1x1 convolutions of the large feature maps
-    static const int stream_min_m = cris_env_int("CRIS_GEMM_STREAM_MIN_M", 0);
-    if (stream_min_m > 0 && lin && p.M >= stream_min_m && (p.C & 63) == 0 && p.K <= 256 && epilogue_kind(p) != 0)
-        return p.N > 64 ? V_STREAM128 : V_STREAM64;
+    // (Measured and removed, calls r03h / r03i: a persistent streaming kernel for the K <= 256 1x1 convolutions of the large
+    // feature maps - weight panel resident in LDS, activation ring running across tile boundaries - ran level with the 128x128
+    // tile (22.2 against 21.2 us at M 86528 / N 256 / K 64): those layers were bound by the epilogue's VALU work, which
+    // gemm_epilogue_fast32 cut instead - 27.8 -> 21.2 us.)
     // 8-wave ping-pong tiles (gemm8.hip; one block per CU): chosen from the per-shape A/B of tools/gemm_variants.py
     // (profiles/r03_gemm_variants.tsv).  CRIS_GEMM8=0 switches the family off.
     static const int g8 = cris_env_int("CRIS_GEMM8", 1);
@@ -378,10 +376,11 @@ static int pick_variant(const cris_conv_gemm_params& p) {
         if (p.K >= 512 && t128 >= g8_t128_lo && t128 <= g8_t128_hi) return V_8W_128x128;
         if (p.N > 128 && p.K >= g8_min_k) {
             const long t256 = (long)cris_cdiv(p.M, 256) * cris_cdiv(p.N, 256);
-            // (a grid of 1.0 .. 1.5 waves of 256x256 tiles idles half the chip in its second round: halve the rows instead)
-            if (t256 >= g8_min && !(t256 > 256 && t256 <= 400)) return V_8W_256x256;
+            // (a grid of 1.0 .. 1.5 waves of 256x256 tiles idles half the chip in its second round: halve the rows instead;
+            // with K = 256 the 128x128 tile is level or ahead except where the 128x256 tiles fit in one round)
+            if (p.K >= 512 && t256 >= g8_min && !(t256 > 256 && t256 <= 400)) return V_8W_256x256;
             const long t128x256 = (long)cris_cdiv(p.M, 128) * cris_cdiv(p.N, 256);
-            if (t128x256 >= g8_min && !(t128x256 > 256 && t128x256 <= 400)) return V_8W_128x256;
+            if (t128x256 >= g8_min && !(t128x256 > 256 && t128x256 <= 400) && (p.K >= 512 || t128x256 <= 256)) return V_8W_128x256;
         }
     }
     // (Measured and rejected, call r03e: the 64x64 / 64x128 tiles with an 8- / 6-deep ring and one block per CU for the M 1352
@@ -414,7 +413,7 @@ static int variant_stat_rows(int v) {
         case V_SKINNY9: return 16;
         case V_128x128: return 64;
         case V_8W_256x256: case V_8W_256x128: return 128;
-        case V_8W_128x256: case V_8W_128x128: case V_STREAM128: return 64;
+        case V_8W_128x256: case V_8W_128x128: return 64;
         default: return 32;
     }
 }
@@ -429,7 +428,7 @@ extern "C" int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, 
 }
 extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
 extern "C" const char* cris_conv_gemm_variant_name(int v) {
-    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128", "stream128", "stream64"};
+    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128"};
     return (v >= 0 && v < V_COUNT) ? names[v] : "?";
 }
 
@@ -486,8 +485,6 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     const int v = resolve_variant(p, variant);
     CRIS_CHECK_ARG(v >= 0, "tile variant not applicable to this problem");
     switch (v) {
-        case V_STREAM128: case V_STREAM64:
-            return cris_launch_gemm_stream(v == V_STREAM128 ? 128 : 64, p, lean, s);
         case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128:
             return cris_launch_gemm8(v - V_8W_256x256, p, lean, s);
         case V_SKINNY1:

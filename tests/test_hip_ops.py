@@ -228,40 +228,6 @@ def test_conv_gemm_8wave_tiles(variant, case):
         assert torch.equal(out, again), "%s is not reproducible" % variant
 
 
-@pytest.mark.parametrize("variant", ["stream128", "stream64"])
-@pytest.mark.parametrize("case", [
-    dict(M=86528, C=64, N=256),        # layer1 conv3 of the benchmark: one K-step per tile, 676 row tiles
-    dict(M=21632, C=128, N=512),       # layer2: two K-steps per tile
-    dict(M=1000, C=256, N=200),        # ragged rows / columns, four K-steps, a single run of tiles
-    dict(M=70, C=64, N=64),            # less than one tile
-])
-def test_conv_gemm_streaming_kernel(variant, case):
-    """the persistent streaming kernel for HBM-bound 1x1 convolutions (csrc/gemm_stream.hip): resident weight panel, activation
-    ring running across tile boundaries - bit-identical with the tile kernels, statistics partials included, with and
-    without the bias / ReLU epilogue"""
-    M, C_, N = case["M"], case["C"], case["N"]
-    x = rnd(M, C_).to(BF).float()
-    w = (rnd(N, C_, seed=1) / math.sqrt(C_)).to(BF).float()
-    g = Geom.linear(M, C_)
-    xd, wd = bf(x), bf(w)
-    out = torch.empty(M, N, dtype=BF, device=DEV)
-    st = ops.conv_gemm(xd, wd, g, N, out=out, stats=True, variant=variant)
-    check(out, x @ w.t(), 6e-3, "%s %s" % (variant, case))
-    base = torch.empty(M, N, dtype=BF, device=DEV)
-    st0 = ops.conv_gemm(xd, wd, g, N, out=base, stats=True, variant="128x128" if variant == "stream128" else "64x64")
-    assert torch.equal(out, base)
-    assert st.rows_per_part == st0.rows_per_part == (64 if variant == "stream128" else 32)
-    assert torch.equal(st[0][:st.nparts], st0[0][:st0.nparts]) and torch.equal(st[1][:st.nparts], st0[1][:st0.nparts])
-    bias = rnd(N, seed=2).to(DEV)
-    res = bf(rnd(M, N, seed=3))
-    o2, b2 = torch.empty(M, N, dtype=BF, device=DEV), torch.empty(M, N, dtype=BF, device=DEV)
-    ops.conv_gemm(xd, wd, g, N, bias=bias, act=3, resid=res, out=o2, variant=variant)
-    ops.conv_gemm(xd, wd, g, N, bias=bias, act=3, resid=res, out=b2, variant="128x128")
-    assert torch.equal(o2, b2)
-    with pytest.raises(ValueError):
-        ops.conv_gemm(xd, wd, g, N, bias=bias, out=torch.empty(M, N, dtype=torch.float32, device=DEV), variant=variant)   # general epilogue
-
-
 @pytest.mark.parametrize("variant", G8)
 def test_conv_gemm_8wave_epilogues(variant):
     """general epilogue (bias, QuickGELU, fp32 residual / output, dropout) and the residual of the lean one on the 8-wave tiles"""

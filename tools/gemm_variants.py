@@ -86,8 +86,6 @@ def main():
                 continue
             if v == "8w128x128" and (M > 30000 or N <= 64):
                 continue
-            if v.startswith("stream") and (k != 1 or K > 256 or C % 64 or (v == "stream64") != (N <= 64)):
-                continue
             try:
                 runners[v] = make_runner(M, N, K, k, -1 if v == "auto" else v, True, args.reps)
             except Exception as e:      # noqa: BLE001
