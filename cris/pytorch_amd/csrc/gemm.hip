@@ -333,8 +333,124 @@ __global__ __launch_bounds__(64 * SK_WAVES) void skinny_gemm_kernel(const cris_c
     }
 }
 
+// Split-K skinny kernels (M <= 144 rows: the text encoder's 12 layers, forward and input gradient - 108 launches per step).
+// The single-pass kernel above puts N/32 = 16 .. 64 blocks on a 256-CU part and walks K in four dependent round trips per wave,
+// then eight serial LDS rounds and the general epilogue: 19 - 42 us per launch for 1 - 2 MB of weights.  Here K is ALSO split
+// over blocks: block (column pair of fragments, K slice) = 4 waves x one or two 64-deep chunks each - every load of a wave
+// is in flight at once - the four partial accumulators are summed through LDS in wave order, and the slice's fp32 partial
+// goes to a workspace slab [slice][fragment][lane][4]; a second small launch adds the slabs in slice order (deterministic)
+// and runs the general epilogue once per output fragment.  128 - 256 blocks per launch instead of 16 - 64.
+#define SK2_WAVES 4
+template <int FM>
+__global__ __launch_bounds__(64 * SK2_WAVES) void skinny_split_kernel(const cris_conv_gemm_params p, int kslice) {
+    constexpr int FN = 2;
+    __shared__ float red[SK2_WAVES - 1][FM * FN][64][4];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int nb = blockIdx.x, ks = blockIdx.y;
+    const int n0 = nb * (FN * 16);
+    const int k_begin = ks * kslice, k_end = min(p.K, k_begin + kslice);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.A), 0, (int)((size_t)p.M * p.lda * 2),
+                                                                        CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.Wt), 0, (int)((size_t)p.N * p.ldb * 2),
+                                                                        CRIS_BUF_FLAGS);
+    unsigned aoff[FM], boff[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        const int m = i * 16 + fr;
+        aoff[i] = m < p.M ? ((unsigned)m * (unsigned)p.lda + (unsigned)p.a_coff) * 2u : CRIS_OOB;
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + j * 16 + fr;
+        boff[j] = n < p.N ? (unsigned)n * (unsigned)p.ldb * 2u : CRIS_OOB;
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // 32-wide chunks of the slice, interleaved over the waves (the block reads contiguous 256-B runs of every row)
+    for (int kb = k_begin + wave * 32; kb < k_end; kb += 2 * 32 * SK2_WAVES) {
+        const int k0 = kb + fg * 8, k1 = k0 + 32 * SK2_WAVES;
+        const unsigned o0 = k0 < k_end ? (unsigned)k0 * 2u : CRIS_OOB, o1 = k1 < k_end ? (unsigned)k1 * 2u : CRIS_OOB;
+        u32x4 av0[FM], bv0[FN], av1[FM], bv1[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) av0[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (aoff[i] | o0) >= CRIS_OOB ? CRIS_OOB : aoff[i] + o0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bv0[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (boff[j] | o0) >= CRIS_OOB ? CRIS_OOB : boff[j] + o0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) av1[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, (aoff[i] | o1) >= CRIS_OOB ? CRIS_OOB : aoff[i] + o1, 0, 0);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) bv1[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (boff[j] | o1) >= CRIS_OOB ? CRIS_OOB : boff[j] + o1, 0, 0);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&av0[i]), *reinterpret_cast<bf16x8*>(&bv0[j]),
+                                                                    acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&av1[i]), *reinterpret_cast<bf16x8*>(&bv1[j]),
+                                                                    acc[i][j], 0, 0, 0);
+            }
+    }
+    // waves 1 .. 3 park their partials in LDS, wave 0 adds them in wave order and stores the slice's slab
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) *reinterpret_cast<f32x4*>(&red[wave - 1][i * FN + j][lane][0]) = acc[i][j];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* slab = p.ws + ((size_t)ks * gridDim.x + nb) * (FM * FN * 256);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                f32x4 v = acc[i][j];
+#pragma unroll
+                for (int w = 0; w < SK2_WAVES - 1; ++w) {
+                    const f32x4 o = *reinterpret_cast<const f32x4*>(&red[w][i * FN + j][lane][0]);
+                    v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+                }
+                *reinterpret_cast<f32x4*>(slab + (i * FN + j) * 256 + lane * 4) = v;
+            }
+    }
+}
+
+// second pass: out fragment (i, column fragment c) = sum over the K slices of its slab entries, then the general epilogue
+template <int FM>
+__global__ __launch_bounds__(256) void skinny_finish_kernel(const cris_conv_gemm_params p, int nslices, int nblocks) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = blockIdx.x * 4 + wave;                       // fragment index over [FM][columns / 16]
+    const int nfc = nblocks * 2;
+    if (u >= FM * nfc) return;
+    const int i = u / nfc, c = u - i * nfc;
+    const int nb = c >> 1, j = c & 1;
+    f32x4 one[1][1];
+    one[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < nslices; ++ks) {
+        const f32x4 o = *reinterpret_cast<const f32x4*>(p.ws + ((size_t)ks * nblocks + nb) * (FM * 2 * 256) + (i * 2 + j) * 256 + lane * 4);
+        one[0][0][0] += o[0]; one[0][0][1] += o[1]; one[0][0][2] += o[2]; one[0][0][3] += o[3];
+    }
+    gemm_epilogue<0, 16, 1, 1>(p, one, i * 16, c * 16, i, lane);
+}
+
+// K slices of the split-K skinny launch: enough blocks for the chip, at least 128 of K per slice
+static int skinny_split_slices(const cris_conv_gemm_params& p) {
+    static const int target = cris_env_int("CRIS_SKINNY_BLOCKS", 192);
+    const int nblocks = cris_cdiv(p.N, 32);
+    int ks = target / nblocks;
+    const int kmax = p.K / 128;
+    if (ks > kmax) ks = kmax;
+    if (ks < 1) ks = 1;
+    return ks;
+}
+static int skinny_kslice(const cris_conv_gemm_params& p, int slices) { return cris_cdiv(cris_cdiv(p.K, slices), 32) * 32; }
+
 // tile selection (host)
-enum { V_SKINNY1 = 0, V_SKINNY9, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_COUNT };
+enum { V_SKINNY1 = 0, V_SKINNY9, V_SKINNY9S, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_COUNT };
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s);       // gemm8.hip
 
 // which epilogue instantiation a problem takes: 0 general, 1 lean, 2 lean + bias / ReLU (see gemm_epilogue)
@@ -347,7 +463,7 @@ static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
     switch (v) {
         case V_SKINNY1: return lin && p.M <= 16;
-        case V_SKINNY9: return lin && p.M <= SKINNY_MAX_M;
+        case V_SKINNY9: case V_SKINNY9S: return lin && p.M <= SKINNY_MAX_M;
         case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128: return (p.C & 63) == 0;
         default: return v >= 0 && v < V_COUNT;
     }
@@ -356,7 +472,8 @@ static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
 static int pick_variant(const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
     if (lin && p.M <= 16) return V_SKINNY1;
-    if (lin && p.M <= SKINNY_MAX_M) return V_SKINNY9;
+    static const int skinny_split = cris_env_int("CRIS_SKINNY_SPLIT", 1);
+    if (lin && p.M <= SKINNY_MAX_M) return (skinny_split && p.K >= 256) ? V_SKINNY9S : V_SKINNY9;
     // (Measured and removed, calls r03h / r03i: a persistent streaming kernel for the K <= 256 1x1 convolutions of the large
     // feature maps - weight panel resident in LDS, activation ring running across tile boundaries - ran level with the 128x128
     // tile (22.2 against 21.2 us at M 86528 / N 256 / K 64): those layers were bound by the epilogue's VALU work, which
@@ -411,6 +528,7 @@ static int variant_stat_rows(int v) {
     switch (v) {
         case V_SKINNY1: return 16;
         case V_SKINNY9: return 16;
+        case V_SKINNY9S: return 16;
         case V_128x128: return 64;
         case V_8W_256x256: case V_8W_256x128: return 128;
         case V_8W_128x256: case V_8W_128x128: return 64;
@@ -426,9 +544,14 @@ extern "C" int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, 
     const int v = resolve_variant(*p, variant);
     return v < 0 ? -1 : variant_stat_rows(v);
 }
+extern "C" long cris_conv_gemm_ws_floats(const cris_conv_gemm_params* p, int variant) {
+    const int v = resolve_variant(*p, variant);
+    if (v != V_SKINNY9S) return 0;
+    return (long)skinny_split_slices(*p) * cris_cdiv(p->N, 32) * (9 * 2 * 256);
+}
 extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
 extern "C" const char* cris_conv_gemm_variant_name(int v) {
-    static const char* names[V_COUNT] = {"skinny1", "skinny9", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128"};
+    static const char* names[V_COUNT] = {"skinny1", "skinny9", "skinny9s", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128"};
     return (v >= 0 && v < V_COUNT) ? names[v] : "?";
 }
 
@@ -490,6 +613,13 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
         case V_SKINNY1:
             hipLaunchKernelGGL(skinny_gemm_kernel<1>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);
             break;
+        case V_SKINNY9S: {
+            CRIS_CHECK_ARG(p.ws != nullptr, "the split-K skinny variant needs the workspace (cris_conv_gemm_ws_floats)");
+            const int slices = skinny_split_slices(p), nblocks = cris_cdiv(p.N, 32);
+            hipLaunchKernelGGL(skinny_split_kernel<9>, dim3(nblocks, slices), dim3(64 * SK2_WAVES), 0, s, p, skinny_kslice(p, slices));
+            hipLaunchKernelGGL(skinny_finish_kernel<9>, dim3(cris_cdiv(9 * nblocks * 2, 4)), dim3(256), 0, s, p, slices, nblocks);
+            break;
+        }
         case V_SKINNY9:
             hipLaunchKernelGGL(skinny_gemm_kernel<9>, dim3(cris_cdiv(p.N, 32)), dim3(64 * SK_WAVES), 0, s, p);
             break;

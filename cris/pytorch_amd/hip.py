@@ -28,7 +28,8 @@ class ConvGemmParams(C.Structure):
                 ("ldc", I), ("c_coff", I), ("out_f32", I),
                 ("T_L", I), ("T_Lpad", I), ("T_E", I),
                 ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U),
-                ("drop_seed_dev", P)]
+                ("drop_seed_dev", P),
+                ("ws", P)]
 
 
 class WgradParams(C.Structure):
@@ -218,6 +219,7 @@ _SIGS = {
     "cris_conv_gemm_stat_rows": (I, [P]),
     "cris_conv_gemm_variant": (I, [P, I, P]),
     "cris_conv_gemm_variant_stat_rows": (I, [P, I]),
+    "cris_conv_gemm_ws_floats": (L, [P, I]),
     "cris_conv_gemm_num_variants": (I, []),
     "cris_conv_gemm_variant_name": (C.c_char_p, [I]),
     "cris_bn_partials_rows": (I, [I]),

@@ -117,6 +117,9 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     if stats:
         st = Stats((g.M + rows - 1) // rows, N, rows, A.device)
         p.colsum, p.colsq = ptr(st[0]), ptr(st[1])
+    nws = hip.load().cris_conv_gemm_ws_floats(C.byref(p), variant)
+    ws = torch.empty(nws, dtype=torch.float32, device=A.device) if nws else None       # (stream-ordered: freed after the launches)
+    p.ws = ptr(ws)
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.launch("skinny_gemm" if rows == 16 else "conv_gemm", 2.0 * g.M * N * g.K,
                             2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm_variant", C.byref(p), variant,

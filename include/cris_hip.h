@@ -64,6 +64,7 @@ typedef struct {
     uint32_t drop_thresh;    /* keep iff hash >= drop_thresh; host computes min(int(p*2^32), 2^32-1); 0 = off */
     uint32_t drop_seed, drop_stream;
     const uint32_t* drop_seed_dev; /* optional device word added to drop_seed (per-step seed of a replayed HIP graph) */
+    float* ws;               /* workspace of cris_conv_gemm_ws_floats(p, variant) floats (the split-K skinny variant; else unused) */
 } cris_conv_gemm_params;
 int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
 /* rows per BatchNorm-statistics partial written for this problem (depends on the tile variant chosen; host only) */
@@ -76,6 +77,8 @@ int cris_conv_gemm_stat_rows(const cris_conv_gemm_params* p);
  * bit-identical; the BatchNorm partials differ in their row grouping (cris_conv_gemm_variant_stat_rows). */
 int cris_conv_gemm_variant(const cris_conv_gemm_params* p, int variant, void* stream);
 int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, int variant);
+/* floats of workspace p->ws the launch of this problem with this variant needs (0 for every variant but the split-K skinny one) */
+long cris_conv_gemm_ws_floats(const cris_conv_gemm_params* p, int variant);
 int cris_conv_gemm_num_variants(void);
 const char* cris_conv_gemm_variant_name(int variant);
 

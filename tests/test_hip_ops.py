@@ -256,6 +256,43 @@ def test_conv_gemm_8wave_epilogues(variant):
     check(out3, b2 * km / (1 - p), 3e-3, "dropout epilogue")
 
 
+@pytest.mark.parametrize("M,K,N", [(136, 512, 1536), (136, 2048, 512), (136, 1536, 512), (136, 512, 2048), (144, 320, 40), (24, 512, 520)])
+def test_skinny_split_k(M, K, N):
+    """the split-K skinny kernels (text encoder: 136 rows): K slices over blocks, slabs added in slice order by the finishing
+    launch, which runs the general epilogue - bias / QuickGELU / fp32 residual + output, bf16 output with ReLU, BatchNorm
+    partials of 16 rows, the head-split transposed copy; reproducible run to run"""
+    x = rnd(M, K).to(BF).float()
+    w = (rnd(N, K, seed=1) / math.sqrt(K)).to(BF).float()
+    bias, res32 = rnd(N, seed=2), rnd(M, N, seed=3)
+    g = Geom.linear(M, K)
+    base = x @ w.t() + bias
+    out = torch.empty(M, N, dtype=torch.float32, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=2, resid=res32.to(DEV), out=out, variant="skinny9s")
+    check(out, base * torch.sigmoid(1.702 * base) + res32, 3e-3, "quickgelu + fp32 residual")
+    again = torch.empty_like(out)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=2, resid=res32.to(DEV), out=again, variant="skinny9s")
+    assert torch.equal(out, again)
+    o2 = torch.empty(M, N, dtype=BF, device=DEV)
+    st = ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=1, out=o2, stats=True, variant="skinny9s")
+    ref = torch.relu(base)
+    check(o2, ref, 6e-3, "relu bf16")
+    assert st.rows_per_part == 16
+    check(st[0][0], ref[:16].sum(0), 3e-3, "part sum")
+    auto = torch.empty(M, N, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), act=1, out=auto)             # the automatic choice for these shapes
+    check(auto, ref, 6e-3, "automatic variant")
+    if M == 136 and N % 512 == 0:                                                     # head-split transposed copy (qkv projection)
+        L, Bn, E = 17, 8, 512
+        Lpad, secs = ops.pad32(L), N // E
+        T = torch.zeros(secs, Bn * (E // 64) * 64, Lpad, dtype=BF, device=DEV)
+        o3 = torch.empty(M, N, dtype=BF, device=DEV)
+        ops.conv_gemm(bf(x), bf(w), g, N, bias=bias.to(DEV), out=o3, outT=T, T_L=L, T_Lpad=Lpad, T_E=E, T_sec_stride=T[0].numel(),
+                      variant="skinny9s")
+        y = o3.float().cpu().view(Bn, L, secs, E // 64, 64)
+        want = y.permute(2, 0, 3, 4, 1).reshape(secs, Bn * (E // 64) * 64, L)
+        assert torch.equal(T[:, :, :L].float().cpu(), want)
+
+
 def test_conv_gemm_variant_refused_when_not_applicable():
     x, w = bf(rnd(64, 72)), bf(rnd(64, 72, seed=1))
     out = torch.empty(64, 64, dtype=BF, device=DEV)
