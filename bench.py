@@ -325,20 +325,17 @@ def main():
                                "share_of_step": (d["ms"] / timer_steps) / (1000.0 * dt / args.steps)}
             # HBM bytes per launch of the same kernel from the PMC passes of tools/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE /
             # WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction): a committed measurement, not taken live
-            for pmf in ("r02_hbm_traffic.json", "r01_hbm_traffic.json"):
+            for pmf, pmk in (("r03_hbm_traffic.json", "conv_gemm (all tile kernels)"), ("r02_hbm_traffic.json", "conv_gemm_kernel")):
                 try:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))["kernels"]["conv_gemm_kernel"]
+                    pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))["kernels"][pmk]
                     out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
                     out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc, eager launches)" % pmf
                     out["roofline"]["algorithmic_bytes_per_launch"] = d["bytes"] / d["launches"]
                     break
                 except Exception:               # noqa: BLE001
                     pass
-            # measured parity of this path (committed with the profiles): 100-step loss trajectory vs the fp32 oracle
-            try:
-                out["config"]["parity"] = json.load(open(os.path.join(ROOT, "profiles", "parity_r02.json")))
-            except Exception:               # noqa: BLE001
-                pass
+            # where the parity measurements of this path are (a pointer, not a measurement of this run)
+            out["config"]["parity"] = "profiles/parity_r03.md (teacher-forced 100-step test + stock-PyTorch autocast study), tests/test_engine_gpu.py"
             out["roofline"]["timing"] = "HIP events around each launch, %d-step eager pass after the timed region" % timer_steps
             out["kernels"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                   "launches_per_step": v["launches"] / timer_steps} for k, v in summ.items()}

@@ -472,8 +472,13 @@ static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
 static int pick_variant(const cris_conv_gemm_params& p) {
     const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;
     if (lin && p.M <= 16) return V_SKINNY1;
+    // M = 17 .. 144 rows (text encoder): standalone, call r03j - K 2048: split-K skinny 13.0 us, 64x64 tile 16.4, single-pass
+    // skinny 28.0; K 512: 64x64 tile 8.3 - 8.5, split-K 9.2 - 10.5, single-pass 14.1 - 14.5.  CRIS_SKINNY_SPLIT=0: single-pass.
     static const int skinny_split = cris_env_int("CRIS_SKINNY_SPLIT", 1);
-    if (lin && p.M <= SKINNY_MAX_M) return (skinny_split && p.K >= 256) ? V_SKINNY9S : V_SKINNY9;
+    if (lin && p.M <= SKINNY_MAX_M) {
+        if (!skinny_split) return V_SKINNY9;
+        return p.K >= 1024 ? V_SKINNY9S : V_64x64;
+    }
     // (Measured and removed, calls r03h / r03i: a persistent streaming kernel for the K <= 256 1x1 convolutions of the large
     // feature maps - weight panel resident in LDS, activation ring running across tile boundaries - ran level with the 128x128
     // tile (22.2 against 21.2 us at M 86528 / N 256 / K 64): those layers were bound by the epilogue's VALU work, which

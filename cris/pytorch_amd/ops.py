@@ -121,7 +121,8 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     ws = torch.empty(nws, dtype=torch.float32, device=A.device) if nws else None       # (stream-ordered: freed after the launches)
     p.ws = ptr(ws)
     if KERNEL_TIMER is not None:
-        KERNEL_TIMER.launch("skinny_gemm" if rows == 16 else "conv_gemm", 2.0 * g.M * N * g.K,
+        # (classified by the problem, not by the kernel that runs it: M <= 144 linears are the text encoder's / per-sample vectors)
+        KERNEL_TIMER.launch("skinny_gemm" if (g.M <= 144 and g.KH == 1) else "conv_gemm", 2.0 * g.M * N * g.K,
                             2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm_variant", C.byref(p), variant,
                             tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
         return st

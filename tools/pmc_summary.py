@@ -35,6 +35,14 @@ def main(fetch_db, write_db, out):
             a["launches"] = n0 + nf
         else:
             res[key] = {"launches": nf, "fetch_bytes_per_launch": fpl, "write_bytes_per_launch": wpl}
+    # the forward / input-gradient GEMM family as one entry (4-wave tiles + 8-wave tiles): what bench.py's roofline line quotes
+    fam = [res[k] for k in ("conv_gemm_kernel", "conv_gemm8_kernel") if k in res]
+    if fam:
+        n = sum(a["launches"] for a in fam)
+        res["conv_gemm (all tile kernels)"] = {
+            "launches": n,
+            "fetch_bytes_per_launch": sum(a["fetch_bytes_per_launch"] * a["launches"] for a in fam) / n,
+            "write_bytes_per_launch": sum(a["write_bytes_per_launch"] * a["launches"] for a in fam) / n}
     for a in res.values():
         a["traffic_bytes_per_launch"] = a["fetch_bytes_per_launch"] + a["write_bytes_per_launch"]
     json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported; eager launches, %s" % fetch_db, "kernels": res},
