@@ -287,6 +287,247 @@ __device__ __forceinline__ void wgrad_tile(const cris_wgrad_params& p, int bx, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 8-wave 256 x 256 tile (round 3).  The 128x128 tile above moves 64 flop per operand byte through the L2 -> LDS path and tops
+// out at 0.6 - 0.75 PFLOP/s like the 4-wave forward tiles did; this is the forward family's answer (csrc/gemm8.hip) applied to
+// the weight gradient: 512 threads = two wave groups of four (group = 128 output rows n), group 1 one barrier behind group
+// 0, one phase per 32-pixel step = MEM segment {4 LDS-DMAs (two 128-column images per operand, each in the layout of the tile
+// above, so the transposing-read addressing carries over), 24 ds_read_b64_tr_b16 of BOTH 16-pixel slices, counted wait} -
+// barrier - 16 MFMAs - barrier; ring of four steps (128 KB), two steps (64 KB) in flight.  Wave tile 128 (n) x 64 (k).
+// Hazards as in gemm8.hip: a step is waited for at the end of the MEM segment one phase before its reads; its buffer is
+// refilled one phase after them.
+// ------------------------------------------------------------------------------------------------
+#define WG8_T 256
+#define WG8_STAGES 4
+#define WG8_IMG (WG_MS * 256)
+#define WG8_STEP (4 * WG8_IMG)                     // [dY n 0..127][dY n 128..255][X k 0..127][X k 128..255]
+#define WG8_LDS (WG8_STAGES * WG8_STEP)
+#define WG8_BARRIER()                               \
+    do {                                            \
+        __builtin_amdgcn_sched_barrier(0);          \
+        __builtin_amdgcn_s_barrier();               \
+        __builtin_amdgcn_sched_barrier(0);          \
+    } while (0)
+
+__device__ __forceinline__ void wgrad8_tile(const cris_wgrad_params& p, int bx, int by, int bz, unsigned char* smem) {
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int k0 = bx * WG8_T;
+    const int n0 = by * WG8_T;
+    const int rows_per = wg_rows_per_split(p.M, p.splits);
+    const int m_begin = bz * rows_per;
+    const int m_end = min(p.M, m_begin + rows_per);
+    const int nsteps = (m_end - m_begin + WG_MS - 1) / WG_MS;
+
+    // ---- DMA role: one instruction per image and step; this wave fills rows wave*4 + (lane>>4), LDS slot lane&15 of the row;
+    // the 16-B chunk that belongs there is slot ^ ((row & 7) << 1), row & 7 = 4*(wave&1) + (lane>>4)
+    const int rsub = lane >> 4;
+    const int row7 = ((wave & 1) << 2) + rsub;
+    const int cg = (lane & 15) ^ (row7 << 1);
+    const int OHW = p.OH * p.OW;
+    unsigned ycol[2];
+    int xc[2], xkh[2], xkw[2];
+    bool xvalid[2];
+#pragma unroll
+    for (int im = 0; im < 2; ++im) {
+        const int yn = n0 + im * 128 + cg * 8;
+        ycol[im] = yn < p.N_ld ? (unsigned)(p.y_coff + yn) * 2u : CRIS_OOB;
+        const int xk = k0 + im * 128 + cg * 8;
+        xvalid[im] = xk < p.K;
+        const int tap = xvalid[im] ? xk / p.C : 0;
+        xc[im] = xvalid[im] ? xk - tap * p.C : 0;
+        xkh[im] = tap / p.KW;
+        xkw[im] = tap - xkh[im] * p.KW;
+    }
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.dY), 0, (int)((size_t)p.M * p.ldy * 2),
+                                                                        CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.X), 0, (int)((size_t)p.Bn * p.H * p.W * p.ldx * 2), CRIS_BUF_FLAGS);
+    const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
+    int rb, roh, row_;                              // (b, oh, ow) of this lane's row of the NEXT step to issue
+    {
+        const int m = m_begin + wave * 4 + rsub;
+        rb = m / OHW;
+        const int r = m - rb * OHW;
+        roh = r / p.OW;
+        row_ = r - roh * p.OW;
+    }
+    int m_issue = m_begin, ibuf = 0;
+    const int dMSb = WG_MS / OHW, dMSq = (WG_MS - dMSb * OHW) / p.OW, dMSr = (WG_MS - dMSb * OHW) - dMSq * p.OW;
+    auto issue_step = [&]() {
+        unsigned char* dst = smem + ibuf * WG8_STEP + wave * 1024;
+        const int m = m_issue + wave * 4 + rsub;
+        const bool mv = m < m_end;
+        const unsigned yrow = (unsigned)m * (unsigned)p.ldy * 2u;
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            const unsigned off = (mv && ycol[im] != CRIS_OOB) ? yrow + ycol[im] : CRIS_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsY, (lds_void_t*)(dst + im * WG8_IMG), 16, off, 0, 0, 0);
+        }
+#pragma unroll
+        for (int im = 0; im < 2; ++im) {
+            unsigned xo;
+            bool xv = mv && xvalid[im];
+            if (lin) {
+                xo = ((unsigned)m * (unsigned)p.ldx + (unsigned)(p.x_coff + xc[im])) * 2u;
+            } else {
+                const int ih = roh * p.stride - p.pad + xkh[im], iw = row_ * p.stride - p.pad + xkw[im];
+                xv = xv && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                xo = ((unsigned)((rb * p.H + ih) * p.W + iw) * (unsigned)p.ldx + (unsigned)(p.x_coff + xc[im])) * 2u;
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void_t*)(dst + (2 + im) * WG8_IMG), 16, xv ? xo : CRIS_OOB, 0, 0, 0);
+        }
+        m_issue += WG_MS;
+        if (!lin) {
+            rb += dMSb; roh += dMSq; row_ += dMSr;
+            if (row_ >= p.OW) { row_ -= p.OW; ++roh; }
+            if (roh >= p.OH) { roh -= p.OH; ++rb; }
+        }
+        if (++ibuf == WG8_STAGES) ibuf = 0;
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment addressing (as in wgrad_tile): lane l, read q: row 8*(l>>5) + 4q + ((l&15)>>2) of the slice, columns
+    // col0 + 16*((l>>4)&1) + 4*(l&3) .. +3 of the image
+    const int fr = lane & 31, fh = lane >> 5;
+    int offY[4][2], offX[2][2];
+    {
+        const int tl = lane & 15, gb = (lane >> 4) & 1;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int r7 = 4 * q + (tl >> 2);
+            const int row = 8 * fh + r7;
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                const int cy = f * 32 + 16 * gb + 4 * (tl & 3);
+                offY[f][q] = wr * WG8_IMG + row * 256 + ((((cy >> 3) ^ (r7 << 1)) & 15) << 4) + (cy & 7) * 2;
+            }
+#pragma unroll
+            for (int f = 0; f < 2; ++f) {
+                const int cx = (wc & 1) * 64 + f * 32 + 16 * gb + 4 * (tl & 3);
+                offX[f][q] = (2 + (wc >> 1)) * WG8_IMG + row * 256 + ((((cx >> 3) ^ (r7 << 1)) & 15) << 4) + (cx & 7) * 2;
+            }
+        }
+    }
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t*)smem;
+    const bool do_bias = p.dbias != nullptr && bx == 0;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // columns 8*bcg .. +7 of dY image t>>8 over this thread's rows
+    const int bt = t & 255, bimg = t >> 8;
+    const int bcg = (bt & 15) ^ ((((bt >> 4) & 7) << 1) & 15);
+
+#pragma unroll
+    for (int s_ = 0; s_ < WG8_STAGES - 1; ++s_) {
+        issue_step();
+    }
+    CRIS_VMCNT((WG8_STAGES - 2) * 4);                // step 0 of this wave has landed
+    WG8_BARRIER();
+    if (wr == 1) WG8_BARRIER();                     // group 1 runs one barrier behind from here on
+    int buf = 0;
+    for (int st = 0; st < nsteps; ++st) {
+        // ---- MEM segment
+        issue_step();                               // step st+3 -> the buffer of step st-1 (steps beyond the range read zeros)
+        const unsigned sbase = lds_base + (unsigned)(buf * WG8_STEP);
+        wg_s16x4 fy[2][4][2], fx[2][2][2];          // [slice][fragment][q]
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            fy[0][f][0] = wg_tr_read<0>(sbase + (unsigned)offY[f][0]);
+            fy[0][f][1] = wg_tr_read<0>(sbase + (unsigned)offY[f][1]);
+            fy[1][f][0] = wg_tr_read<4096>(sbase + (unsigned)offY[f][0]);
+            fy[1][f][1] = wg_tr_read<4096>(sbase + (unsigned)offY[f][1]);
+        }
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+            fx[0][f][0] = wg_tr_read<0>(sbase + (unsigned)offX[f][0]);
+            fx[0][f][1] = wg_tr_read<0>(sbase + (unsigned)offX[f][1]);
+            fx[1][f][0] = wg_tr_read<4096>(sbase + (unsigned)offX[f][0]);
+            fx[1][f][1] = wg_tr_read<4096>(sbase + (unsigned)offX[f][1]);
+        }
+        if (do_bias) {                              // block-uniform: only the blocks of the first k-tile
+            const unsigned char* sy = smem + buf * WG8_STEP + bimg * WG8_IMG;
+#pragma unroll
+            for (int j = 0; j < WG_MS / 16; ++j) {
+                float f8[8];
+                unpack8(*reinterpret_cast<const uint4*>(sy + ((bt >> 4) + 16 * j) * 256 + (bt & 15) * 16), f8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bsum[e] += f8[e];
+            }
+        }
+        // fragments in registers (the asm carries them: every use is ordered after it), step st+1 landed (2 steps stay in flight)
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)"
+                     : "+v"(fy[0][0][0]), "+v"(fy[0][0][1]), "+v"(fy[0][1][0]), "+v"(fy[0][1][1]), "+v"(fy[0][2][0]), "+v"(fy[0][2][1]),
+                       "+v"(fy[0][3][0]), "+v"(fy[0][3][1]), "+v"(fy[1][0][0]), "+v"(fy[1][0][1]), "+v"(fy[1][1][0]), "+v"(fy[1][1][1]),
+                       "+v"(fy[1][2][0]), "+v"(fy[1][2][1]), "+v"(fy[1][3][0]), "+v"(fy[1][3][1])
+                     :
+                     : "memory");
+        asm volatile("" : "+v"(fx[0][0][0]), "+v"(fx[0][0][1]), "+v"(fx[0][1][0]), "+v"(fx[0][1][1]), "+v"(fx[1][0][0]), "+v"(fx[1][0][1]),
+                          "+v"(fx[1][1][0]), "+v"(fx[1][1][1]));
+        WG8_BARRIER();
+        // ---- MFMA segment
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]),
+                          "+v"(acc[3][1]));
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 bfr[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = wg_join(fx[ks][j][0], fx[ks][j][1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 af = wg_join(fy[ks][i][0], fy[ks][i][1]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]),
+                          "+v"(acc[3][1]));
+        __builtin_amdgcn_s_setprio(0);
+        WG8_BARRIER();
+        if (++buf == WG8_STAGES) buf = 0;
+    }
+    if (wr == 0) WG8_BARRIER();
+    CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before LDS is reused / the block retires
+
+    const bool single = p.splits == 1;
+    float* dW = single ? p.dW : p.ws + (size_t)bz * wg_slab_floats(p.N, p.ldw);
+    float* dB = single ? p.dbias : dW + (size_t)p.N * p.ldw;
+    if (do_bias) {                                   // block-wide column sums: [16 row groups][256 n] through LDS, fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[(bt >> 4) * 256 + bimg * 128 + bcg * 8 + e] = bsum[e];
+        __syncthreads();
+        if (t < 256 && n0 + t < p.N) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) sacc += red[g * 256 + t];
+            dB[n0 + t] = sacc;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {                       // C/D: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+            const int n = n0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (n >= p.N) continue;
+            float* row = dW + (size_t)n * p.ldw;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + wc * 64 + j * 32 + fr;
+                if (k < p.ldw) row[k] = acc[i][j][r];
+            }
+        }
+    }
+}
+
 // XCD-aware block order over a flattened grid of T blocks: workgroups are dispatched round-robin over the 8 XCDs, so
 // physical block p runs on XCD p & 7.  Logical ids are handed out in runs of WG_RUN consecutive tiles per XCD (consecutive
 // k-tiles of one dY tile, which then stays in that XCD's L2) while every XCD still sees every part of a sorted problem list.
@@ -316,6 +557,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const cris_wgrad_
     const int tk = (p.K + WG_T - 1) / WG_T, tn = (p.N + WG_T - 1) / WG_T;
     const int bx = l % tk, by = (l / tk) % tn, bz = l / (tk * tn);
     wgrad_tile<WG_MS, WG_STAGES>(p, bx, by, bz, smem);
+}
+
+__global__ __launch_bounds__(512) void conv_wgrad8_kernel(const cris_wgrad_params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tk = (p.K + WG8_T - 1) / WG8_T, tn = (p.N + WG8_T - 1) / WG8_T;
+    const int lb = wg_logical_block(blockIdx.x, gridDim.x);
+    const int bx = lb % tk, by = (lb / tk) % tn, bz = lb / (tk * tn);
+    wgrad8_tile(p, bx, by, bz, smem);
+}
+
+__global__ __launch_bounds__(512) void conv_wgrad8_group_kernel(const cris_wgrad_group g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lb = wg_logical_block(blockIdx.x, gridDim.x);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CRIS_WGRAD_GROUP_MAX; ++i) pi += g.block_start[i] <= lb ? 1 : 0;
+    const cris_wgrad_params p = g.prob[pi];
+    const int l = lb - g.block_start[pi];
+    const int tk = (p.K + WG8_T - 1) / WG8_T, tn = (p.N + WG8_T - 1) / WG8_T;
+    const int bx = l % tk, by = (l / tk) % tn, bz = l / (tk * tn);
+    wgrad8_tile(p, bx, by, bz, smem);
 }
 
 // dW (and dbias) = sum over the splits' workspace slabs (deterministic: a fixed tree - 16 split lanes each add their splits
@@ -383,11 +645,21 @@ static int wgrad_effective_splits(int M, int splits) {
     const int rows_per = wg_rows_per_split(M, splits < 1 ? 1 : splits);
     return (M + rows_per - 1) / rows_per;
 }
-static int wgrad_blocks(const cris_wgrad_params& p) { return cris_cdiv(p.K, WG_T) * cris_cdiv(p.N, WG_T) * p.splits; }
+// output tile the launchers use for a problem: 256 (8-wave kernel) when both dimensions fill most of it, else 128.
+// CRIS_WGRAD8=0 switches the 8-wave kernel off.
+static int wgrad_tile_size(const cris_wgrad_params& p) {
+    static const int on = cris_env_int("CRIS_WGRAD8", 1);
+    static const int min_n = cris_env_int("CRIS_WGRAD8_MIN_N", 192), min_k = cris_env_int("CRIS_WGRAD8_MIN_K", 192);
+    return (on && p.N >= min_n && p.K >= min_k) ? WG8_T : WG_T;
+}
+extern "C" int cris_conv_wgrad_tile(const cris_wgrad_params* p) { return wgrad_tile_size(*p); }
+static int wgrad_blocks(const cris_wgrad_params& p, int tile) { return cris_cdiv(p.K, tile) * cris_cdiv(p.N, tile) * p.splits; }
 
 static int wgrad_lds_ready() {
     static const int rc = (int)hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) |
-                          (int)hipFuncSetAttribute((const void*)conv_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS);
+                          (int)hipFuncSetAttribute((const void*)conv_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) |
+                          (int)hipFuncSetAttribute((const void*)conv_wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG8_LDS) |
+                          (int)hipFuncSetAttribute((const void*)conv_wgrad8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG8_LDS);
     if (rc != 0) cris_set_error("cris_conv_wgrad: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", rc);
     return rc;
 }
@@ -415,7 +687,8 @@ extern "C" int cris_conv_wgrad(const cris_wgrad_params* pp, void* stream) {
     p.splits = wgrad_effective_splits(p.M, p.splits);
     if (wgrad_check(p, __func__)) return -1;
     if (wgrad_lds_ready() != 0) return -1;
-    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(wgrad_blocks(p)), dim3(256), WG_LDS, (hipStream_t)stream, p);
+    if (wgrad_tile_size(p) == WG8_T) hipLaunchKernelGGL(conv_wgrad8_kernel, dim3(wgrad_blocks(p, WG8_T)), dim3(512), WG8_LDS, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(conv_wgrad_kernel, dim3(wgrad_blocks(p, WG_T)), dim3(256), WG_LDS, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return p.splits > 1 ? cris_wgrad_reduce(&p, stream) : 0;
 }
@@ -424,15 +697,18 @@ extern "C" int cris_conv_wgrad_group(const cris_wgrad_group* gp, void* stream) {
     CRIS_CHECK_ARG(gp && gp->n > 0 && gp->n <= CRIS_WGRAD_GROUP_MAX, "1 .. CRIS_WGRAD_GROUP_MAX problems per launch");
     cris_wgrad_group g = *gp;
     int start = 0;
+    const int tile = wgrad_tile_size(g.prob[0]);
     for (int i = 0; i < g.n; ++i) {
         g.prob[i].splits = wgrad_effective_splits(g.prob[i].M, g.prob[i].splits);
         if (wgrad_check(g.prob[i], __func__)) return -1;
+        CRIS_CHECK_ARG(wgrad_tile_size(g.prob[i]) == tile, "the problems of one group must share the output tile (cris_conv_wgrad_tile)");
         g.block_start[i] = start;
-        start += wgrad_blocks(g.prob[i]);
+        start += wgrad_blocks(g.prob[i], tile);
     }
     for (int i = g.n; i <= CRIS_WGRAD_GROUP_MAX; ++i) g.block_start[i] = start;
     if (wgrad_lds_ready() != 0) return -1;
-    hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3(start), dim3(256), WG_LDS, (hipStream_t)stream, g);
+    if (tile == WG8_T) hipLaunchKernelGGL(conv_wgrad8_group_kernel, dim3(start), dim3(512), WG8_LDS, (hipStream_t)stream, g);
+    else hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3(start), dim3(256), WG_LDS, (hipStream_t)stream, g);
     CRIS_LAUNCH_CHECK();
     for (int i = 0; i < g.n; ++i)
         if (g.prob[i].splits > 1 && cris_wgrad_reduce(&g.prob[i], stream) != 0) return -1;

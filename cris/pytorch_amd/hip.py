@@ -211,6 +211,7 @@ _SIGS = {
     "cris_conv_gemm": (I, [P, P]),
     "cris_conv_wgrad": (I, [P, P]),
     "cris_conv_wgrad_group": (I, [P, P]),
+    "cris_conv_wgrad_tile": (I, [P]),
     "cris_wgrad_reduce": (I, [P, P]),
     "cris_wgrad_ws_floats": (L, [I, I, I, I]),
     "cris_pack_weights": (I, [P, I, I, P]),

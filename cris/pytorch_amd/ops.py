@@ -181,12 +181,16 @@ _WGRAD_MIN_STEPS = int(os.environ.get("CRIS_WGRAD_MIN_STEPS", "8"))    # 128-row
 _WGRAD_FLUSH_BLOCKS = int(os.environ.get("CRIS_WGRAD_FLUSH_BLOCKS", "3072"))
 
 
-def wgrad_splits(M: int, N: int, K: int) -> int:
-    """split the pixel reduction only as far as needed to put ~2 blocks on each of the 256 CUs; every split costs a
-    128x128 partial tile written to and read back from the workspace, so long reductions per block win"""
-    tiles = ((N + 127) // 128) * ((K + 127) // 128)
+_WGRAD8_BLOCKS = int(os.environ.get("CRIS_WGRAD8_BLOCKS", "256"))    # 8-wave 256x256 tile: one block (128 KB of LDS) per CU
+
+
+def wgrad_splits(M: int, N: int, K: int, tile: int = 128) -> int:
+    """split the pixel reduction only as far as needed to put ~2 blocks (128x128 tile) / 1 block (256x256 tile) on each of the
+    256 CUs; every split costs a partial tile written to and read back from the workspace, so long reductions per block win"""
+    tiles = ((N + tile - 1) // tile) * ((K + tile - 1) // tile)
     steps = (M + 127) // 128
-    want = max(1, (_WGRAD_BLOCKS + tiles // 2) // tiles)
+    blocks = _WGRAD_BLOCKS if tile == 128 else _WGRAD8_BLOCKS
+    want = max(1, (blocks + tiles // 2) // tiles)
     return max(1, min(want, (steps + _WGRAD_MIN_STEPS - 1) // _WGRAD_MIN_STEPS, 256))
 
 
@@ -219,7 +223,8 @@ class WgradQueue:
         self.on_full = on_full        # called instead of flush() when enough blocks are waiting (the engine picks the stream)
 
     def add(self, p, keep, flops, nbytes):
-        self.items.append((p, keep, flops, nbytes))
+        tile = hip.load().cris_conv_wgrad_tile(C.byref(p))       # 128 or 256: a group launch runs ONE tile kernel
+        self.items.append((p, keep, flops, nbytes, tile))
         self.blocks += ((p.N + 127) // 128) * ((p.K + 127) // 128)
         if self.blocks >= _WGRAD_FLUSH_BLOCKS:
             (self.on_full or self.flush)()
@@ -230,9 +235,12 @@ class WgradQueue:
         items, self.items, self.blocks = self.items, [], 0
         if not items:
             return []
-        items.sort(key=lambda it: -it[0].M)                    # stable: longest pixel reductions are dispatched first
-        for i in range(0, len(items), hip.WGRAD_GROUP_MAX):
-            chunk = items[i:i + hip.WGRAD_GROUP_MAX]
+        items.sort(key=lambda it: (-it[4], -it[0].M))          # by tile kernel; stable: longest pixel reductions first
+        bounds = [i for i in range(len(items)) if i == 0 or items[i][4] != items[i - 1][4]] + [len(items)]
+        starts = [i for a, b in zip(bounds, bounds[1:]) for i in range(a, b, hip.WGRAD_GROUP_MAX)]
+        ends = [min(i + hip.WGRAD_GROUP_MAX, next(b for b in bounds[1:] if b > i)) for i in starts]
+        for i, j in zip(starts, ends):
+            chunk = items[i:j]
             grp = hip.WgradGroup()
             grp.n = len(chunk)
             for j, it in enumerate(chunk):
@@ -255,8 +263,8 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
         p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, 1, dbias)
         queue.add(p, (dY, X, dW, dbias), flops, nbytes)
         return
-    p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, splits if splits is not None else wgrad_splits(g.M, N, g.K),
-                      dbias)
+    p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, 1, dbias)
+    p.splits = splits if splits is not None else wgrad_splits(g.M, N, g.K, hip.load().cris_conv_wgrad_tile(C.byref(p)))
     nws = hip.load().cris_wgrad_ws_floats(p.M, p.N, p.ldw, p.splits)
     ws = torch.empty(nws, dtype=torch.float32, device=dW.device) if nws else None
     p.ws = ptr(ws)

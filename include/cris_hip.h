@@ -103,6 +103,9 @@ typedef struct {
     float* ws;               /* splits > 1: workspace of cris_wgrad_ws_floats(M, N, ldw, splits) floats, 16-byte aligned */
 } cris_wgrad_params;
 int cris_conv_wgrad(const cris_wgrad_params* p, void* stream);
+/* output tile (128: 4-wave kernel, 256: 8-wave kernel) the launchers use for this problem; host only.  A caller that sizes the
+ * pixel split from the tile count asks this first; the problems of one cris_conv_wgrad_group launch must share the tile. */
+int cris_conv_wgrad_tile(const cris_wgrad_params* p);
 long cris_wgrad_ws_floats(int M, int N, int ldw, int splits);
 int cris_wgrad_reduce(const cris_wgrad_params* p, void* stream);
 

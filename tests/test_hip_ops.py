@@ -331,6 +331,8 @@ WGRAD_CASES = [
     dict(B=8, H=1, W=1, C=1024, N=2305, k=1),
     dict(B=1500, H=1, W=1, C=40, N=24, k=1),
     dict(B=2, H=26, W=26, C=128, N=256, k=3),          # M=1352: many tiles, long pixel loop with image-border carries
+    dict(B=3, H=10, W=10, C=72, N=200, k=3),           # 8-wave 256x256 tile with ragged n / k tails (N 200, K 648), M 300
+    dict(B=8, H=52, W=52, C=128, N=256, k=3),          # benchmark shape M 21632 / N 256 / K 1152: 8-wave tile, split pixel range
 ]
 
 
@@ -376,6 +378,18 @@ def test_conv_wgrad(case):
         if splits in outs:
             assert torch.equal(outs[splits][0], dWg) and torch.equal(outs[splits][1], dbias), "split reduction is not deterministic"
         outs[splits] = (dWg, dbias)
+
+
+def test_conv_wgrad_tile_choice():
+    """which problems the launchers put on the 8-wave 256x256 tile (cris_conv_wgrad_tile): both dimensions >= 192"""
+    import ctypes
+    from cris.pytorch_amd import hip
+    got = []
+    for case in WGRAD_CASES:
+        p = hip.WgradParams()
+        p.N, p.K = case["N"], case["k"] * case["k"] * case["C"]
+        got.append(hip.load().cris_conv_wgrad_tile(ctypes.byref(p)))
+    assert got == [128, 128, 128, 128, 256, 128, 256, 256, 256], got
 
 
 def test_conv_wgrad_group():
