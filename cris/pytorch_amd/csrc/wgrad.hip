@@ -309,6 +309,7 @@ __device__ __forceinline__ void wgrad_tile(const cris_wgrad_params& p, int bx, i
         __builtin_amdgcn_sched_barrier(0);          \
     } while (0)
 
+template <bool DMA_IN_MFMA>
 __device__ __forceinline__ void wgrad8_tile(const cris_wgrad_params& p, int bx, int by, int bz, unsigned char* smem) {
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -434,7 +435,9 @@ __device__ __forceinline__ void wgrad8_tile(const cris_wgrad_params& p, int bx, 
     int buf = 0;
     for (int st = 0; st < nsteps; ++st) {
         // ---- MEM segment
-        issue_step();                               // step st+3 -> the buffer of step st-1 (steps beyond the range read zeros)
+        if constexpr (!DMA_IN_MFMA) {
+            issue_step();                           // step st+3 -> the buffer of step st-1 (steps beyond the range read zeros)
+        }
         const unsigned sbase = lds_base + (unsigned)(buf * WG8_STEP);
         wg_s16x4 fy[2][4][2], fx[2][2][2];          // [slice][fragment][q]
 #pragma unroll
@@ -462,6 +465,13 @@ __device__ __forceinline__ void wgrad8_tile(const cris_wgrad_params& p, int bx, 
             }
         }
         // fragments in registers (the asm carries them: every use is ordered after it), step st+1 landed (2 steps stay in flight)
+#define WG8_WAIT_OPERANDS                                                                                                              \
+    "+v"(fy[0][0][0]), "+v"(fy[0][0][1]), "+v"(fy[0][1][0]), "+v"(fy[0][1][1]), "+v"(fy[0][2][0]), "+v"(fy[0][2][1]), "+v"(fy[0][3][0]), \
+        "+v"(fy[0][3][1]), "+v"(fy[1][0][0]), "+v"(fy[1][0][1]), "+v"(fy[1][1][0]), "+v"(fy[1][1][1]), "+v"(fy[1][2][0]),                \
+        "+v"(fy[1][2][1]), "+v"(fy[1][3][0]), "+v"(fy[1][3][1])
+        if constexpr (DMA_IN_MFMA) {                // step st+3 is issued later, inside the MFMA segment: one step stays in flight here
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" : WG8_WAIT_OPERANDS : : "memory");
+        } else
         asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)"
                      : "+v"(fy[0][0][0]), "+v"(fy[0][0][1]), "+v"(fy[0][1][0]), "+v"(fy[0][1][1]), "+v"(fy[0][2][0]), "+v"(fy[0][2][1]),
                        "+v"(fy[0][3][0]), "+v"(fy[0][3][1]), "+v"(fy[1][0][0]), "+v"(fy[1][0][1]), "+v"(fy[1][1][0]), "+v"(fy[1][1][1]),
@@ -485,6 +495,11 @@ __device__ __forceinline__ void wgrad8_tile(const cris_wgrad_params& p, int bx, 
                 const bf16x8 af = wg_join(fy[ks][i][0], fy[ks][i][1]);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
+                if constexpr (DMA_IN_MFMA) {
+                    if (ks == 0 && i == 0) {
+                        issue_step();               // the DMAs of step st+3 issue underneath the MFMAs
+                    }
+                }
             }
         }
         asm volatile("" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[2][0]), "+v"(acc[2][1]), "+v"(acc[3][0]),
@@ -559,12 +574,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const cris_wgrad_
     wgrad_tile<WG_MS, WG_STAGES>(p, bx, by, bz, smem);
 }
 
+template <bool MI>
 __global__ __launch_bounds__(512) void conv_wgrad8_kernel(const cris_wgrad_params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tk = (p.K + WG8_T - 1) / WG8_T, tn = (p.N + WG8_T - 1) / WG8_T;
     const int lb = wg_logical_block(blockIdx.x, gridDim.x);
     const int bx = lb % tk, by = (lb / tk) % tn, bz = lb / (tk * tn);
-    wgrad8_tile(p, bx, by, bz, smem);
+    wgrad8_tile<MI>(p, bx, by, bz, smem);
 }
 
 __global__ __launch_bounds__(512) void conv_wgrad8_group_kernel(const cris_wgrad_group g) {
@@ -577,7 +593,7 @@ __global__ __launch_bounds__(512) void conv_wgrad8_group_kernel(const cris_wgrad
     const int l = lb - g.block_start[pi];
     const int tk = (p.K + WG8_T - 1) / WG8_T, tn = (p.N + WG8_T - 1) / WG8_T;
     const int bx = l % tk, by = (l / tk) % tn, bz = l / (tk * tn);
-    wgrad8_tile(p, bx, by, bz, smem);
+    wgrad8_tile<true>(p, bx, by, bz, smem);
 }
 
 // dW (and dbias) = sum over the splits' workspace slabs (deterministic: a fixed tree - 16 split lanes each add their splits
@@ -645,12 +661,16 @@ static int wgrad_effective_splits(int M, int splits) {
     const int rows_per = wg_rows_per_split(M, splits < 1 ? 1 : splits);
     return (M + rows_per - 1) / rows_per;
 }
-// output tile the launchers use for a problem: 256 (8-wave kernel) when both dimensions fill most of it, else 128.
+// output tile the launchers use for a problem (p.tile == 0; 128 / 256 there force one): the 8-wave 256x256 kernel for the long,
+// wide reductions only.  Measured (profiles/r03_ab_experiments.md): +16-19% on the three K = 4608, M >= 21632 shapes of the
+// benchmark (766 vs 643 TFLOP/s), slower than the 4-wave kernel on the mid-size ones (fewer, larger blocks on 256 CUs).
 // CRIS_WGRAD8=0 switches the 8-wave kernel off.
 static int wgrad_tile_size(const cris_wgrad_params& p) {
     static const int on = cris_env_int("CRIS_WGRAD8", 1);
-    static const int min_n = cris_env_int("CRIS_WGRAD8_MIN_N", 192), min_k = cris_env_int("CRIS_WGRAD8_MIN_K", 192);
-    return (on && p.N >= min_n && p.K >= min_k) ? WG8_T : WG_T;
+    static const int min_n = cris_env_int("CRIS_WGRAD8_MIN_N", 192), min_k = cris_env_int("CRIS_WGRAD8_MIN_K", 4096);
+    static const int min_m = cris_env_int("CRIS_WGRAD8_MIN_M", 16384);
+    if (p.tile == WG_T || p.tile == WG8_T) return p.tile;
+    return (on && p.N >= min_n && p.K >= min_k && p.M >= min_m) ? WG8_T : WG_T;
 }
 extern "C" int cris_conv_wgrad_tile(const cris_wgrad_params* p) { return wgrad_tile_size(*p); }
 static int wgrad_blocks(const cris_wgrad_params& p, int tile) { return cris_cdiv(p.K, tile) * cris_cdiv(p.N, tile) * p.splits; }
@@ -658,7 +678,8 @@ static int wgrad_blocks(const cris_wgrad_params& p, int tile) { return cris_cdiv
 static int wgrad_lds_ready() {
     static const int rc = (int)hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) |
                           (int)hipFuncSetAttribute((const void*)conv_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) |
-                          (int)hipFuncSetAttribute((const void*)conv_wgrad8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG8_LDS) |
+                          (int)hipFuncSetAttribute((const void*)conv_wgrad8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG8_LDS) |
+                          (int)hipFuncSetAttribute((const void*)conv_wgrad8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WG8_LDS) |
                           (int)hipFuncSetAttribute((const void*)conv_wgrad8_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG8_LDS);
     if (rc != 0) cris_set_error("cris_conv_wgrad: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", rc);
     return rc;
@@ -687,7 +708,11 @@ extern "C" int cris_conv_wgrad(const cris_wgrad_params* pp, void* stream) {
     p.splits = wgrad_effective_splits(p.M, p.splits);
     if (wgrad_check(p, __func__)) return -1;
     if (wgrad_lds_ready() != 0) return -1;
-    if (wgrad_tile_size(p) == WG8_T) hipLaunchKernelGGL(conv_wgrad8_kernel, dim3(wgrad_blocks(p, WG8_T)), dim3(512), WG8_LDS, (hipStream_t)stream, p);
+    static const int w8_mi = cris_env_int("CRIS_WGRAD8_MI", 1);
+    if (wgrad_tile_size(p) == WG8_T) {
+        if (w8_mi) hipLaunchKernelGGL(conv_wgrad8_kernel<true>, dim3(wgrad_blocks(p, WG8_T)), dim3(512), WG8_LDS, (hipStream_t)stream, p);
+        else hipLaunchKernelGGL(conv_wgrad8_kernel<false>, dim3(wgrad_blocks(p, WG8_T)), dim3(512), WG8_LDS, (hipStream_t)stream, p);
+    }
     else hipLaunchKernelGGL(conv_wgrad_kernel, dim3(wgrad_blocks(p, WG_T)), dim3(256), WG_LDS, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return p.splits > 1 ? cris_wgrad_reduce(&p, stream) : 0;

@@ -39,7 +39,7 @@ class WgradParams(C.Structure):
                 ("Bn", I), ("H", I), ("W", I), ("C", I),
                 ("OH", I), ("OW", I), ("KH", I), ("KW", I), ("stride", I), ("pad", I),
                 ("M", I), ("N", I), ("K", I),
-                ("ldw", I), ("splits", I),
+                ("ldw", I), ("splits", I), ("tile", I), ("pad_", I),
                 ("dbias", P), ("ws", P)]
 
 

@@ -194,8 +194,9 @@ def wgrad_splits(M: int, N: int, K: int, tile: int = 128) -> int:
     return max(1, min(want, (steps + _WGRAD_MIN_STEPS - 1) // _WGRAD_MIN_STEPS, 256))
 
 
-def _wgrad_params(dY, X, g: Geom, N: int, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, splits, dbias):
+def _wgrad_params(dY, X, g: Geom, N: int, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, splits, dbias, tile=0):
     p = hip.WgradParams()
+    p.tile = tile
     p.dY, p.X, p.dW = ptr(dY), ptr(X), ptr(dW)
     p.ldy = ldy if ldy is not None else dY.shape[-1]
     p.y_coff = y_coff
@@ -254,16 +255,16 @@ class WgradQueue:
 
 
 def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, ldw=None, splits=None, dbias=None,
-               queue: Optional[WgradQueue] = None):
+               queue: Optional[WgradQueue] = None, tile: int = 0):
     """dW[N][K] = dY^T X_im2col (GEMM layout), dbias = column sums of dY.  With a `queue`, problems of up to
     CRIS_WGRAD_GROUP_M pixel rows are deferred to the queue's next grouped launch (unsplit); larger ones (and every call
     without a queue) launch now, their pixel range split over blocks with a deterministic workspace reduction."""
     flops, nbytes = 2.0 * g.M * N * g.K, 2.0 * (g.M * N + g.M * g.C) + 4.0 * N * g.K
     if queue is not None and splits is None and g.M <= _WGRAD_GROUP_M:
-        p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, 1, dbias)
+        p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, 1, dbias, tile)
         queue.add(p, (dY, X, dW, dbias), flops, nbytes)
         return
-    p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, 1, dbias)
+    p = _wgrad_params(dY, X, g, N, dW, ldy, y_coff, N_ld, ldx, x_coff, ldw, 1, dbias, tile)
     p.splits = splits if splits is not None else wgrad_splits(g.M, N, g.K, hip.load().cris_conv_wgrad_tile(C.byref(p)))
     nws = hip.load().cris_wgrad_ws_floats(p.M, p.N, p.ldw, p.splits)
     ws = torch.empty(nws, dtype=torch.float32, device=dW.device) if nws else None

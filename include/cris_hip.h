@@ -99,6 +99,8 @@ typedef struct {
     int ldw;                 /* row stride of dW (>= K) */
     int splits;              /* requested split of the pixel range (each split covers ceil(M/splits) rows rounded up to 128;
                                 the launcher drops splits that would be empty) */
+    int tile;                /* output tile: 0 = the library's choice (cris_conv_wgrad_tile), 128 = 4-wave kernel, 256 = 8-wave */
+    int pad_;
     float* dbias;            /* optional [N]: = column sums of dY (bias gradient); or NULL */
     float* ws;               /* splits > 1: workspace of cris_wgrad_ws_floats(M, N, ldw, splits) floats, 16-byte aligned */
 } cris_wgrad_params;

@@ -328,11 +328,13 @@ WGRAD_CASES = [
     dict(B=2, H=12, W=12, C=64, N=64, k=3),
     dict(B=1, H=20, W=20, C=32, N=32, k=3),
     dict(B=2, H=9, W=9, C=136, N=72, k=3, C_real=130),
-    dict(B=8, H=1, W=1, C=1024, N=2305, k=1),
+    dict(B=8, H=1, W=1, C=1024, N=2305, k=1, tile=256),
     dict(B=1500, H=1, W=1, C=40, N=24, k=1),
     dict(B=2, H=26, W=26, C=128, N=256, k=3),          # M=1352: many tiles, long pixel loop with image-border carries
-    dict(B=3, H=10, W=10, C=72, N=200, k=3),           # 8-wave 256x256 tile with ragged n / k tails (N 200, K 648), M 300
-    dict(B=8, H=52, W=52, C=128, N=256, k=3),          # benchmark shape M 21632 / N 256 / K 1152: 8-wave tile, split pixel range
+    dict(B=2, H=26, W=26, C=128, N=256, k=3, tile=256),    # the same on the 8-wave 256x256 tile (forced: the library picks it
+    dict(B=3, H=10, W=10, C=72, N=200, k=3, tile=256),     # only for M >= 16384, K >= 4096); ragged n / k tails (N 200, K 648)
+    dict(B=8, H=52, W=52, C=128, N=256, k=3, tile=256),    # benchmark shape M 21632 / N 256 / K 1152, split pixel range
+    dict(B=6, H=52, W=52, C=512, N=256, k=3),          # M 16224 / K 4608: the library's own choice is the 8-wave tile
 ]
 
 
@@ -373,7 +375,7 @@ def test_conv_wgrad(case):
     for splits in (None, 1, 3, 3):
         dWg = torch.full((N, k * k * C_), float("nan"), device=DEV)      # GEMM layout [n][tap][c]; every element is overwritten
         dbias = torch.full((N,), float("nan"), device=DEV)
-        ops.conv_wgrad(bf(dy), bf(x), g, N, dWg, splits=splits, dbias=dbias)
+        ops.conv_wgrad(bf(dy), bf(x), g, N, dWg, splits=splits, dbias=dbias, tile=case.get("tile", 0))
         _wgrad_check(case, dWg, dbias, dy, ref, C_real, "splits=%s" % splits)
         if splits in outs:
             assert torch.equal(outs[splits][0], dWg) and torch.equal(outs[splits][1], dbias), "split reduction is not deterministic"
@@ -381,15 +383,17 @@ def test_conv_wgrad(case):
 
 
 def test_conv_wgrad_tile_choice():
-    """which problems the launchers put on the 8-wave 256x256 tile (cris_conv_wgrad_tile): both dimensions >= 192"""
+    """which problems the launchers put on the 8-wave 256x256 tile (cris_conv_wgrad_tile): long, wide reductions
+    (M >= 16384, K >= 4096, N >= 192), or whatever params.tile asks for"""
     import ctypes
     from cris.pytorch_amd import hip
     got = []
-    for case in WGRAD_CASES:
+    for M, N, K, tile in [(21632, 512, 4608, 0), (21632, 256, 1152, 0), (5408, 512, 4608, 0), (21632, 128, 4608, 0),
+                          (86528, 256, 4608, 0), (300, 200, 648, 256), (21632, 512, 4608, 128)]:
         p = hip.WgradParams()
-        p.N, p.K = case["N"], case["k"] * case["k"] * case["C"]
+        p.M, p.N, p.K, p.tile = M, N, K, tile
         got.append(hip.load().cris_conv_wgrad_tile(ctypes.byref(p)))
-    assert got == [128, 128, 128, 128, 256, 128, 256, 256, 256], got
+    assert got == [256, 128, 128, 128, 256, 256, 128], got
 
 
 def test_conv_wgrad_group():
@@ -406,7 +410,7 @@ def test_conv_wgrad_group():
         dWg = torch.full((N, k * k * C_), float("nan"), device=DEV)
         dbias = torch.full((N,), float("nan"), device=DEV)
         dyb, xb = bf(dy), bf(x)
-        ops.conv_wgrad(dyb, xb, g, N, dWg, dbias=dbias, queue=q)
+        ops.conv_wgrad(dyb, xb, g, N, dWg, dbias=dbias, queue=q, tile=case.get("tile", 0))
         jobs.append((case, dWg, dbias, dy, ref, C_real, dyb, xb, g))
     assert q.items, "nothing was queued"
     q.flush()
@@ -415,7 +419,8 @@ def test_conv_wgrad_group():
         _wgrad_check(case, dWg, dbias, dy, ref, C_real, "grouped")
         one = torch.empty_like(dWg)
         ob = torch.empty_like(dbias)
-        ops.conv_wgrad(dyb, xb, g, case["N"], one, splits=1, dbias=ob)
+        # (problems of more than 8192 pixel rows are not queued: they were launched at once with their automatic split)
+        ops.conv_wgrad(dyb, xb, g, case["N"], one, splits=1 if g.M <= 8192 else None, dbias=ob, tile=case.get("tile", 0))
         assert torch.equal(one, dWg) and torch.equal(ob, dbias)
 
 
