@@ -462,15 +462,30 @@ __device__ __forceinline__ void al_stage_f32(const __amdgpu_buffer_rsrc_t& rs, u
 __device__ __forceinline__ bf16x8 al_ld16(const unsigned char* tile, int row, int chunk) {
     return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(tile + row * 128 + (((chunk ^ row) & 7) << 4)));
 }
+// XCD-aware block order: consecutive workgroups go to the 8 XCDs round-robin, each with its own 4 MB L2.  The grid is
+// (sequence tiles, batch*heads); with the plain order the ~11 tile blocks of one (batch, head) - which all stream the SAME
+// K / V (Q / dO) panel - land on 8 different XCDs and the panel is fetched from HBM up to 8 times (round 2 PMC: 96-152 MB
+// fetched per launch against ~20 MB of operands).  Here every XCD gets a contiguous run of (batch, head) pairs, so a panel
+// is fetched by one L2 only.  (x, bh) out: the tile index and the batch*heads index this block works on.
+__device__ __forceinline__ void al_block(int& x, int& bh) {
+    const int nx = gridDim.x, total = nx * gridDim.y;
+    int lin = blockIdx.y * nx + blockIdx.x;
+    const int q = total >> 3, r = total & 7;
+    const int xcd = lin & 7, idx = lin >> 3;
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    bh = lin / nx;
+    x = lin - bh * nx;
+}
 // ---- forward: block = AL_WAVES x 32 queries; stage = K tile | V^T tile -------------------------------------------------
 __global__ __launch_bounds__(64 * AL_WAVES) void attn_fwd_lds_kernel(const cris_attn_params p) {
     constexpr int STAGES = 3, STAGE_BYTES = 2 * AL_TILE, NDMA = 2 * AL_NI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int bh = blockIdx.y;
+    int bx, bh;
+    al_block(bx, bh);
     const int b = bh / p.Hn, h = bh - b * p.Hn;
-    const int q0w = blockIdx.x * (32 * AL_WAVES) + wave * 32;
+    const int q0w = bx * (32 * AL_WAVES) + wave * 32;
 
     int q[2];
     bool qok[2];
@@ -618,9 +633,10 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int bh = blockIdx.y;
+    int bx, bh;
+    al_block(bx, bh);
     const int b = bh / p.Hn, h = bh - b * p.Hn;
-    const int q0w = blockIdx.x * (32 * AL_WAVES) + wave * 32;
+    const int q0w = bx * (32 * AL_WAVES) + wave * 32;
 
     int q[2];
     bool qok[2];
@@ -761,9 +777,10 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fg = lane >> 4;
-    const int bh = blockIdx.y;
+    int bx, bh;
+    al_block(bx, bh);
     const int b = bh / p.Hn, h = bh - b * p.Hn;
-    const int k0w = blockIdx.x * (32 * AL_WAVES) + wave * 32;
+    const int k0w = bx * (32 * AL_WAVES) + wave * 32;
 
     int key[2];
     bool kok[2], kpad[2];

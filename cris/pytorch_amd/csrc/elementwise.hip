@@ -424,7 +424,8 @@ extern "C" int cris_embed_fwd(const int64_t* tokens, const float* table, const f
 }
 // Deterministic (no atomics): the thread of row r, column d adds up every row that holds the same token (same position) in
 // row order and only the FIRST such row stores the sum - B*L is 136 / 176 rows, the scan is free.
-__global__ void embed_bwd_kernel(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos) {
+__global__ void embed_bwd_kernel(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos,
+                                 unsigned char* row_live) {
     const long total = (long)Bn * L * D;
     const int R = Bn * L;
     GRID_STRIDE(idx, total) {
@@ -438,6 +439,7 @@ __global__ void embed_bwd_kernel(const int64_t* tokens, const float* dx, int Bn,
             for (int q = r; q < R; ++q)
                 if (tokens[q] == tok) a += dx[(size_t)q * D + d];
             dtable[(size_t)tok * D + d] = a;
+            if (row_live && d == 0) row_live[tok] = 1;
         }
         if (r < L) {                                   // position r: rows r, r + L, r + 2L, ...
             float a = 0.f;
@@ -447,10 +449,10 @@ __global__ void embed_bwd_kernel(const int64_t* tokens, const float* dx, int Bn,
     }
 }
 extern "C" int cris_embed_bwd(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos,
-                              void* stream) {
+                              unsigned char* row_live, void* stream) {
     CRIS_CHECK_ARG(tokens && dx && dtable && dpos, "bad args");
     hipLaunchKernelGGL(embed_bwd_kernel, dim3(cris_grid_1d((long)Bn * L * D, 256)), dim3(256), 0, (hipStream_t)stream, tokens, dx,
-                       Bn, L, D, dtable, dpos);
+                       Bn, L, D, dtable, dpos, row_live);
     CRIS_LAUNCH_CHECK();
     return 0;
 }
@@ -918,9 +920,11 @@ __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restr
         return;
     }
     const long base = (long)(bid - d.block_start) * ADAM_ELEMS;
+    const unsigned char* live = (wd == 0.f && d.taps == 0) ? d.row_live : nullptr;      // see cris_adam_desc.row_live
     for (int e = threadIdx.x; e < ADAM_ELEMS; e += 256) {
         const long i = base + e;
         if (i >= d.n) break;
+        if (live && !live[i / d.row_len]) continue;       // a row without any gradient so far: the update is the identity
         long gi = i;
         if (d.taps > 0) {                 // gradient kept in the GEMM layout [n][tap][cpad] (cris_conv_wgrad)
             const long per_n = (long)d.cin * d.taps;

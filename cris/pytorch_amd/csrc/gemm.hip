@@ -430,9 +430,17 @@ __global__ __launch_bounds__(256) void skinny_finish_kernel(const cris_conv_gemm
     const int nb = c >> 1, j = c & 1;
     f32x4 one[1][1];
     one[0][0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int ks = 0; ks < nslices; ++ks) {
-        const f32x4 o = *reinterpret_cast<const f32x4*>(p.ws + ((size_t)ks * nblocks + nb) * (FM * 2 * 256) + (i * 2 + j) * 256 + lane * 4);
-        one[0][0][0] += o[0]; one[0][0][1] += o[1]; one[0][0][2] += o[2]; one[0][0][3] += o[3];
+    // (slab loads in batches of four issued together: the kernel is a few waves on an idle chip, i.e. load latency; the
+    // additions stay in slice order)
+    const float* src = p.ws + (size_t)nb * (FM * 2 * 256) + (i * 2 + j) * 256 + lane * 4;
+    const size_t slab = (size_t)nblocks * (FM * 2 * 256);
+    for (int k0 = 0; k0 < nslices; k0 += 4) {
+        f32x4 o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q] = *reinterpret_cast<const f32x4*>(src + (size_t)min(k0 + q, nslices - 1) * slab);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (k0 + q < nslices) { one[0][0][0] += o[q][0]; one[0][0][1] += o[q][1]; one[0][0][2] += o[q][2]; one[0][0][3] += o[q][3]; }
     }
     gemm_epilogue<0, 16, 1, 1>(p, one, i * 16, c * 16, i, lane);
 }

@@ -7,85 +7,148 @@
 // ------------------------------------------------------------------------------------------------
 // BN coefficients
 // ------------------------------------------------------------------------------------------------
-#define BN_MERGE_SLICES 64      // first-level merge width for long partial lists (see cris_bn_partials_rows)
-#define BN_MERGE_MIN 512        // lists up to this long go straight to the (16-lane) final merge
+#define BN_WIDE_MIN 128         // partial lists longer than this are merged by 64 part lanes per channel (1024-thread blocks)
+#define BN_MERGE_MIN 512        // ... and lists longer than this by a first-level merge launch into BN_MERGE_SLICES slices
+#define BN_MERGE_SLICES 64
 
-// Chan et al. pairwise update of (n, mean, M2) with a block (nb rows, sum sb, M2 mb)
-__device__ __forceinline__ void chan_add(float& n, float& mean, float& m2, float nb, float sb, float mb) {
-    if (nb <= 0.f) return;
-    const float mean_b = sb / nb;
-    const float nt = n + nb;
-    const float d = mean_b - mean;
-    mean += d * (nb / nt);
-    m2 += mb + d * d * (n * nb / nt);
-    n = nt;
+// sum of one value per (part lane, channel) over the PL part lanes of a block, returned to every lane of the channel; a fixed
+// order (PL = 64: eight groups of eight lanes, then the eight group sums), so the result is deterministic
+template <int PL>
+__device__ __forceinline__ float bn_lane_sum(float (*sh)[17], float v, int pl, int cl) {
+    __syncthreads();                        // the previous use of sh is over
+    sh[pl][cl] = v;
+    __syncthreads();
+    if (PL == 64) {
+        float g = 0.f;
+        if (pl < 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g += sh[pl * 8 + j][cl];
+        }
+        __syncthreads();
+        if (pl < 8) sh[pl][cl] = g;
+        __syncthreads();
+    }
+    float t = sh[0][cl];
+#pragma unroll
+    for (int j = 1; j < (PL == 64 ? 8 : PL); ++j) t += sh[j][cl];
+    return t;
 }
 
-// level 1: slice s merges parts [s*pps, (s+1)*pps) into one (sum, M2 about the slice mean) row.  Block = 64 channels x 4
-// part lanes, coalesced 256-B rows; deterministic (fixed merge tree).
+// level 1 for the longest lists (the stem and layer-1 outputs: 676 - 2704 parts): slice s merges parts [s*pps, (s+1)*pps) into
+// one (sum, M2 about the slice mean) row, so that many CUs read the list - a single finalize launch has only C/16 blocks (4 at
+// C = 64) and one CU's load throughput then bounds it (measured: 50 us for 2704 parts against ~8 + 5 us for the two launches).
+// Block = 16 channels x 16 part lanes (as the finalize kernel: 64 x C/16 blocks), the same two-pass, division-free merge.
 __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__ psum, const float* __restrict__ pm2, int nparts,
                                                        int rows_per_part, int M, int C, int pps, float* __restrict__ osum,
                                                        float* __restrict__ om2) {
-    __shared__ float sh[3][4][64];
-    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float sh[16][17];
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl, cc = min(c, C - 1);
     const int s = blockIdx.y;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (c < C) {
-        const int i1 = min(nparts, (s + 1) * pps);
-        for (int i = s * pps + pl; i < i1; i += 4) {
-            const int rows = min(rows_per_part, M - i * rows_per_part);
-            if (rows > 0) chan_add(n, mean, m2, (float)rows, psum[(size_t)i * C + c], pm2[(size_t)i * C + c]);
+    const int i_begin = s * pps, i_end = min(nparts, (s + 1) * pps), last = nparts - 1;
+    const float n_full = (float)rows_per_part, n_last = (float)(M - last * rows_per_part);
+    const float n_slice = (float)(min(M, i_end * rows_per_part) - i_begin * rows_per_part);
+    // both columns of this lane's entries are requested up front (a slice is a few entries per lane)
+    float t = 0.f;
+    for (int i0 = i_begin + pl; i0 < i_end; i0 += 64) {
+        float ps[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) ps[u] = psum[(size_t)min(i0 + 16 * u, i_end - 1) * C + cc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + 16 * u < i_end) t += ps[u];
+    }
+    const float total = bn_lane_sum<16>(sh, t, pl, cl);
+    const float mean = total / n_slice;
+    const float inv_full = 1.f / n_full, inv_last = 1.f / n_last;
+    float q = 0.f;
+    for (int i0 = i_begin + pl; i0 < i_end; i0 += 64) {
+        float ps[4], pq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const size_t o = (size_t)min(i0 + 16 * u, i_end - 1) * C + cc;
+            ps[u] = psum[o];
+            pq[u] = pm2[o];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 16 * u;
+            if (i < i_end) {
+                const float d = ps[u] * (i == last ? inv_last : inv_full) - mean;
+                q += pq[u] + (i == last ? n_last : n_full) * d * d;
+            }
         }
     }
-    sh[0][pl][cl] = n; sh[1][pl][cl] = mean; sh[2][pl][cl] = m2;
-    __syncthreads();
+    const float m2 = bn_lane_sum<16>(sh, q, pl, cl);
     if (pl == 0 && c < C) {
-#pragma unroll
-        for (int j = 1; j < 4; ++j) chan_add(n, mean, m2, sh[0][j][cl], sh[1][j][cl] * sh[0][j][cl], sh[2][j][cl]);
-        osum[(size_t)s * C + c] = mean * n;
+        osum[(size_t)s * C + c] = total;
         om2[(size_t)s * C + c] = m2;
     }
 }
 
-// final merge + coefficients: block = 16 channels x 16 part lanes (coalesced 64-B rows), LDS tree over the part lanes
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
+// merge + coefficients in ONE launch: block = 16 channels x PL part lanes (coalesced 64-B rows).  Two passes over the partial
+// list (sum, M2 about the part mean; all parts rows_per_part rows, the last one what is left of count_local):
+//   mean = sum_i S_i / n,   M2 = sum_i [ M2_i + n_i (S_i / n_i - mean)^2 ]
+// - the exact decomposition of the sum of squares about the common mean (no E[x^2] - mean^2 cancellation) and, unlike a chain
+// of pairwise (Chan) updates, free of divisions inside the loops: with 64 lanes x 16 channels in a block the chain's three
+// divisions per entry made the kernel VALU-bound on its one CU (14 us per launch, 71 us for the 2704-part list of the stem).
+// The second pass re-reads the list (L2 hits).  PL = 64 serves lists of 129 - 512 parts; longer ones come through bn_merge_kernel.
+// The kernel is a handful of blocks on an otherwise idle chip, i.e. memory latency: the per-channel parameters are requested
+// before the list is walked, and the list in batches of eight entries whose loads are issued together.
+template <int PL>
+__global__ __launch_bounds__(16 * PL) void bn_finalize_kernel(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
                                    float count, const float* gamma, const float* beta, float* rmean, float* rvar,
                                    float momentum, float eps, int C, float* scale, float* shift, float* mean_o,
                                    float* invstd_o, float* merged /* optional [2*C]: local (sum, M2) for SyncBN */,
                                    const float* global_stats /* optional [2*C]: (sum, M2 about the global mean) */) {
-    __shared__ float sh[3][16][17];
+    __shared__ float sh[PL][17];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
+    const int cc = min(c, C - 1);            // lanes beyond C read channel C-1 and store nothing
+    float mean, m2;
+    float gam = 0.f, bet = 0.f, rm0 = 0.f, rv0 = 0.f;
+    if (pl == 0 && c < C && !merged) {
+        gam = gamma[c];
+        bet = beta[c];
+        if (rmean) { rm0 = rmean[c]; rv0 = rvar[c]; }
+    }
     if (!global_stats) {
-        if (c < C) {
-            // the loads of four list entries are issued together, ahead of the (dependent) merge arithmetic: the kernel is a
-            // handful of blocks on an otherwise idle chip, i.e. pure memory latency
-            const int M = (int)count_local;
-            for (int i0 = pl; i0 < nparts; i0 += 64) {
-                float ps[4], pq[4];
+        float s = 0.f;
+        for (int i0 = pl; i0 < nparts; i0 += 8 * PL) {
+            float ps[8];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = min(i0 + 16 * u, nparts - 1);
-                    ps[u] = psum[(size_t)i * C + c];
-                    pq[u] = pm2[(size_t)i * C + c];
-                }
+            for (int u = 0; u < 8; ++u) ps[u] = psum[(size_t)min(i0 + PL * u, nparts - 1) * C + cc];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + 16 * u;
-                    const int rows = i < nparts ? min(rows_per_part, M - i * rows_per_part) : 0;
-                    if (rows > 0) chan_add(n, mean, m2, (float)rows, ps[u], pq[u]);
+            for (int u = 0; u < 8; ++u)
+                if (i0 + PL * u < nparts) s += ps[u];
+        }
+        const float total = bn_lane_sum<PL>(sh, s, pl, cl);
+        mean = total / count_local;
+        const int last = nparts - 1;
+        const float n_full = (float)rows_per_part, n_last = count_local - (float)last * n_full;
+        const float inv_full = 1.f / n_full, inv_last = 1.f / n_last;
+        float q = 0.f;
+        for (int i0 = pl; i0 < nparts; i0 += 8 * PL) {
+            float ps[8], pq[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const size_t o = (size_t)min(i0 + PL * u, nparts - 1) * C + cc;
+                ps[u] = psum[o];
+                pq[u] = pm2[o];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = i0 + PL * u;
+                if (i < nparts) {
+                    const float d = ps[u] * (i == last ? inv_last : inv_full) - mean;
+                    q += pq[u] + (i == last ? n_last : n_full) * d * d;
                 }
             }
         }
-        sh[0][pl][cl] = n; sh[1][pl][cl] = mean; sh[2][pl][cl] = m2;
-        __syncthreads();
+        m2 = bn_lane_sum<PL>(sh, q, pl, cl);
         if (pl != 0 || c >= C) return;
-#pragma unroll
-        for (int j = 1; j < 16; ++j) chan_add(n, mean, m2, sh[0][j][cl], sh[1][j][cl] * sh[0][j][cl], sh[2][j][cl]);
         if (merged) {                       // hand the local (sum, M2) to the SyncBN exchange; finalize runs again after it
-            merged[c] = mean * n;
+            merged[c] = total;
             merged[C + c] = m2;
             mean_o[c] = mean;               // local mean, needed to re-centre M2 about the global mean
             return;
@@ -97,15 +160,15 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* psum, con
     }
     const float var = fmaxf(m2 / count, 0.f);
     const float inv = rsqrtf(var + eps);
-    const float sc = gamma[c] * inv;
+    const float sc = gam * inv;
     scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
+    shift[c] = bet - mean * sc;
     mean_o[c] = mean;
     invstd_o[c] = inv;
     if (rmean) {
         const float unb = count > 1.f ? var * (count / (count - 1.f)) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unb;
+        rmean[c] = (1.f - momentum) * rm0 + momentum * mean;
+        rvar[c] = (1.f - momentum) * rv0 + momentum * unb;
     }
 }
 
@@ -113,21 +176,32 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     __shared__ float sh[16][17];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
+    // latency-bound (a few blocks, a few loads each): the value to add to and this lane's rows are all requested up front
+    float o = 0.f;
+    if (pl == 0 && c < ncol) o = out[c];
     float a = 0.f;
-    if (c < ncol)
-        for (int i = pl; i < nparts; i += 16) a += part[(size_t)i * ncol + c];
+    if (c < ncol) {
+        for (int i0 = pl; i0 < nparts; i0 += 64) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = part[(size_t)min(i0 + 16 * u, nparts - 1) * ncol + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (i0 + 16 * u < nparts) a += v[u];
+        }
+    }
     sh[pl][cl] = a;
     __syncthreads();
     if (pl == 0 && c < ncol) {
 #pragma unroll
         for (int j = 1; j < 16; ++j) a += sh[j][cl];
-        out[c] += a;
+        out[c] = o + a;
     }
 }
 void cris_launch_sum_partials(const float* part, int nparts, int ncol, float* out, hipStream_t stream) {
     hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, stream, part, nparts, ncol, out);
 }
-// rows the caller must allocate for a partials buffer of `nparts` parts (room for the level-1 merge output)
+// rows the caller must allocate for a partials buffer of `nparts` parts (room for the level-1 merge output of long lists)
 extern "C" int cris_bn_partials_rows(int nparts) { return nparts > BN_MERGE_MIN ? nparts + BN_MERGE_SLICES : nparts; }
 
 extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
@@ -136,13 +210,15 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
                                 float* merged, const float* global_stats, void* stream) {
     CRIS_CHECK_ARG((global_stats || (psum && pm2 && nparts > 0 && rows_per_part > 0)) && gamma && beta && mean && C > 0 && count > 0.f, "bad args");
     CRIS_CHECK_ARG(merged || (scale && shift && invstd), "bad args");
+    CRIS_CHECK_ARG(global_stats || ((double)(nparts - 1) * rows_per_part < count_local && (double)nparts * rows_per_part >= count_local),
+                   "the partial list must cover count_local rows: nparts = ceil(count_local / rows_per_part)");
     if (!global_stats && nparts > BN_MERGE_MIN) {
-        // two-level merge: BN_MERGE_SLICES slices written behind the partials (rows nparts .. nparts+slices)
+        // two levels: BN_MERGE_SLICES slices written behind the partials (rows nparts .. nparts+slices), merged below
         const int pps = cris_cdiv(nparts, BN_MERGE_SLICES);
         const int slices = cris_cdiv(nparts, pps);
         float* osum = const_cast<float*>(psum) + (size_t)nparts * C;
         float* om2 = const_cast<float*>(pm2) + (size_t)nparts * C;
-        hipLaunchKernelGGL(bn_merge_kernel, dim3(cris_cdiv(C, 64), slices), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts,
+        hipLaunchKernelGGL(bn_merge_kernel, dim3(cris_cdiv(C, 16), slices), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts,
                            rows_per_part, (int)count_local, C, pps, osum, om2);
         CRIS_LAUNCH_CHECK();
         psum = osum;
@@ -150,9 +226,14 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
         nparts = slices;
         rows_per_part *= pps;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cris_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
-                       count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
-                       merged, global_stats);
+    if (!global_stats && nparts > BN_WIDE_MIN)
+        hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3(cris_cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
+                           count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
+                           merged, global_stats);
+    else
+        hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3(cris_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
+                           count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
+                           merged, global_stats);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

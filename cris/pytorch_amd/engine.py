@@ -94,6 +94,7 @@ class Engine:
         # inference_only (infer.InferEngine): no gradient arena (587 MB fp32 at R50) and no input-gradient weight packs -
         # a model that evaluates during training (engine/engine.py:90-123 `validate`) would otherwise hold both twice
         self.inference_only = inference_only
+        self.embed_live = None          # optional uint8 [vocabulary]: rows of the token embedding that ever had a gradient (trainer)
         self.P, self.Bf = params, buffers
         self.comm = comm or Comm()
         self.sync_bn = sync_bn and (self.comm.world > 1 or debug.HOOKS.force_dist)
@@ -666,7 +667,8 @@ class Engine:
         state = self.gemm(rows, "backbone.text_projection", self.clip.embed_dim, w_transposed=True)
         if self.training:
             def bwd_embed():
-                ops.embed_bwd(word, x0.g, self.G["backbone.token_embedding.weight"], self.G["backbone.positional_embedding"])
+                ops.embed_bwd(word, x0.g, self.G["backbone.token_embedding.weight"], self.G["backbone.positional_embedding"],
+                              row_live=self.embed_live)
             self.tape.insert(self._text_tape_start, bwd_embed)
         return xf, state
 

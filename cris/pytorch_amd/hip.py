@@ -155,7 +155,8 @@ class AdamDesc(C.Structure):
                 ("cin", I), ("cpad", I),
                 ("dstF", P), ("dstD", P),
                 ("N", I), ("npad", I),
-                ("transposed", I), ("pad2_", I)]
+                ("transposed", I), ("pad2_", I),
+                ("row_live", P), ("row_len", I), ("pad3_", I)]
 
 
 ZERO_RANGES_MAX = 16
@@ -256,7 +257,7 @@ _SIGS = {
     "cris_quickgelu_fwd": (I, [P, P, L, P]),
     "cris_quickgelu_bwd": (I, [P, P, P, L, P]),
     "cris_embed_fwd": (I, [P, P, P, I, I, I, P, P]),
-    "cris_embed_bwd": (I, [P, P, I, I, I, P, P, P]),
+    "cris_embed_bwd": (I, [P, P, I, I, I, P, P, P, P]),
     "cris_eot_gather": (I, [P, P, I, I, I, P, P, P]),
     "cris_eot_scatter_add": (I, [P, P, I, I, I, P, P]),
     "cris_posresize_fwd": (I, [P, P, I, I, I, P, P]),

@@ -78,6 +78,14 @@ class NativeTrainer:
         self.names = names
         self.group = {n: (0 if (n.startswith("backbone") and "positional_embedding" not in n) else 1) for n in names}
         self.base_lr, self.lr_multi, self.weight_decay = base_lr, lr_multi, weight_decay
+        # Rows of the token embedding (49408 x 512: 17% of the parameters) that have never received a gradient keep g = m = v = 0
+        # and Adam leaves them exactly as they are (while weight_decay == 0): the embedding backward marks the rows of each
+        # batch's tokens and the update skips the rest - bit-identical to the dense update.  One process only: with more
+        # ranks the all-reduced gradient has the other ranks' rows too, which this rank's marks do not cover.
+        # CRIS_ADAM_ROW_SKIP=0 switches it off.
+        if (self.comm.world == 1 and weight_decay == 0.0 and os.environ.get("CRIS_ADAM_ROW_SKIP", "1") == "1"
+                and torch.device(device).type == "cuda"):
+            e.embed_live = torch.zeros(e.P["backbone.token_embedding.weight"].shape[0], dtype=torch.uint8, device=device)
         self._build_adam([base_lr] * len(names))
         self.metric = torch.zeros(2, device=device)
         # per-step device state: steps done (int32) and the dropout seed of the running step
@@ -118,8 +126,9 @@ class NativeTrainer:
     def _build_adam(self, lrs):
         e, names = self.engine, self.names
         lr_of = dict(zip(names, lrs))
+        live = {names.index("backbone.token_embedding.weight"): e.embed_live} if e.embed_live is not None else None
         self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [lr_of[n] for n in names],
-                                  layouts=[e.gemm_layout(n) for n in names], packs=[e.pack_info.get(n) for n in names])
+                                  layouts=[e.gemm_layout(n) for n in names], packs=[e.pack_info.get(n) for n in names], row_live=live)
 
     @property
     def step_idx(self):
@@ -330,6 +339,8 @@ class NativeTrainer:
             self.adam.m[j].copy_(st["exp_avg"].to(self.device))
             self.adam.v[j].copy_(st["exp_avg_sq"].to(self.device))
             step = max(step, int(float(st["step"])))
+        for j, live in self.adam.row_live.items():       # rows with Adam state are live rows
+            live.copy_(((self.adam.m[j] != 0) | (self.adam.v[j] != 0)).any(dim=1))
         self.step_dev.fill_(step)
         self.adam.step_count = step
         self.set_group_lrs(sd["param_groups"][0]["lr"], sd["param_groups"][1]["lr"])

@@ -148,8 +148,9 @@ int cris_pack_block_elems(void);
  * epilogue or cris_colstats_bf16 and are merged with Chan's parallel-variance formula.
  * SyncBN: call once with `merged` (local sum / M2 / mean out), exchange (cris_bn_sync_pack + ONE all-reduce +
  * cris_bn_sync_unpack), then call again with `global_stats`.
- * Long partial lists are merged in two levels: psum / pm2 must have room for cris_bn_partials_rows(nparts) rows of C
- * floats each (the first-level result is written behind the nparts partial rows).
+ * Lists of up to 512 parts take one launch (16 or, for more than 128 parts, 64 merge lanes per channel); longer ones are first
+ * merged into 64 slices by a second launch: psum / pm2 must have room for cris_bn_partials_rows(nparts) rows of C floats each
+ * (the slices are written behind the nparts partial rows).  nparts must be ceil(count_local / rows_per_part).
  * ---------------------------------------------------------------------------------------------- */
 int cris_bn_partials_rows(int nparts);
 int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local, float count,
@@ -328,7 +329,9 @@ int cris_quickgelu_bwd(const cris_bf16* x, const cris_bf16* dy, cris_bf16* dx, l
 /* token embedding + positional embedding (model/clip.py:440-443) and its backward (embedding_dense_backward) */
 int cris_embed_fwd(const int64_t* tokens, const float* table, const float* pos, int Bn, int L, int D, float* out,
                    void* stream);
-int cris_embed_bwd(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos,
+/* row_live (optional, [vocabulary] bytes, sticky): set to 1 for every token of the batch - the rows of the table that have ever
+ * received a gradient (see cris_adam_desc.row_live) */
+int cris_embed_bwd(const int64_t* tokens, const float* dx, int Bn, int L, int D, float* dtable, float* dpos, unsigned char* row_live,
                    void* stream);
 /* rows x[b*L + argmax_l tokens[b,:]] -> bf16 (EOT feature select, model/clip.py:451-452; first max wins) */
 int cris_eot_gather(const int64_t* tokens, const cris_bf16* x, int Bn, int L, int D, cris_bf16* out, int* eot_index,
@@ -414,6 +417,12 @@ typedef struct {
     cris_bf16* dstF; cris_bf16* dstD;
     int N; int npad;                 /* packed tensors: rows, padded rows of the D layout (cin / cpad above) */
     int transposed; int pad2_;       /* packed: parameter stored [cin][N] (one tap) */
+    const unsigned char* row_live;   /* optional (plain tensors, weight_decay == 0): byte r != 0 <=> row r (row_len elements) has ever
+                                        had a non-zero gradient.  Rows that never had one are skipped: with g = m = v = 0 the
+                                        Adam update is the identity (p - step * 0 / (0 + eps) = p), so the result is bit-identical
+                                        to the dense update - the token embedding is 17% of CRIS-R50's parameters and a step
+                                        touches at most B*L of its 49408 rows. */
+    int row_len; int pad3_;
 } cris_adam_desc;
 int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
                    float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,

@@ -475,12 +475,15 @@ def test_bn_stats_robust_to_large_mean():
     check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), 1e-4, "invstd")
 
 
-def test_bn_finalize_two_level_merge():
-    """> 128 partials take the two-level (slice) merge path; result must equal the direct statistics."""
-    M, C_ = 40000, 72                                        # 1250 parts of 32 rows, ragged last slice
+@pytest.mark.parametrize("M,rows", [(40000, 32), (5000, 32), (86528, 128), (346112, 128), (3000, 32)])
+def test_bn_finalize_long_lists(M, rows):
+    """lists of 129 - 512 partials are merged by 64 lanes per channel inside the finalize launch (157 parts here), longer ones
+    (1250, 676, 2704 parts) through a first-level merge into 64 slices, ragged last slice included; 94 parts take the 16-lane
+    form.  The result must equal the direct statistics."""
+    C_ = 72
     y = (rnd(M, C_) * 2.0 + 3.0).to(BF).float()
-    st = ops.colstats(bf(y), M, C_, 32, DEV)
-    assert st.nparts > 512 and st.t.shape[1] == st.nparts + 64
+    st = ops.colstats(bf(y), M, C_, rows, DEV)
+    assert st.nparts == (M + rows - 1) // rows and st.t.shape[1] == st.nparts + (64 if st.nparts > 512 else 0)
     outs = [torch.empty(C_, device=DEV) for _ in range(4)]
     ops.bn_finalize(st, M, M, torch.ones(C_, device=DEV), torch.zeros(C_, device=DEV), None, None, 0.1, 1e-5, C_, *outs)
     check(outs[2], y.double().mean(0), 1e-6, "mean")
@@ -808,7 +811,10 @@ def test_embedding_and_eot():
     dx = rnd(B * L, D, seed=2)
     dt = torch.zeros(V, D, device=DEV)
     dp = torch.zeros(77, D, device=DEV)
-    ops.embed_bwd(toks.to(DEV), dx.to(DEV), dt, dp)
+    live = torch.zeros(V, dtype=torch.uint8, device=DEV)
+    live[17] = 1                                         # sticky: marks of earlier batches stay
+    ops.embed_bwd(toks.to(DEV), dx.to(DEV), dt, dp, row_live=live)
+    assert sorted(live.nonzero().flatten().tolist()) == sorted(set(toks.flatten().tolist()) | {17})
     rt = torch.zeros(V, D).index_add_(0, toks.flatten(), dx)
     check(dt, rt, 1e-6)
     check(dp[:L], dx.view(B, L, D).sum(0), 1e-6)
@@ -939,6 +945,35 @@ def test_adam_matches_torch():
         tab.step()
     for dp, rp in zip(dev_p, ref_p):
         check(dp, rp.data, 1e-6, "adam")
+
+
+def test_adam_row_skip_is_bit_identical_to_dense():
+    """row_live: rows of an embedding table that never had a gradient are skipped; parameters and both moments stay bit-identical
+    to the dense update over steps in which new rows become live, and a non-zero weight decay switches the skipping off"""
+    V, D = 3000, 48                                      # 144000 elements: 18 blocks of 8192, rows straddle block edges
+    table = rnd(V, D)
+    other = rnd(777, seed=1)
+    for wd in (0.0, 0.01):
+        runs = []
+        for use_live in (False, True):
+            p = [table.clone().to(DEV), other.clone().to(DEV)]
+            g = [torch.zeros(V, D, device=DEV), torch.zeros(777, device=DEV)]
+            live = torch.zeros(V, dtype=torch.uint8, device=DEV)
+            tab = ops.AdamTable(p, g, [1e-3, 1e-3], row_live={0: live} if use_live else None)
+            for step in range(4):
+                rows = torch.tensor([3, 170, 171, 2999, 5 + 11 * step], device=DEV)
+                g[0].zero_()
+                g[0][rows] = rnd(5, D, seed=10 + step).to(DEV)
+                g[1].copy_(rnd(777, seed=20 + step))
+                live[rows] = 1
+                tab.step(weight_decay=wd)
+            runs.append((p[0].clone(), tab.m[0].clone(), tab.v[0].clone(), p[1].clone()))
+        for a, b in zip(*runs):
+            assert torch.equal(a, b), "wd=%g" % wd
+        untouched = torch.ones(V, dtype=torch.bool)
+        untouched[[3, 170, 171, 2999, 5, 16, 27, 38]] = False
+        if wd == 0.0:
+            assert torch.equal(runs[1][0].cpu()[untouched], table[untouched])      # (and the dense update leaves them alone too)
 
 
 def test_adam_gemm_layout_gradient_and_device_step():
