@@ -823,7 +823,9 @@ extern "C" int cris_train_metric(const float* logits, const float* target, int B
 #ifndef ADAM_ELEMS
 #define ADAM_ELEMS 8192
 #endif
-#define AP_T 64                                   // packed tensors: a block owns 64 output rows x 64 input channels x all taps
+#define AP_T 64                                   // packed tensors: a block owns AP_TN output rows x 64 input channels x all taps
+#define AP_TN(PT) ((PT) == 9 ? 32 : 64)           // 9 taps: 32 rows (37 KB of LDS, four blocks per CU; 64 rows = 74 KB, two blocks, ran
+                                                  // the table at 3.4 TB/s against 5.7 for the 1-tap one)
 #define AP_LROW(PT) (AP_T * (PT) + 2)             // bf16 elements per LDS tile row (+1 dword: conflict-free column reads)
 
 struct adam_coef {
@@ -846,10 +848,13 @@ __device__ __forceinline__ void adam_pack_tile(const cris_adam_desc& d, int lb, 
     constexpr int LROW = AP_LROW(PT);
     const int tiles_c = (d.cin + AP_T - 1) / AP_T;
     const int tn = lb / tiles_c, tc = lb - tn * tiles_c;
-    const int n0 = tn * AP_T, c0 = tc * AP_T;
-    const int rows = min(AP_T, d.N - n0), cw = min(AP_T, d.cin - c0);
+    constexpr int TN = AP_TN(PT);
+    const int n0 = tn * TN, c0 = tc * AP_T;
+    const int rows = min(TN, d.N - n0), cw = min(AP_T, d.cin - c0);
     if (!d.transposed) {
-        // parameter layout [n][c][tap]: for one n the tile's (c, tap) range is contiguous
+        // parameter layout [n][c][tap]: for one n the tile's (c, tap) range is contiguous.  (Eight elements per thread with all
+        // 32 loads requested ahead of the first update - more bytes in flight for the two 74-KB-LDS blocks a CU holds - ran the
+        // 9-tap table 25% slower, 0.41 against 0.33 ms: call r03u.)
         for (int i = threadIdx.x; i < rows * AP_T * PT; i += 256) {
             const int n_l = i / (AP_T * PT), e = i - n_l * (AP_T * PT);
             const int c_l = e / PT, tap = e - c_l * PT;
@@ -883,8 +888,8 @@ __device__ __forceinline__ void adam_pack_tile(const cris_adam_desc& d, int lb, 
         }
     }
     if (d.dstD) {                                  // D[(c*PT + PT-1-tap)*Npad + n]: consecutive threads = consecutive rows n
-        for (int i = threadIdx.x; i < cw * PT * AP_T; i += 256) {
-            const int n_l = i & (AP_T - 1), r = i >> 6;
+        for (int i = threadIdx.x; i < cw * PT * TN; i += 256) {
+            const int n_l = i & (TN - 1), r = i / TN;
             const int c_l = r / PT, tapf = r - c_l * PT;
             if (n_l < rows) d.dstD[((long)(c0 + c_l) * PT + tapf) * d.npad + n0 + n_l] = tile[n_l * LROW + c_l * PT + (PT - 1 - tapf)];
         }
@@ -940,7 +945,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restr
 }
 // blocks a descriptor needs (host): tiles for tensors whose bf16 packs are refreshed by the update, else 8192-element chunks
 extern "C" int cris_adam_blocks(const cris_adam_desc* d) {
-    if (d->dstF || d->dstD) return cris_cdiv(d->N, AP_T) * cris_cdiv(d->cin, AP_T);
+    if (d->dstF || d->dstD) return cris_cdiv(d->N, d->taps == 9 ? AP_TN(9) : AP_TN(1)) * cris_cdiv(d->cin, AP_T);
     return cris_cdiv(d->n, ADAM_ELEMS);
 }
 extern "C" int cris_adam_block_elems(void) { return ADAM_ELEMS; }
@@ -983,7 +988,7 @@ extern "C" int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int t
     CRIS_CHECK_ARG(pack_taps == 1 || pack_taps == 9, "a table holds tensors packed with 1 tap (and unpacked ones) or with 9 taps");
     typedef void (*adam_fn)(const cris_adam_desc*, int, float, float, float, float, float, float, float, const int*);
     const adam_fn k9 = adam_kernel<9>, k1 = adam_kernel<1>;
-    constexpr int LDS9 = AP_T * AP_LROW(9) * 2, LDS1 = AP_T * AP_LROW(1) * 2;
+    constexpr int LDS9 = AP_TN(9) * AP_LROW(9) * 2, LDS1 = AP_TN(1) * AP_LROW(1) * 2;
     static const int ready = (int)hipFuncSetAttribute((const void*)k9, hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
     if (ready != 0) {
         cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, ready);

@@ -485,6 +485,9 @@ static int pick_variant(const cris_conv_gemm_params& p) {
     static const int skinny_split = cris_env_int("CRIS_SKINNY_SPLIT", 1);
     if (lin && p.M <= SKINNY_MAX_M) {
         if (!skinny_split) return V_SKINNY9;
+        // (an eight-deep ring for these few-block launches - every operand byte of a K <= 512 problem requested in the
+        // prologue - changed nothing: 9.0 against 8.3 us standalone, 12.50 against 12.50 ms per step, call r03v: the launches
+        // sit on the ~4-5 us floor of any dependent kernel plus the general epilogue, not on operand latency)
         return p.K >= 1024 ? V_SKINNY9S : V_64x64;
     }
     // (Measured and removed, calls r03h / r03i: a persistent streaming kernel for the K <= 256 1x1 convolutions of the large

@@ -737,7 +737,7 @@ class AdamTable:
                 if pk is not None:
                     dstF, dstD, N, Cin, ptaps, Cpad, Npad, transposed = pk
                     assert ptaps in (1, 9), "packed weights have 1 or 9 taps"
-                    assert d.taps in (0, ptaps)
+                    assert d.taps == ptaps or (d.taps == 0 and ptaps == 1), "a 9-tap packed weight takes its gradient in the GEMM layout"
                     d.dstF, d.dstD = ptr(dstF), ptr(dstD)
                     d.N, d.cin, d.cpad, d.npad, d.transposed = N, Cin, Cpad, Npad, int(transposed)
                 if row_live is not None and i in row_live:

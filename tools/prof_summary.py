@@ -18,6 +18,19 @@ def main(db_path, out_path, steps=None, marker=None):
         if len(marks) <= steps:
             raise SystemExit("only %d launches of %r in the trace, need more than %d" % (len(marks), marker, steps))
         where = "where start > %d and start <= %d" % (marks[-steps - 1][0], marks[-1][0])
+    # how much of the window has at least one kernel running (union of the intervals), and how much none
+    iv = c.execute("select start, end from kernels %s order by start" % where).fetchall()
+    busy, cur_s, cur_e = 0, None, None
+    for s_, e_ in iv:
+        if cur_e is None or s_ > cur_e:
+            if cur_e is not None:
+                busy += cur_e - cur_s
+            cur_s, cur_e = s_, e_
+        else:
+            cur_e = max(cur_e, e_)
+    if cur_e is not None:
+        busy += cur_e - cur_s
+    span = (iv[-1][1] - iv[0][0]) if iv else 0
     rows = c.execute("select name, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) from kernels %s "
                      "group by name order by 3 desc" % where).fetchall()
     tot = sum(r[2] for r in rows)
@@ -29,6 +42,9 @@ def main(db_path, out_path, steps=None, marker=None):
     print("kernels %d, launches %d%s, total kernel time %.2f ms%s" % (
         len(rows), sum(r[1] for r in rows), (" (%.1f per step)" % (sum(r[1] for r in rows) / steps)) if steps else "", tot / 1e6,
         (", %.3f ms/step" % (tot / 1e6 / steps)) if steps else ""))
+    if steps and span:
+        print("window %.3f ms/step: some kernel running %.3f ms/step, none %.3f ms/step (launch gaps), overlapped (two or more) %.3f ms/step"
+              % (span / 1e6 / steps, busy / 1e6 / steps, (span - busy) / 1e6 / steps, (tot - busy) / 1e6 / steps))
 
 
 if __name__ == "__main__":
