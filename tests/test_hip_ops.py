@@ -525,9 +525,12 @@ def test_bn_finalize_and_running_stats():
     check(rv, 0.9 * 2 + 0.1 * y2.var(0, unbiased=True), 1e-4)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 8, 48), (3, 10, 10, 64), (4, 100, 100, 64), (2, 6, 6, 2048)])
 @pytest.mark.parametrize("variant", ["plain", "pool", "ident", "two", "mul"])
-def test_bn_apply_and_backward(variant):
-    B, H, W, C_ = 2, 8, 8, 48
+def test_bn_apply_and_backward(variant, shape):
+    """C = 48: the generic kernels (C/8 not a power of two); C = 64 / 2048: the fast apply kernels (one channel vector per thread) -
+    one row per thread at M = 300 / 72, several passes with a ragged last one at M = 40000; pool / mul always take the generic ones"""
+    B, H, W, C_ = shape
     y, gamma, beta = _bn_setup(B, H, W, C_)
     y2d = y.reshape(-1, C_)
     M = y2d.shape[0]
