@@ -162,6 +162,12 @@ static int attn_check(const cris_attn_params& p) {
 __global__ void attn_fwd_lds_kernel(const cris_attn_params p);
 __global__ void attn_bwd_dq_lds_kernel(const cris_attn_params p);
 __global__ void attn_bwd_dkv_lds_kernel(const cris_attn_params p);
+#ifndef AL_WAVES
+#define AL_WAVES 4                         // waves per block
+#endif
+#ifndef AL_G
+#define AL_G 1                             // 16-row groups per wave: a block covers 16 * AL_G * AL_WAVES = 64 rows
+#endif
 #define AL_LDS_FWD (3 * 2 * 8192)
 #define AL_LDS_DQ (2 * 3 * 8192)
 #define AL_LDS_DKV (2 * (4 * 8192 + 512))
@@ -177,9 +183,9 @@ static int attn_launch_lds(int which, const cris_attn_params& p, dim3 grid, void
         cris_set_error("cris_attn: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", ready);
         return ready;
     }
-    if (which == 0) hipLaunchKernelGGL(attn_fwd_lds_kernel, grid, dim3(128), AL_LDS_FWD, (hipStream_t)stream, p);
-    else if (which == 1) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, grid, dim3(128), AL_LDS_DQ, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, grid, dim3(128), AL_LDS_DKV, (hipStream_t)stream, p);
+    if (which == 0) hipLaunchKernelGGL(attn_fwd_lds_kernel, grid, dim3(64 * AL_WAVES), AL_LDS_FWD, (hipStream_t)stream, p);
+    else if (which == 1) hipLaunchKernelGGL(attn_bwd_dq_lds_kernel, grid, dim3(64 * AL_WAVES), AL_LDS_DQ, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_bwd_dkv_lds_kernel, grid, dim3(64 * AL_WAVES), AL_LDS_DKV, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return 0;
 }
@@ -429,8 +435,10 @@ extern "C" int cris_attn_bwd_dkv(const cris_attn_params* pp, void* stream) {
 // launch and one L2 round trip per 32-key step.  Here a block of AL_WAVES waves shares 64-row operand tiles through LDS:
 // [64][64] bf16 tiles (128-B rows, 16-B chunk index XOR (row & 7): conflict-free 16-B / 8-B fragment reads) staged by
 // LDS-DMA (buffer_load_dwordx4 ... lds, swizzle applied on the source side, rows beyond the sequence = out-of-range offsets
-// = zeros) through a ring with counted vmcnt + one raw barrier per 64-row step, and every wave works on TWO 16-row groups
-// (32 queries / keys) so that each fragment read from LDS feeds two MFMA chains.  The arithmetic (S^T formulation, slot
+// = zeros) through a ring with counted vmcnt + one raw barrier per 64-row step.  A wave works on AL_G 16-row groups: round 2
+// ran 2 waves x TWO groups (each fragment read from LDS feeds two MFMA chains), round 3 runs 4 waves x ONE group - the grid is only
+// (L/64) x batch*heads = 704 blocks, so two waves per block left 1.4 waves per SIMD and every MFMA -> softmax -> MFMA dependency
+// exposed; 2.75 waves per SIMD: forward 51 -> 39 us, dq 54 -> 44, dkv 67 -> 44 (call r03ab; LDS reads are not the limit).  The arithmetic (S^T formulation, slot
 // permutation of the PV product, online softmax, dropout hash, masks of rows beyond the sequence) is exactly that of the
 // kernels above; no causal mask, key-padding mask on the key-side backward only (the cross attention's 676-query loop).  One difference in bookkeeping: the rows of the two
 // 16-row MFMA blocks of a 32-row half step are interleaved (block kb takes rows (m>>2)*8 + kb*4 + (m&3)), so that the 8
@@ -438,7 +446,6 @@ extern "C" int cris_attn_bwd_dkv(const cris_attn_params* pp, void* stream) {
 // 16-byte ds_read_b128 (hipcc puts an s_waitcnt vmcnt(0) - a full drain of the DMA ring - in front of merged 8-byte LDS
 // reads that follow an LDS-DMA, but not in front of ds_read_b128).
 // ================================================================================================
-#define AL_WAVES 2
 #define AL_TILE 8192                       // bytes of one [64][64] bf16 tile
 #define AL_NI (8 / AL_WAVES)               // 1-KB DMA instructions per wave per tile
 
@@ -485,14 +492,14 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_fwd_lds_kernel(const cris_
     int bx, bh;
     al_block(bx, bh);
     const int b = bh / p.Hn, h = bh - b * p.Hn;
-    const int q0w = bx * (32 * AL_WAVES) + wave * 32;
+    const int q0w = bx * (16 * AL_G * AL_WAVES) + wave * (16 * AL_G);
 
     int q[2];
     bool qok[2];
     bf16x8 bq[2][2];
     uint32_t didx0[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < AL_G; ++g) {
         q[g] = q0w + g * 16 + fr;
         qok[g] = q[g] < p.Lq;
         const bf16_t* Qp = p.Q + (size_t)(b * p.Lq + min(q[g], p.Lq - 1)) * p.ldq + h * 64 + fg * 8;   // clamped: masked by !qok
@@ -516,11 +523,15 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_fwd_lds_kernel(const cris_
     const bool has_drop = p.drop_thresh > 0u;
     const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const float inv_keep = has_drop ? 1.f / (1.f - p.drop_p) : 1.f;
+    // pre-mixed hash word of (query row, key fg*8) per group; key k0 + j adds (k0 + j) * CRIS_DROP_MUL (see cris_keep_h)
+    uint32_t dh0[2];
+#pragma unroll
+    for (int g = 0; g < AL_G; ++g) dh0[g] = (didx0[g] + (uint32_t)(fg * 8)) * CRIS_DROP_MUL + dkey;
 
     f32x4 o[2][4];
     float m_run[2], l_run[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < AL_G; ++g) {
         m_run[g] = NEG_INF;
         l_run[g] = 0.f;
 #pragma unroll
@@ -545,6 +556,8 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_fwd_lds_kernel(const cris_
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int k0 = kt * 64 + half * 32;
+            const bool tail = k0 + 32 > p.Lk;
+            const uint32_t k0m = (uint32_t)k0 * CRIS_DROP_MUL;
             bf16x8 av[4], ak[2][2];
 #pragma unroll
             for (int db = 0; db < 4; ++db) av[db] = al_ld16(tV, db * 16 + fr, half * 4 + fg);
@@ -555,17 +568,22 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_fwd_lds_kernel(const cris_
                 ak[kb][1] = al_ld16(tK, row, fg + 4);
             }
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < AL_G; ++g) {
                 float s[8];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     f32x4 st = (f32x4){0.f, 0.f, 0.f, 0.f};
                     st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[kb][0], bq[g][0], st, 0, 0, 0);
                     st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[kb][1], bq[g][1], st, 0, 0, 0);
+                    if (tail) {                                   // (uniform) only the last key tile has keys beyond Lk
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int kk = k0 + fg * 8 + kb * 4 + r;
-                        s[kb * 4 + r] = kk >= p.Lk ? NEG_INF : st[r] * p.scale;
+                        for (int r = 0; r < 4; ++r) {
+                            const int kk = k0 + fg * 8 + kb * 4 + r;
+                            s[kb * 4 + r] = kk >= p.Lk ? NEG_INF : st[r] * p.scale;
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[kb * 4 + r] = st[r] * p.scale;
                     }
                 }
                 float mx = s[0];
@@ -589,16 +607,17 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_fwd_lds_kernel(const cris_
                 rs = grp_sum(rs);
                 l_run[g] = l_run[g] * alpha + rs;
                 m_run[g] = m_new;
+                if (__builtin_amdgcn_ballot_w64(alpha != 1.f)) {      // (uniform) the running maximum of some row moved: rescale
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[g][i][r] *= alpha;
+                        for (int r = 0; r < 4; ++r) o[g][i][r] *= alpha;
+                }
                 if (has_drop) {
+                    const uint32_t hb = dh0[g] + k0m;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int kk = k0 + fg * 8 + j;
-                        pv[j] = cris_keep(dkey, didx0[g] + (uint32_t)kk, p.drop_thresh) ? pv[j] * inv_keep : 0.f;
-                    }
+                    for (int j = 0; j < 8; ++j)
+                        pv[j] = cris_keep_h(hb + (uint32_t)j * CRIS_DROP_MUL, p.drop_thresh) ? pv[j] * inv_keep : 0.f;
                 }
                 const bf16x8 bp = pack_frag(pv);
 #pragma unroll
@@ -611,7 +630,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_fwd_lds_kernel(const cris_
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < AL_G; ++g) {
         const float inv_l = l_run[g] > 0.f ? 1.f / l_run[g] : 0.f;
         if (qok[g]) {
             bf16_t* op = p.O + (size_t)(b * p.Lq + q[g]) * p.ldo + h * 64 + fg * 4;
@@ -636,7 +655,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
     int bx, bh;
     al_block(bx, bh);
     const int b = bh / p.Hn, h = bh - b * p.Hn;
-    const int q0w = bx * (32 * AL_WAVES) + wave * 32;
+    const int q0w = bx * (16 * AL_G * AL_WAVES) + wave * (16 * AL_G);
 
     int q[2];
     bool qok[2];
@@ -644,7 +663,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
     float delta[2], lse[2];
     uint32_t didx0[2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < AL_G; ++g) {
         q[g] = q0w + g * 16 + fr;
         qok[g] = q[g] < p.Lq;
         const int qcl = min(q[g], p.Lq - 1);                   // rows beyond Lq read the last row; they are masked (!qok)
@@ -668,7 +687,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
         dl = grp_sum(dl);
         delta[g] = dl;
         if (qok[g] && fg == 0) p.delta[(size_t)bh * p.Lq + q[g]] = dl;
-        lse[g] = p.lse[(size_t)bh * p.Lq + qcl];
+        lse[g] = qok[g] ? p.lse[(size_t)bh * p.Lq + qcl] : __builtin_inff();      // rows beyond Lq: exp(s - inf) = 0, no test per element
         didx0[g] = ((uint32_t)bh * (uint32_t)p.Lq + (uint32_t)q[g]) * (uint32_t)p.Lk;
     }
     const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.K), 0, (int)((size_t)p.B * p.Lk * p.ldk * 2),
@@ -691,9 +710,12 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
     const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const float inv_keep = has_drop ? 1.f / (1.f - p.drop_p) : 1.f;
 
+    uint32_t dh0[2];                              // pre-mixed hash words, as in the forward kernel
+#pragma unroll
+    for (int g = 0; g < AL_G; ++g) dh0[g] = (didx0[g] + (uint32_t)(fg * 8)) * CRIS_DROP_MUL + dkey;
     f32x4 dq[2][4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < AL_G; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dq[g][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -716,6 +738,8 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int k0 = kt * 64 + half * 32;
+            const bool tail = k0 + 32 > p.Lk;
+            const uint32_t k0m = (uint32_t)k0 * CRIS_DROP_MUL;
             bf16x8 akt[4], ak[2][2], avv[2][2];
 #pragma unroll
             for (int db = 0; db < 4; ++db) akt[db] = al_ld16(tKt, db * 16 + fr, half * 4 + fg);
@@ -728,7 +752,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
                 avv[kb][1] = al_ld16(tV, row, fg + 4);
             }
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < AL_G; ++g) {
                 float ds[8];
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
@@ -737,13 +761,13 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
                     st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak[kb][1], bq[g][1], st, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avv[kb][0], bd[g][0], dp, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(avv[kb][1], bd[g][1], dp, 0, 0, 0);
+                    const uint32_t hb = dh0[g] + k0m + (uint32_t)(kb * 4) * CRIS_DROP_MUL;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int kk = k0 + fg * 8 + kb * 4 + r;
-                        const bool masked = kk >= p.Lk || !qok[g];
-                        const float pr = masked ? 0.f : __expf(st[r] * p.scale - lse[g]);
+                        float pr = __expf(st[r] * p.scale - lse[g]);
+                        if (tail) pr = (k0 + fg * 8 + kb * 4 + r) >= p.Lk ? 0.f : pr;      // (uniform) last key tile only
                         float dpv = dp[r];
-                        if (has_drop) dpv = cris_keep(dkey, didx0[g] + (uint32_t)kk, p.drop_thresh) ? dpv * inv_keep : 0.f;
+                        if (has_drop) dpv = cris_keep_h(hb + (uint32_t)r * CRIS_DROP_MUL, p.drop_thresh) ? dpv * inv_keep : 0.f;
                         ds[kb * 4 + r] = pr * (dpv - delta[g]);
                     }
                 }
@@ -757,7 +781,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dq_lds_kernel(const cr
     }
     CRIS_VMCNT(0);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < AL_G; ++g) {
         if (qok[g]) {
             bf16_t* op = p.dQ + (size_t)(b * p.Lq + q[g]) * p.lddq + h * 64 + fg * 4;
 #pragma unroll
@@ -780,13 +804,13 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
     int bx, bh;
     al_block(bx, bh);
     const int b = bh / p.Hn, h = bh - b * p.Hn;
-    const int k0w = bx * (32 * AL_WAVES) + wave * 32;
+    const int k0w = bx * (16 * AL_G * AL_WAVES) + wave * (16 * AL_G);
 
     int key[2];
     bool kok[2], kpad[2];
     bf16x8 bk[2][2], bv[2][2];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < AL_G; ++g) {
         key[g] = k0w + g * 16 + fr;
         kok[g] = key[g] < p.Lk;
         const int keyc = min(key[g], p.Lk - 1);                // keys beyond Lk read the last key; nothing is stored for them
@@ -826,9 +850,19 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
     const uint32_t dkey = cris_drop_key(p.drop_seed + (p.drop_seed_dev ? p.drop_seed_dev[0] : 0u), p.drop_stream);
     const float inv_keep = has_drop ? 1.f / (1.f - p.drop_p) : 1.f;
 
+    // dropout index of (query qq, key) = (bh*Lq + qq)*Lk + key with qq = q0 + fg*8 + j: the pre-mixed word of (fg*8, key) per
+    // group; q0 + j adds (q0 + j) * (Lk * CRIS_DROP_MUL), a scalar
+    const uint32_t LkM = (uint32_t)p.Lk * CRIS_DROP_MUL;
+    uint32_t dh0[2];
+    bool kvalid[2];
+#pragma unroll
+    for (int g = 0; g < AL_G; ++g) {
+        dh0[g] = (((uint32_t)bh * (uint32_t)p.Lq + (uint32_t)(fg * 8)) * (uint32_t)p.Lk + (uint32_t)key[g]) * CRIS_DROP_MUL + dkey;
+        kvalid[g] = kok[g] && !kpad[g];
+    }
     f32x4 dk[2][4], dv[2][4];
 #pragma unroll
-    for (int g = 0; g < 2; ++g)
+    for (int g = 0; g < AL_G; ++g)
 #pragma unroll
         for (int i = 0; i < 4; ++i) dk[g][i] = dv[g][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -854,6 +888,8 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             const int q0 = qt * 64 + half * 32;
+            const bool tail = q0 + 32 > p.Lq;
+            const uint32_t q0m = (uint32_t)q0 * LkM;
             bf16x8 ado[4], aqt[4], aq[2][2], ad[2][2];
 #pragma unroll
             for (int db = 0; db < 4; ++db) {
@@ -876,7 +912,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
                 dl[j] = s_del[lq_i];
             }
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < AL_G; ++g) {
                 float pd[8], ds[8];
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
@@ -885,22 +921,23 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
                     sv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[qb][1], bk[g][1], sv, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[qb][0], bv[g][0], dp, 0, 0, 0);
                     dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad[qb][1], bv[g][1], dp, 0, 0, 0);
+                    const uint32_t hb = dh0[g] + q0m + (uint32_t)(qb * 4) * LkM;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int qq = q0 + fg * 8 + qb * 4 + r;      // C/D row of this lane = query (interleaved blocks)
-                        const bool ok = qq < p.Lq && kok[g] && !kpad[g];
-                        const float pr = ok ? __expf(sv[r] * p.scale - lq[qb * 4 + r]) : 0.f;
-                        const float dlt = ok ? dl[qb * 4 + r] : 0.f;
+                        // C/D row of this lane = query qq = q0 + fg*8 + qb*4 + r (interleaved blocks).  pr = 0 for keys that are
+                        // beyond Lk or padded (per lane) and, in the last query tile only (uniform), for rows beyond Lq; with pr = 0
+                        // the products below are 0 whatever delta is (it is finite), so delta needs no select of its own
+                        float pr = kvalid[g] ? __expf(sv[r] * p.scale - lq[qb * 4 + r]) : 0.f;
+                        if (tail) pr = (q0 + fg * 8 + qb * 4 + r) < p.Lq ? pr : 0.f;
                         float dpv = dp[r];
                         float prd = pr;
                         if (has_drop) {
-                            const bool keep = cris_keep(dkey, ((uint32_t)bh * (uint32_t)p.Lq + (uint32_t)qq) * (uint32_t)p.Lk + (uint32_t)key[g],
-                                                        p.drop_thresh);
+                            const bool keep = cris_keep_h(hb + (uint32_t)r * LkM, p.drop_thresh);
                             prd = keep ? pr * inv_keep : 0.f;
                             dpv = keep ? dpv * inv_keep : 0.f;
                         }
                         pd[qb * 4 + r] = prd;
-                        ds[qb * 4 + r] = pr * (dpv - dlt);
+                        ds[qb * 4 + r] = pr * (dpv - dl[qb * 4 + r]);
                     }
                 }
                 const bf16x8 bp = pack_frag(pd), bds = pack_frag(ds);
@@ -916,7 +953,7 @@ __global__ __launch_bounds__(64 * AL_WAVES) void attn_bwd_dkv_lds_kernel(const c
     }
     CRIS_VMCNT(0);
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
+    for (int g = 0; g < AL_G; ++g) {
         if (kok[g]) {
             bf16_t* kp = p.dK + (size_t)(b * p.Lk + key[g]) * p.lddk + h * 64 + fg * 4;
             bf16_t* vp = p.dV + (size_t)(b * p.Lk + key[g]) * p.lddv + h * 64 + fg * 4;

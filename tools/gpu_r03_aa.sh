@@ -1,0 +1,15 @@
+#!/bin/bash
+# round 3, call AA: LDS attention VALU diet (hoisted hash multiply, masks in the last tile only, rescale only when a maximum moved)
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out; L=gpurun_out/r03aa
+F="Warning\|warn\|return float\|Consider using\|amdgpu.ids\|Gloo\|c10d"
+python -c "import __graft_entry__ as g; g.build()" || exit 1
+timeout 900 python -m pytest tests/test_hip_ops.py -m gpu -q -x -k "attention or attn" 2>&1 | grep -v "$F" | tail -5 | cut -c1-400 > $L.kernel_tests.log
+echo "=== kernel tests"; cat $L.kernel_tests.log
+timeout 900 python -m pytest tests/test_engine_gpu.py -m gpu -q -x -k "not 100_steps" 2>&1 | grep -v "$F" | tail -4 | cut -c1-400 > $L.engine_tests.log
+echo "=== engine tests"; cat $L.engine_tests.log
+timeout 200 python bench.py --steps 200 --warmup 10 --no-cpu-baseline --no-kernel-timer 2>/dev/null | cut -c1-260
+rm -rf gpurun_out/prof
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o r03aa -- python bench.py --steps 40 --warmup 3 --no-cpu-baseline --no-kernel-timer > $L.prof.log 2>&1
+python tools/prof_summary.py $(ls gpurun_out/prof/*/r03aa_results.db gpurun_out/prof/r03aa_results.db 2>/dev/null | head -1) $L.kernel_stats.csv 40 "void adam_kernel<1>" 2>&1 | tail -3
+rm -rf gpurun_out/prof
+grep "attn_\|conv_gemm8_kernel<2, 2, 1>" $L.kernel_stats.csv | awk -F, '{print $NF, $(NF-1), $(NF-5), substr($1,1,50)}' | head
