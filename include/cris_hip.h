@@ -145,7 +145,8 @@ int cris_pack_block_elems(void);
  * BatchNorm (training statistics), replaces native_batch_norm / its backward
  * (reference: every nn.BatchNorm2d/1d, model/clip.py:18-41,78,173-183; model/layers.py:11,16,262).
  * Statistics arrive as per-row-block partials (column sum, M2 about the block mean) from the conv GEMM
- * epilogue or cris_colstats_bf16 and are merged with Chan's parallel-variance formula.
+ * epilogue or cris_colstats_bf16 and are merged exactly: mean = sum_i S_i / n, M2 = sum_i [M2_i + n_i (S_i / n_i - mean)^2] (the
+ * decomposition of the sum of squares about the common mean; two passes over the list, no E[x^2] - mean^2 cancellation).
  * SyncBN: call once with `merged` (local sum / M2 / mean out), exchange (cris_bn_sync_pack + ONE all-reduce +
  * cris_bn_sync_unpack), then call again with `global_stats`.
  * Lists of up to 512 parts take one launch (16 or, for more than 128 parts, 64 merge lanes per channel); longer ones are first
