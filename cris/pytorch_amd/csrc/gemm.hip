@@ -38,8 +38,12 @@
 // descriptors over the activation / weight extents: zero fill (spatial padding, M / N / K tails) = an out-of-range byte
 // offset, which the hardware returns as 0 - a branch-free per-lane select, so every wave issues exactly NA + NB DMAs per
 // K-step and the counted vmcnt below is exact.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, int MT_ = 32>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_params p) {
+// KS = 2 (intra-block split-K): a second group of four waves runs the same loop over the ODD K-steps in its own LDS ring (the
+// first group takes the even ones), so a block holds two independent MFMA / LDS dependency chains per SIMD instead of one; the
+// second group's accumulators are added to the first's through LDS at the end (fixed order: even steps + odd steps) and the
+// first group runs the epilogue.  For the mid-size problems whose grids put barely one block on a CU.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, int MT_ = 32, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const cris_conv_gemm_params p) {
     constexpr int WTM = BM / WAVES_M;          // wave tile rows
     constexpr int WTN = BN / WAVES_N;
     // v_mfma_f32_32x32x16_bf16: one 16-B A chunk + one 16-B B chunk per lane feed 32x32x16 MACs - half the LDS read
@@ -58,7 +62,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
 
     const int t = threadIdx.x;
     const int lane = t & 63;
-    const int wave = t >> 6;
+    const int wave = (t >> 6) & 3;             // role inside the group of four (DMA rows, wave tile)
+    const int grp = KS > 1 ? (t >> 8) : 0;     // K-split group: K-steps grp, grp + KS, ...
+    unsigned char* const ring = smem + grp * (STAGES * STAGE_BYTES);
     const int wm = wave / WAVES_N;
     const int wn = wave % WAVES_N;
 
@@ -115,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(p.Wt), 0, (int)((size_t)p.N * p.ldb * 2), CRIS_BUF_FLAGS);
     // running (tap, c) of this lane's chunk
-    int kcur = kc * 8;
+    int kcur = kc * 8 + grp * BK;
     int c_cur = kcur % p.C;
     int tap = kcur / p.C;
     int kh = tap / p.KW;
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
 
     // general K-step issue: the 8-channel chunk of a lane may sit in any tap (C not a multiple of 64)
     auto issue_gen = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE_BYTES + wave * 1024;          // wave-uniform LDS base of DMA j: + j*4096
+        unsigned char* sa = ring + buf * STAGE_BYTES + wave * 1024;          // wave-uniform LDS base of DMA j: + j*4096
         unsigned char* sb = sa + A_BYTES;
         const bool kvalid = kcur < p.K;
 #pragma unroll
@@ -138,9 +144,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
             const unsigned off = b_off[i] + (unsigned)kcur * 2u;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + i * 4096), 16, kvalid ? off : CRIS_OOB, 0, 0, 0);
         }
-        // advance to the next K step
-        kcur += BK;
-        c_cur += BK;
+        // advance to this group's next K step
+        kcur += BK * KS;
+        c_cur += BK * KS;
         while (c_cur >= p.C) {
             c_cur -= p.C;
             if (++kw == p.KW) { kw = 0; ++kh; }
@@ -150,13 +156,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     // ONE tap, so the tap is wave-uniform; the per-row pixel offsets / padding validity are recomputed only when the tap
     // changes (every C/64 steps) and a K-step costs one v_add + v_or per DMA instead of ~20 VALU instructions - the main
     // loop of these kernels is otherwise bound by address arithmetic, not by MFMA or memory.
-    int f_kh = 0, f_kw = 0, f_c = 0, f_k = 0;                               // wave-uniform
+    int f_kh = 0, f_kw = 0, f_c = 0, f_k = grp * BK;                        // wave-uniform
+    bool f_newtap = true;
+    if (KS > 1) {                                                           // this group's first step may lie in a later tap
+        f_c = f_k;
+        while (f_c >= p.C) {
+            f_c -= p.C;
+            if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
+        }
+    }
     unsigned a_base[NA];
     const unsigned lane_k = (unsigned)kc * 16u;                             // byte offset of this lane's chunk inside a K-step
     auto issue_fast = [&](int buf) {
-        unsigned char* sa = smem + buf * STAGE_BYTES + wave * 1024;
+        unsigned char* sa = ring + buf * STAGE_BYTES + wave * 1024;
         unsigned char* sb = sa + A_BYTES;
-        if (f_c == 0) {
+        if (f_newtap) {
+            f_newtap = false;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int ih = a_ih[i] + f_kh, iw = a_iw[i] + f_kw;
@@ -176,10 +191,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
             const unsigned off = (b_off[i] + kb) | kvm;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + i * 4096), 16, off, 0, 0, 0);
         }
-        f_k += BK;
-        f_c += BK;
-        if (f_c >= p.C) {
-            f_c = 0;
+        f_k += BK * KS;
+        f_c += BK * KS;
+        while (f_c >= p.C) {                 // (C is a multiple of 64 here: f_c lands on 0 whenever KS = 1)
+            f_c -= p.C;
+            f_newtap = true;
             if (++f_kw == p.KW) { f_kw = 0; ++f_kh; }
         }
     };
@@ -206,7 +222,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s) issue_stage(s);
         int buf = 0;
-        for (int kt = 0; kt < nk; ++kt) {
+        const int nkg = (nk + KS - 1) / KS;              // K-steps per group (a group's steps beyond nk read zeros)
+        for (int kt = 0; kt < nkg; ++kt) {
             CRIS_VMCNT((STAGES - 2) * (NA + NB));       // this wave's share of K-step kt has landed ...
             __builtin_amdgcn_s_barrier();               // ... and everyone's; everyone is also done reading step kt-1
             {
@@ -214,7 +231,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
                 if (nb >= STAGES) nb -= STAGES;
                 issue_stage(nb);                        // refill the buffer of step kt-1 with step kt+STAGES-1
             }
-            const unsigned char* sa = smem + buf * STAGE_BYTES;
+            const unsigned char* sa = ring + buf * STAGE_BYTES;
             const unsigned char* sb = sa + A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < KSL; ++ks) {
@@ -243,6 +260,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const cris_conv_gemm_par
     }
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
 
+    if constexpr (KS > 1) {
+        // group 1's partial sums -> LDS (over the drained rings) -> group 0: acc(even K-steps) + acc(odd K-steps)
+        constexpr int NR = MT == 32 ? 16 : 4;
+        float* xch = reinterpret_cast<float*>(smem) + (wave * 64 + lane) * (FM * FN * NR + 1);
+        __syncthreads();                            // every wave is done reading the operand rings
+        if (grp == 1) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) xch[(i * FN + j) * NR + r] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (grp == 1) return;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[i][j][r] += xch[(i * FN + j) * NR + r];
+    }
     gemm_epilogue<EPI, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
 }
 
@@ -458,7 +497,7 @@ static int skinny_split_slices(const cris_conv_gemm_params& p) {
 static int skinny_kslice(const cris_conv_gemm_params& p, int slices) { return cris_cdiv(cris_cdiv(p.K, slices), 32) * 32; }
 
 // tile selection (host)
-enum { V_SKINNY1 = 0, V_SKINNY9, V_SKINNY9S, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_COUNT };
+enum { V_SKINNY1 = 0, V_SKINNY9, V_SKINNY9S, V_128x64, V_64x64, V_64x128, V_128x128, V_8W_256x256, V_8W_256x128, V_8W_128x256, V_8W_128x128, V_64x64_K2, V_COUNT };
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s);       // gemm8.hip
 
 // which epilogue instantiation a problem takes: 0 general, 1 lean, 2 lean + bias / ReLU (see gemm_epilogue)
@@ -534,7 +573,15 @@ static int pick_variant(const cris_conv_gemm_params& p) {
         // K 9216: 96 us against 119 us; K 4608: 54 against 57)
         static const int t64_max = cris_env_int("CRIS_GEMM_T64_MAX", 1024);
         const bool long_k = p.K >= 4096 && p.M >= 4096 && p.N >= 256;
-        if (!long_k && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128) < t64_max) return V_64x64;
+        if (!long_k && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128) < t64_max) {
+            // grids of at most two blocks per CU: the K-steps split over two wave groups inside the block (CRIS_GEMM_KS2=1; K >= 256
+            // so that each group has at least two steps).  Measured, call r03af: 12.27 ms per step (grids <= 512 blocks) and 12.20
+            // (<= 256) against 12.17 without - twice the waves do not pay for the two-deep rings and the combine; stays off,
+            // available by name ("64x64k2")
+            static const int ks2 = cris_env_int("CRIS_GEMM_KS2", 0), ks2_max = cris_env_int("CRIS_GEMM_KS2_MAX_BLOCKS", 512);
+            if (ks2 && p.K >= 256 && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64) <= ks2_max) return V_64x64_K2;
+            return V_64x64;
+        }
         return V_64x128;
     }
     return V_128x128;
@@ -567,7 +614,7 @@ extern "C" long cris_conv_gemm_ws_floats(const cris_conv_gemm_params* p, int var
 }
 extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
 extern "C" const char* cris_conv_gemm_variant_name(int v) {
-    static const char* names[V_COUNT] = {"skinny1", "skinny9", "skinny9s", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128"};
+    static const char* names[V_COUNT] = {"skinny1", "skinny9", "skinny9s", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128", "64x64k2"};
     return (v >= 0 && v < V_COUNT) ? names[v] : "?";
 }
 
@@ -609,10 +656,14 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     // with 5 blocks per CU 20.00 ms/step - neither helps)
     static const kern_t k_64x64[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 0>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 1>,
                                       conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 2>};
+    // 64x64 with the K-steps split over two wave groups: two-deep ring per group = 64 KB, two blocks (16 waves) per CU
+    constexpr int ST_K2 = 2, LDS_64x64K2 = 2 * ST_K2 * (64 + 64) * 128;
+    static const kern_t k_64x64k2[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_K2, 0, 32, 2>, conv_gemm_kernel<64, 64, 2, 2, ST_K2, 1, 32, 2>,
+                                        conv_gemm_kernel<64, 64, 2, 2, ST_K2, 2, 32, 2>};
     static const int lds_ready = [&]() {
         int rc = 0;
         for (int e = 0; e < 3; ++e)
-            rc |= set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
+            rc |= set_lds((const void*)k_64x64k2[e], LDS_64x64K2) | set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
                   set_lds((const void*)k_128x128[e], LDS_128x128) | set_lds((const void*)k_64x64[e], LDS_64x64);
         return rc;
     }();
@@ -644,6 +695,9 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
             break;
         case V_64x64:
             hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
+            break;
+        case V_64x64_K2:
+            hipLaunchKernelGGL(k_64x64k2[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(512), LDS_64x64K2, s, p);
             break;
         case V_64x128:
             hipLaunchKernelGGL(k_64x128[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 128)), dim3(256), LDS_64x128, s, p);
