@@ -125,3 +125,41 @@ def test_comm_entry_points_resolve_rccl_and_fail_loudly_without_a_gpu(lib):
         assert l.cris_comm_init(0, 1, buf, C.byref(h)) != 0
         assert b"cris_comm_init" in l.cris_last_error()
     assert l.cris_comm_init(3, 2, buf, None) != 0                                         # bad arguments are rejected
+
+
+def test_host_side_selection_logic_without_gpu(lib):
+    """the launch-geometry decisions that are pure host arithmetic (no device call): tile-variant table, weight-gradient tile
+    choice, BatchNorm partial-list rows, Adam block counts"""
+    hip, l = lib
+    l.cris_conv_gemm_variant_name.restype = C.c_char_p
+    names = [l.cris_conv_gemm_variant_name(i).decode() for i in range(l.cris_conv_gemm_num_variants())]
+    assert names == ["skinny1", "skinny9", "skinny9s", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256",
+                     "8w128x128", "64x64k2"]
+    # weight gradients: the 8-wave 256x256 tile for long, wide reductions only; params.tile forces either
+    got = []
+    for M, N, K, tile in [(21632, 512, 4608, 0), (21632, 256, 1152, 0), (5408, 512, 4608, 0), (21632, 128, 4608, 0),
+                          (86528, 256, 4608, 0), (300, 200, 648, 256), (21632, 512, 4608, 128)]:
+        p = hip.WgradParams()
+        p.M, p.N, p.K, p.tile = M, N, K, tile
+        got.append(l.cris_conv_wgrad_tile(C.byref(p)))
+    assert got == [256, 128, 128, 128, 256, 256, 128], got
+    # BatchNorm partial lists: up to 512 parts one launch, beyond that room for the 64 first-level slices
+    assert [l.cris_bn_partials_rows(n) for n in (1, 85, 512, 513, 2704)] == [1, 85, 512, 577, 2768]
+    # Adam: plain tensors in 8192-element blocks, 1-tap packed weights in 64x64 tiles, 9-tap ones in 32-row tiles
+    be = l.cris_adam_block_elems()
+    assert be == 8192
+    d = hip.AdamDesc()
+    d.n = 3 * be + 1
+    assert l.cris_adam_blocks(C.byref(d)) == 4
+    d = hip.AdamDesc()
+    d.dstF, d.N, d.cin, d.taps = 0x1000, 130, 200, 0
+    assert l.cris_adam_blocks(C.byref(d)) == 3 * 4
+    d.taps = 9
+    assert l.cris_adam_blocks(C.byref(d)) == 5 * 4
+    # general epilogue / lean epilogue, tile choice of a mid-size and a large problem (names through the stat-row contract)
+    p = hip.ConvGemmParams()
+    p.M, p.N, p.K, p.C, p.KH, p.KW, p.stride, p.pad, p.H, p.W, p.OH, p.OW, p.Bn = 136, 512, 512, 512, 1, 1, 1, 0, 17, 1, 17, 1, 8
+    assert l.cris_conv_gemm_stat_rows(C.byref(p)) == 32            # M <= 144, K < 1024: the 64x64 tile (32-row wave tiles)
+    p.K = p.C = 2048
+    assert l.cris_conv_gemm_stat_rows(C.byref(p)) == 16            # split-K skinny kernels
+    assert l.cris_conv_gemm_ws_floats(C.byref(p), -1) > 0
