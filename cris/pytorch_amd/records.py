@@ -9,8 +9,9 @@ call per batch whose pixel work runs on the GPU:
 
 `load_record` reads one value of the LMDB the reference's tools/folder2lmdb.py:50-64 writes (`pickle5.dumps(obj, protocol=5)`;
 the reference's own reader still calls the long-removed `pyarrow.deserialize`, utils/dataset.py:87-92 - protocol-5 pickles are
-read by the standard library since Python 3.8).  The LMDB container itself is not read here: iterate it with `lmdb` as
-`RefDataset._init_db` does and pass the values.  Modes follow the reference: 'train' (random sentence, image + mask + tokens),
+read by the standard library since Python 3.8).  `LmdbRecords` opens the LMDB environment itself (reference `RefDataset._init_db` /
+`__getitem__` up to the unpickling, utils/dataset.py:112-133) through this package's own read-only container reader
+(`lmdbfile.LmdbReader`: the `lmdb` C extension is not available on the training image).  Modes follow the reference: 'train' (random sentence, image + mask + tokens),
 'val' (first sentence, image + tokens + params), 'test' (image + params with every sentence).
 """
 import pickle
@@ -32,6 +33,59 @@ def load_record(value: bytes) -> dict:
     if not isinstance(rec, dict) or "img" not in rec:
         raise ValueError("not a CRIS record (expected a dict with 'img', 'mask', 'sents', ...)")
     return rec
+
+
+class LmdbRecords:
+    """The records of one dataset split, indexable like the reference's `RefDataset` before its image processing:
+    `len(ds)` = the pickled `__len__` entry, `ds[i]` = the record dict stored under `__keys__[i]` (utils/dataset.py:112-133,
+    written by tools/folder2lmdb.py:36-68).  `path` is what the reference passes to `lmdb.open` (a directory holding `data.mdb`,
+    or the file).  Opened lazily, like the reference, so that an instance can be handed to worker processes."""
+
+    def __init__(self, path: str):
+        self.path = path
+        self._db = None
+        self.length = None
+        self.keys = None
+
+    def _init_db(self):
+        from .lmdbfile import LmdbReader
+        self._db = LmdbReader(self.path)
+        n, keys = self._db.get(b"__len__"), self._db.get(b"__keys__")
+        if n is None or keys is None:
+            raise ValueError("%s: no __len__ / __keys__ entries (not written by tools/folder2lmdb.py?)" % self.path)
+        self.length, self.keys = pickle.loads(n), pickle.loads(keys)
+
+    def __len__(self):
+        if self._db is None:
+            self._init_db()
+        return self.length
+
+    def raw(self, index: int) -> bytes:
+        """the stored value of record `index` (what `txn.get(self.keys[index])` returns)"""
+        if self._db is None:
+            self._init_db()
+        value = self._db.get(self.keys[index])
+        if value is None:
+            raise KeyError("record %d (key %r) is listed in __keys__ but missing" % (index, self.keys[index]))
+        return value
+
+    def __getitem__(self, index: int) -> dict:
+        return load_record(self.raw(index))
+
+    def batch(self, indices: Sequence[int]) -> List[dict]:
+        """records for RecordPipeline.__call__"""
+        return [self[int(i)] for i in indices]
+
+    def close(self):
+        if self._db is not None:
+            self._db.close()
+            self._db = None
+
+    def __getstate__(self):                      # (the mmap does not travel to worker processes: reopen there)
+        return {"path": self.path}
+
+    def __setstate__(self, st):
+        self.__init__(st["path"])
 
 
 class RecordPipeline:
