@@ -15,13 +15,11 @@ imported to make golden fixtures) and the GPU box (where it cannot) build bit-id
 """
 from __future__ import annotations
 
-import dataclasses
 import hashlib
 import math
-import os
 from collections import OrderedDict
-from dataclasses import dataclass, field
-from typing import Dict, List, Tuple
+from dataclasses import dataclass
+from typing import Dict, Tuple
 
 import torch
 from torch import nn

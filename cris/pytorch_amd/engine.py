@@ -13,7 +13,6 @@ Reference call graph being restated (file:line in DerrickWang005/CRIS.pytorch):
 """
 from __future__ import annotations
 
-import os
 from typing import Callable, Dict, List, Optional
 
 import torch

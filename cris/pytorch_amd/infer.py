@@ -24,7 +24,7 @@ import torch
 from . import ops
 from .arch import ClipSpec, HeadSpec
 from .engine import Act, BN_EPS, Engine
-from .ops import BF16, Geom, pad8
+from .ops import Geom, pad8
 
 F32 = torch.float32
 

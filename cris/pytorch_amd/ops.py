@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 from dataclasses import dataclass
-from typing import Optional, Tuple
+from typing import Optional
 
 import torch
 

@@ -10,7 +10,6 @@ rounding points => mostly identical rounded values) and the fp32 oracle only to 
 import contextlib
 
 import torch
-import torch.nn.functional as F
 
 from . import cris_oracle as O
 
