@@ -63,6 +63,9 @@ class LmdbReader:
         self._m = mmap.mmap(self._f.fileno(), 0, access=mmap.ACCESS_READ)
         try:
             self._read_meta(size)
+        except struct.error as e:                    # a header that runs past the end of a damaged file
+            self.close()
+            raise LmdbFormatError("%s: %s" % (self.path, e)) from None
         except Exception:
             self.close()
             raise
@@ -112,6 +115,8 @@ class LmdbReader:
         got, _, flags, lower, _ = _HDR.unpack_from(self._m, off)
         if got != pgno:
             raise LmdbFormatError("%s: page %d carries page number %d" % (self.path, pgno, got))
+        if lower < PAGEHDRSZ or lower > self.psize or (lower - PAGEHDRSZ) & 1:
+            raise LmdbFormatError("%s: page %d has an implausible node-offset array (lower = %d)" % (self.path, pgno, lower))
         if flags & (P_LEAF2 | P_SUBP):
             raise LmdbFormatError("%s: page %d has flags %#x (fixed-size-key / sub-page layouts are not supported)" % (self.path, pgno, flags))
         return off, flags, (lower - PAGEHDRSZ) >> 1
@@ -119,7 +124,11 @@ class LmdbReader:
     def _node(self, off: int, i: int):
         """node i of the page at byte `off` -> (lo, hi, flags, key offset, key size)"""
         ptr = struct.unpack_from("<H", self._m, off + PAGEHDRSZ + 2 * i)[0]
+        if ptr < PAGEHDRSZ or ptr + NODESIZE > self.psize:
+            raise LmdbFormatError("%s: node offset %d outside its page (corrupt file)" % (self.path, ptr))
         lo, hi, flags, ksize = _NODE.unpack_from(self._m, off + ptr)
+        if ptr + NODESIZE + ksize > self.psize:
+            raise LmdbFormatError("%s: key of %d bytes runs past its page (corrupt file)" % (self.path, ksize))
         return lo, hi, flags, off + ptr + NODESIZE, ksize
 
     def _key(self, off: int, i: int) -> bytes:
@@ -132,12 +141,18 @@ class LmdbReader:
             raise LmdbFormatError("%s: node with flags %#x (sub-database / duplicates) is not supported" % (self.path, flags))
         dsize = lo | (hi << 16)
         if flags & F_BIGDATA:
+            if (ko + ks - off) + 8 > self.psize:
+                raise LmdbFormatError("%s: overflow reference runs past its page (corrupt file)" % self.path)
             ovf = struct.unpack_from("<Q", self._m, ko + ks)[0]
             o = ovf * self.psize
+            if o + PAGEHDRSZ > self._size:
+                raise LmdbFormatError("%s: overflow page %d lies beyond the end of the file" % (self.path, ovf))
             got, _, pflags, npages = struct.unpack_from("<QHHI", self._m, o)
             if got != ovf or not pflags & P_OVERFLOW or PAGEHDRSZ + dsize > npages * self.psize or o + PAGEHDRSZ + dsize > self._size:
                 raise LmdbFormatError("%s: bad overflow page %d for a %d-byte value" % (self.path, ovf, dsize))
             return self._m[o + PAGEHDRSZ:o + PAGEHDRSZ + dsize]
+        if (ko + ks - off) + dsize > self.psize:
+            raise LmdbFormatError("%s: inline value of %d bytes runs past its page (corrupt file)" % (self.path, dsize))
         return self._m[ko + ks:ko + ks + dsize]
 
     @staticmethod
@@ -193,9 +208,11 @@ class LmdbReader:
     def __len__(self) -> int:
         return self.entries
 
-    def _walk(self, pgno: int, depth: int) -> Iterator[Tuple[int, int]]:
-        if depth > 64:
-            raise LmdbFormatError("%s: tree deeper than 64 levels (corrupt file)" % self.path)
+    def _walk(self, pgno: int, depth: int, seen: Optional[set] = None) -> Iterator[Tuple[int, int]]:
+        seen = set() if seen is None else seen
+        if depth > 64 or pgno in seen:               # a tree visits every page once: a repeat is a cycle in a corrupt file
+            raise LmdbFormatError("%s: page %d reached twice or below level 64 (corrupt file)" % (self.path, pgno))
+        seen.add(pgno)
         off, flags, n = self._page(pgno)
         if flags & P_LEAF:
             for i in range(n):
@@ -203,7 +220,7 @@ class LmdbReader:
         elif flags & P_BRANCH:
             for i in range(n):
                 lo, hi, nflags, _, _ = self._node(off, i)
-                yield from self._walk(self._child(lo, hi, nflags), depth + 1)
+                yield from self._walk(self._child(lo, hi, nflags), depth + 1, seen)
         else:
             raise LmdbFormatError("%s: page %d is neither branch nor leaf" % (self.path, pgno))
 

@@ -174,3 +174,36 @@ def test_lmdb_records_follow_the_reference_dataset_protocol(tmp_path):
     write_env(bad, {b"0": items[b"0"]})
     with pytest.raises(ValueError, match="__len__"):
         len(LmdbRecords(bad))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_damaged_files_are_refused_or_read_never_hung_or_crashed(tmp_path, seed):
+    """random byte damage in the meta, branch and leaf pages: opening, looking up every key and walking the tree either works
+    or raises LmdbFormatError - no other exception type, no endless walk (a page reached twice is a cycle)"""
+    rng = random.Random(100 + seed)
+    items = {("%d" % i).encode(): _rand_bytes(rng, rng.choice([3, 40, 3000])) for i in range(400)}
+    p = str(tmp_path / "ok.mdb")
+    write_env(p, items, psize=512)
+    blob = bytearray(open(p, "rb").read())
+    npages = len(blob) // 512
+    outcomes = set()
+    for trial in range(60):
+        bad = bytearray(blob)
+        for _ in range(rng.randint(1, 6)):
+            page = rng.choice([0, 1, rng.randrange(npages), npages - 1 - rng.randrange(min(40, npages))])
+            pos = page * 512 + (rng.randrange(16) if rng.random() < 0.5 else rng.randrange(512))
+            bad[pos] = rng.getrandbits(8)
+        q = str(tmp_path / "bad.mdb")
+        open(q, "wb").write(bytes(bad))
+        try:
+            with LmdbReader(q) as db:
+                for k in list(items)[:50]:
+                    db.get(k)
+                n = 0
+                for _ in db.items():
+                    n += 1
+                    assert n <= 100000
+            outcomes.add("read")
+        except LmdbFormatError:
+            outcomes.add("refused")
+    assert outcomes <= {"read", "refused"} and outcomes
