@@ -1012,12 +1012,12 @@ extern "C" int cris_bn_bwd_apply(const cris_bn_bwd_params* pp, void* stream) {
 // ------------------------------------------------------------------------------------------------
 #define LN_MAXV 4
 
-template <bool WANT_MASK>
+template <bool WANT_MASK, int V = LN_MAXV>
 __device__ __forceinline__ void ln_load_row(const void* x, int x_f32, size_t rowoff, int C, int lane, int in_relu,
                                             uint32_t in_thresh, float in_scale, uint32_t in_key, uint32_t row,
-                                            float (&v)[LN_MAXV][8], float (&mask_out)[LN_MAXV][8]) {
+                                            float (&v)[V][8], float (&mask_out)[V][8]) {
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < V; ++i) {
         const int c0 = (lane + 64 * i) * 8;
         if (c0 < C) {
             if (x_f32) load8f(reinterpret_cast<const float*>(x) + rowoff + c0, v[i]);
@@ -1127,12 +1127,17 @@ extern "C" int cris_ln_fwd(const cris_ln_fwd_params* pp, void* stream) {
     return 0;
 }
 
+// V = 8-channel vectors per lane (C <= 512 V).  V = 4 serves every C <= 2048 and is what runs by default; the narrower instantiations
+// (CRIS_LN_BWD_V=1: V = 1 / 2 for C <= 512 / 1024) keep a quarter / half of the registers - the V = 4 kernel holds 238 VGPRs, two
+// waves per SIMD, for rows of which a C = 512 LayerNorm uses one vector.  Built in round 3 after the GPU budget was spent: not yet
+// run (the default path is unchanged); to be measured first thing next round together with a larger grid.
+template <int V>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p) {
-    __shared__ float sg[2][64 * 8 * LN_MAXV];        // dgamma / dbeta block accumulators
+    __shared__ float sg[2][64 * 8 * V];        // dgamma / dbeta block accumulators
     const int lane = threadIdx.x & 63;
     const int wave_g = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int nwaves = gridDim.x * 4;
-    for (int i = threadIdx.x; i < 2 * 64 * 8 * LN_MAXV; i += 256) (&sg[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * 64 * 8 * V; i += 256) (&sg[0][0])[i] = 0.f;
     __syncthreads();
     const uint32_t sdev = p.seed_dev ? p.seed_dev[0] : 0u;
     const uint32_t in_key = cris_drop_key(p.in_seed + sdev, p.in_stream);
@@ -1140,21 +1145,21 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p)
     const float in_scale = p.in_thresh ? 1.f / (1.f - p.in_drop_p) : 1.f;
     const float out_scale = p.out_thresh ? 1.f / (1.f - p.out_drop_p) : 1.f;
     const float invC = 1.f / (float)p.C;
-    float dga[LN_MAXV][8], dbe[LN_MAXV][8];
+    float dga[V][8], dbe[V][8];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i)
+    for (int i = 0; i < V; ++i)
 #pragma unroll
         for (int j = 0; j < 8; ++j) dga[i][j] = dbe[i][j] = 0.f;
 
     for (int row = wave_g; row < p.rows; row += nwaves) {
-        float v[LN_MAXV][8], msk[LN_MAXV][8];
-        ln_load_row<true>(p.x, p.x_f32, (size_t)row * p.ldx, p.C, lane, p.in_relu, p.in_thresh, in_scale, in_key, (uint32_t)row,
+        float v[V][8], msk[V][8];
+        ln_load_row<true, V>(p.x, p.x_f32, (size_t)row * p.ldx, p.C, lane, p.in_relu, p.in_thresh, in_scale, in_key, (uint32_t)row,
                           v, msk);
         const float mean = p.mean[row], rstd = p.rstd[row];
-        float a[LN_MAXV][8];
+        float a[V][8];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < V; ++i) {
             const int c0 = (lane + 64 * i) * 8;
             if (c0 < p.C) {
                 const size_t oo = (size_t)row * p.C + c0;
@@ -1198,7 +1203,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p)
         }
         const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
 #pragma unroll
-        for (int i = 0; i < LN_MAXV; ++i) {
+        for (int i = 0; i < V; ++i) {
             const int c0 = (lane + 64 * i) * 8;
             if (c0 >= p.C) continue;
             float o[8];
@@ -1225,7 +1230,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p)
     for (int w = 0; w < 4; ++w) {
         if ((int)(threadIdx.x >> 6) == w) {
 #pragma unroll
-            for (int i = 0; i < LN_MAXV; ++i) {
+            for (int i = 0; i < V; ++i) {
                 const int c0 = (lane + 64 * i) * 8;
                 if (c0 < p.C) {
 #pragma unroll
@@ -1257,7 +1262,11 @@ extern "C" int cris_ln_bwd(const cris_ln_bwd_params* pp, void* stream) {
     CRIS_CHECK_ARG(p.dy || p.dypos || p.dout_f32, "no incoming gradient");
     CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 64 * 8 * LN_MAXV && (p.ldx & 7) == 0, "C must be a multiple of 8, <= 2048");
     CRIS_CHECK_ARG(!p.dx_accum || p.dx_f32, "accumulate only into fp32");
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(ln_bwd_grid(p.rows)), dim3(256), 0, (hipStream_t)stream, p);
+    static const int narrow = cris_env_int("CRIS_LN_BWD_V", 0);
+    const dim3 grid(ln_bwd_grid(p.rows));        // (= the rows of the partials table the caller sized with cris_ln_bwd_parts)
+    if (narrow && p.C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else if (narrow && p.C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(ln_bwd_kernel<LN_MAXV>, grid, dim3(256), 0, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

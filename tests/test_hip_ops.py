@@ -4,6 +4,7 @@ rounding of an fp32-accumulated result is 2^-9 ~ 2e-3 per element); fp32 outputs
 5e-3; pure fp32 kernels -> 1e-5.  Index/mask decisions (dropout keep, nearest resize, EOT argmax) are
 bit exact."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -1099,3 +1100,16 @@ def test_syncbn_single_exchange_far_reference(d, tol):
                     global_stats=g)
     check(outs[2], y.double().mean(0), 1e-6, "global mean, reference %g std away" % d)
     check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), tol, "global invstd, reference %g std away" % d)
+
+
+@pytest.mark.skipif(os.environ.get("CRIS_TEST_NEXT") != "1", reason="code path written after the round's GPU budget was spent: "
+                    "not yet run on a GPU; CRIS_TEST_NEXT=1 includes it (first thing next round)")
+def test_layernorm_backward_narrow_instantiations():
+    """CRIS_LN_BWD_V=1 (read once per process, hence the subprocess): C <= 512 / <= 1024 run the 1- / 2-vector-per-lane
+    instantiations of the LayerNorm backward; the same checks as test_layernorm_variants must hold"""
+    import subprocess
+    import sys
+    env = dict(os.environ, CRIS_LN_BWD_V="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_layernorm_variants",
+                        "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
