@@ -633,6 +633,53 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+// the same reduction for a table of problems in one launch (table by value; block -> problem by a scan of <= 24 starts)
+struct wgrad_reduce_job {
+    const float* ws; float* dW; float* dbias;
+    long slab, n_dw;
+    int splits, N, block_start, pad_;
+};
+struct wgrad_reduce_table {
+    int n, pad_;
+    wgrad_reduce_job job[CRIS_WGRAD_GROUP_MAX];
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const wgrad_reduce_table t) {
+    __shared__ float4 sh[16][17];
+    int j = 0;
+    while (j + 1 < t.n && (int)blockIdx.x >= t.job[j + 1].block_start) ++j;
+    const wgrad_reduce_job& q = t.job[j];
+    const long n4 = q.n_dw >> 2;
+    const long nb4 = q.dbias ? (q.N + 3) >> 2 : 0;
+    const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const long i = (long)((int)blockIdx.x - q.block_start) * 16 + cl;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4 + nb4) {
+        const float* src = q.ws + (i < n4 ? i * 4 : q.n_dw + (i - n4) * 4);
+        for (int s = pl; s < q.splits; s += 16) {
+            const float4 b = *reinterpret_cast<const float4*>(src + (size_t)s * q.slab);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    }
+    sh[pl][cl] = a;
+    __syncthreads();
+    if (pl == 0 && i < n4 + nb4) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const float4 b = sh[k][cl];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (i < n4) {
+            *reinterpret_cast<float4*>(q.dW + i * 4) = a;
+        } else {
+            const long n = (i - n4) * 4;
+            const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (n + k < q.N) q.dbias[n + k] = v[k];
+        }
+    }
+}
+
 static int wgrad_check(const cris_wgrad_params& p, const char* fn) {
 #define WG_ARG(cond, msg)                            \
     do {                                             \
@@ -715,7 +762,33 @@ extern "C" int cris_conv_wgrad(const cris_wgrad_params* pp, void* stream) {
     }
     else hipLaunchKernelGGL(conv_wgrad_kernel, dim3(wgrad_blocks(p, WG_T)), dim3(256), WG_LDS, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
-    return p.splits > 1 ? cris_wgrad_reduce(&p, stream) : 0;
+    return (p.splits > 1 && !p.defer_reduce) ? cris_wgrad_reduce(&p, stream) : 0;
+}
+
+extern "C" int cris_wgrad_reduce_group(const cris_wgrad_group* gp, void* stream) {
+    CRIS_CHECK_ARG(gp && gp->n > 0 && gp->n <= CRIS_WGRAD_GROUP_MAX, "1 .. CRIS_WGRAD_GROUP_MAX problems per launch");
+    wgrad_reduce_table t;
+    t.n = 0;
+    t.pad_ = 0;
+    int start = 0;
+    for (int i = 0; i < gp->n; ++i) {
+        cris_wgrad_params p = gp->prob[i];
+        p.splits = wgrad_effective_splits(p.M, p.splits);          // as cris_conv_wgrad launched it
+        if (p.splits <= 1) continue;
+        if (wgrad_check(p, __func__)) return -1;
+        CRIS_CHECK_ARG(p.ws != nullptr, "split reduction without a workspace");
+        wgrad_reduce_job& q = t.job[t.n++];
+        q.ws = p.ws; q.dW = p.dW; q.dbias = p.dbias;
+        q.slab = wg_slab_floats(p.N, p.ldw);
+        q.n_dw = (long)p.N * p.ldw;
+        q.splits = p.splits; q.N = p.N; q.block_start = start; q.pad_ = 0;
+        const long cols4 = q.n_dw / 4 + (p.dbias ? (p.N + 3) / 4 : 0);
+        start += cris_cdiv(cols4, 16);
+    }
+    if (t.n == 0) return 0;
+    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(start), dim3(256), 0, (hipStream_t)stream, t);
+    CRIS_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int cris_conv_wgrad_group(const cris_wgrad_group* gp, void* stream) {

@@ -39,7 +39,7 @@ class WgradParams(C.Structure):
                 ("Bn", I), ("H", I), ("W", I), ("C", I),
                 ("OH", I), ("OW", I), ("KH", I), ("KW", I), ("stride", I), ("pad", I),
                 ("M", I), ("N", I), ("K", I),
-                ("ldw", I), ("splits", I), ("tile", I), ("pad_", I),
+                ("ldw", I), ("splits", I), ("tile", I), ("defer_reduce", I),
                 ("dbias", P), ("ws", P)]
 
 
@@ -214,6 +214,7 @@ _SIGS = {
     "cris_conv_wgrad_group": (I, [P, P]),
     "cris_conv_wgrad_tile": (I, [P]),
     "cris_wgrad_reduce": (I, [P, P]),
+    "cris_wgrad_reduce_group": (I, [P, P]),
     "cris_wgrad_ws_floats": (L, [I, I, I, I]),
     "cris_pack_weights": (I, [P, I, I, P]),
     "cris_pack_blocks": (I, [P]),

@@ -182,6 +182,9 @@ _WGRAD_FLUSH_BLOCKS = int(os.environ.get("CRIS_WGRAD_FLUSH_BLOCKS", "3072"))
 
 
 _WGRAD8_BLOCKS = int(os.environ.get("CRIS_WGRAD8_BLOCKS", "256"))    # 8-wave 256x256 tile: one block (128 KB of LDS) per CU
+# 1: the split reductions of the large layers (32 launches of ~6.6 us per step) are deferred to the queue's flush and run as
+# grouped launches (cris_wgrad_reduce_group).  Written after round 3's GPU budget was spent: default off until measured.
+_WGRAD_REDUCE_GROUP = os.environ.get("CRIS_WGRAD_REDUCE_GROUP", "0") == "1"
 
 
 def wgrad_splits(M: int, N: int, K: int, tile: int = 128) -> int:
@@ -222,6 +225,11 @@ class WgradQueue:
         self.items = []
         self.blocks = 0
         self.on_full = on_full        # called instead of flush() when enough blocks are waiting (the engine picks the stream)
+        self.reduces = []             # (params, operand tensors) of launches whose split reduction was deferred to the flush
+
+    def add_reduce(self, p, keep):
+        """a problem launched with defer_reduce: its slabs are added up by the next flush (same stream as the launch)"""
+        self.reduces.append((p, keep))
 
     def add(self, p, keep, flops, nbytes):
         tile = hip.load().cris_conv_wgrad_tile(C.byref(p))       # 128 or 256: a group launch runs ONE tile kernel
@@ -234,8 +242,16 @@ class WgradQueue:
         """launch everything queued on the current stream; returns the operand tensors of the launched problems (a caller
         that launches on a side stream keeps them alive until that stream has been joined)"""
         items, self.items, self.blocks = self.items, [], 0
+        reduces, self.reduces = self.reduces, []
+        for i in range(0, len(reduces), hip.WGRAD_GROUP_MAX):
+            chunk = reduces[i:i + hip.WGRAD_GROUP_MAX]
+            grp = hip.WgradGroup()
+            grp.n = len(chunk)
+            for j, it in enumerate(chunk):
+                grp.prob[j] = it[0]
+            hip.call("cris_wgrad_reduce_group", C.byref(grp), _stream())
         if not items:
-            return []
+            return [it[1] for it in reduces]
         items.sort(key=lambda it: (-it[4], -it[0].M))          # by tile kernel; stable: longest pixel reductions first
         bounds = [i for i in range(len(items)) if i == 0 or items[i][4] != items[i - 1][4]] + [len(items)]
         starts = [i for a, b in zip(bounds, bounds[1:]) for i in range(a, b, hip.WGRAD_GROUP_MAX)]
@@ -251,7 +267,7 @@ class WgradQueue:
                                     C.byref(grp), tag="group of %d (M %d..%d)" % (len(chunk), chunk[-1][0].M, chunk[0][0].M))
             else:
                 hip.call("cris_conv_wgrad_group", C.byref(grp), _stream())
-        return [it[1] for it in items]
+        return [it[1] for it in items] + [it[1] for it in reduces]
 
 
 def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx=None, x_coff=0, ldw=None, splits=None, dbias=None,
@@ -271,6 +287,11 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
     p.ws = ptr(ws)
     if KERNEL_TIMER is not None:
         KERNEL_TIMER.launch("conv_wgrad", flops, nbytes, "cris_conv_wgrad", C.byref(p), tag="M%d N%d K%d k%d s%d" % (g.M, N, g.K, g.KH, p.splits))
+        return
+    if queue is not None and _WGRAD_REDUCE_GROUP and p.splits > 1:
+        p.defer_reduce = 1
+        hip.call("cris_conv_wgrad", C.byref(p), _stream())
+        queue.add_reduce(p, (dY, X, dW, dbias, ws))
         return
     hip.call("cris_conv_wgrad", C.byref(p), _stream())
 

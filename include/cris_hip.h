@@ -100,7 +100,8 @@ typedef struct {
     int splits;              /* requested split of the pixel range (each split covers ceil(M/splits) rows rounded up to 128;
                                 the launcher drops splits that would be empty) */
     int tile;                /* output tile: 0 = the library's choice (cris_conv_wgrad_tile), 128 = 4-wave kernel, 256 = 8-wave */
-    int pad_;
+    int defer_reduce;        /* 1: cris_conv_wgrad leaves the split slabs in `ws`; the caller adds them up later with
+                                cris_wgrad_reduce or, for several problems in one launch, cris_wgrad_reduce_group */
     float* dbias;            /* optional [N]: = column sums of dY (bias gradient); or NULL */
     float* ws;               /* splits > 1: workspace of cris_wgrad_ws_floats(M, N, ldw, splits) floats, 16-byte aligned */
 } cris_wgrad_params;
@@ -121,6 +122,9 @@ typedef struct {
     cris_wgrad_params prob[CRIS_WGRAD_GROUP_MAX];
 } cris_wgrad_group;
 int cris_conv_wgrad_group(const cris_wgrad_group* g, void* stream);
+/* the split reductions (cris_wgrad_reduce) of up to CRIS_WGRAD_GROUP_MAX problems launched with defer_reduce, in ONE launch;
+ * problems with splits == 1 are skipped.  (Written after round 3's GPU budget was spent: cross-compiled, not yet run.) */
+int cris_wgrad_reduce_group(const cris_wgrad_group* g, void* stream);
 
 /* Batched weight packing (fp32 parameter layout -> bf16 GEMM layouts), one launch for a table of tensors.
  *   F layout: Wf[n][tap][Cpad]        (forward, k = tap*Cpad + c, zero padded)
