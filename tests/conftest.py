@@ -11,11 +11,13 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / the driver's GPU tier)")
+    config.addinivalue_line("markers", "gpu_long: GPU parity runs of a minute or more each (100-step trajectories, teacher-forced "
+                                       "runs of every BASELINE configuration); select with -m 'gpu or gpu_long'")
 
 
 # GPU run order: deterministic per-kernel parity first, then the whole-network comparisons, then the statistical ones
 # (loss trajectories, multi-process runs) - under `-x` a failure in a late, noise-sensitive test must not hide the kernel tests.
-_GPU_ORDER = ["test_hip_ops", "test_engine_gpu", "test_module_gpu", "test_dist_gpu", "test_ref_loop_gpu", "test_eval_post", "test_input_pipe", "test_jpeg_gpu", "test_records_gpu", "test_p2p_gpu", "test_comm_gpu"]
+_GPU_ORDER = ["test_hip_ops", "test_engine_gpu", "test_parity_long_gpu", "test_module_gpu", "test_dist_gpu", "test_ref_loop_gpu", "test_eval_post", "test_input_pipe", "test_jpeg_gpu", "test_records_gpu", "test_p2p_gpu", "test_comm_gpu"]
 
 
 def _gpu_rank(item):
@@ -33,5 +35,5 @@ def pytest_collection_modifyitems(config, items):
         return
     skip = pytest.mark.skip(reason="no GPU in this container")
     for it in items:
-        if "gpu" in it.keywords:
+        if "gpu" in it.keywords or "gpu_long" in it.keywords:
             it.add_marker(skip)

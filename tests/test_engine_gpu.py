@@ -236,93 +236,62 @@ def test_loss_trajectory_tiny_100_steps():
     assert losses[-1] < 0.5 * losses[0]            # and it actually trains
 
 
-# Fixed bounds on |loss_hip - loss_fp32_oracle| per phase of the 100-step curve: (first step, last step + 1, max, mean).  Measured
-# on an MI355X (the path is deterministic: a given build reproduces its curve bit for bit; profiles/parity_r02.json):
-#   steps 0-4   before the transient                      max 2.9e-2
-#   steps 5-39  the violent transient of the untrained head at lr 1e-4 (the fp32 loss itself jumps between 0.5 and 2.2):
-#               max 4.5e-1, mean 9.0e-2 - the oracle with bf16 storage rounding: 3.7e-1 / 7.6e-2, and two builds of THIS path
-#               that differ only in the summation order of the BatchNorm partial sums: 1.9e-1 apart.  This phase is chaotic;
-#               its bound says "same regime", nothing finer can be asserted of any bf16 implementation.
-#   steps 40-99 max 9.9e-2, mean 1.0e-2;  steps 60-99 max 2.8e-2, mean 8.7e-3 (bf16-storage oracle: 2.4e-2 / 7.6e-3).
-# The chaotic phase (steps 5-39) is not bounded here any more: every one of the 100 states is checked tightly by the
-# teacher-forced test below, where errors cannot compound through the optimizer.
-TRAJ_PHASES = [(0, 5, 6.0e-2, 3.0e-2), (40, 100, 2.0e-1, 2.5e-2), (60, 100, 6.0e-2, 1.8e-2)]
+# Teacher-forced bounds, fixed numbers (profiles/parity_r04.md): at EVERY state of the fp32 oracle's own trajectory
+# |loss_hip - loss_fp32| <= TF_LOSS, logits relative L2 <= TF_LOGITS, median parameter-gradient cosine >= TF_COS_MED, worst
+# parameter's cosine >= TF_COS_MIN; and the MEAN |dloss| over the states <= the bound given per configuration.
+TF_LOSS, TF_LOGITS, TF_COS_MED, TF_COS_MIN = 3.0e-2, 8.0e-2, 0.99, 0.75
 
 
-def test_loss_trajectory_r50_full_size_100_steps():
-    """BASELINE.json configs[1] (R50, 416x416, batch 8, L=17, dropout 0.1) for 100 optimizer steps at the REFERENCE's learning
-    rate (Adam lr 1e-4, config/refcoco/cris_r50.yaml) against the fp32 CPU oracle + torch.optim.Adam
-    (tests/golden/traj_r50_b8_s416_d0.1_lr0.0001.json, made by tests/golden/make_trajectory.py).  The untrained head makes the
-    first ~40 steps violent for ANY implementation (fp32: 0.90, 1.80, 1.46, 0.78, 1.11, 2.17, ...); every bound is a constant.
-    The oracle run with bf16 storage rounding (..._bf16emul.json) is printed beside it for orientation only - no bound
-    depends on it."""
-    fp32, emul = "traj_r50_b8_s416_d0.1_lr0.0001.json", "traj_r50_b8_s416_d0.1_lr0.0001_bf16emul.json"
-    losses, ref, diffs = _trajectory(fp32)
-    n = len(losses)
-    assert n >= 100, "fixture must hold 100 steps"
-    ref_e = json.load(open(os.path.join(GOLDEN, emul)))["loss"][:n] if os.path.exists(os.path.join(GOLDEN, emul)) else [float("nan")] * n
-    print("r50 trajectory hip / fp32 oracle / bf16-emulated oracle:",
-          ["%.4f/%.4f/%.4f" % (a, b, c) for a, b, c in zip(losses, ref, ref_e)])
-    de = [abs(a - b) for a, b in zip(ref_e, ref)]
-    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):         # the measured curve, for profiles/parity_r02.json
-        with open(os.path.join(ROOT, "gpurun_out", "traj_r50_hip.json"), "w") as f:
-            json.dump({"loss_hip": [round(x, 6) for x in losses]}, f)
-    print("max |hip-fp32| %.3e mean %.3e ; bf16-emulated oracle vs fp32: max %.3e mean %.3e"
-          % (max(diffs), sum(diffs) / n, max(de), sum(de) / n))
-    assert abs(losses[0] - ref[0]) < 5e-3                      # before any update
-    for lo, hi, bmax, bmean in TRAJ_PHASES:
-        seg = diffs[lo:hi]
-        assert max(seg) <= bmax and sum(seg) / len(seg) <= bmean, (lo, hi, max(seg), sum(seg) / len(seg))
-    assert losses[-1] < 0.5 * losses[0]                        # and it trains: 0.91 -> ~0.3
-
-
-# Teacher-forced bounds, fixed numbers set from the values measured on an MI355X (profiles/parity_r03.md: |dloss| max 1.86e-2 at
-# step 3 - fp32 loss 0.78 between 1.46 and 1.11 -, mean 1.09e-3 over the 100 states; logits max 6.1e-2, mean 5.7e-3; median
-# gradient cosine >= 0.9945 at every state; worst tensor of any state 0.825, a BatchNorm bias): at EVERY state of the fp32
-# trajectory |loss_hip - loss_fp32| <= TF_LOSS, logits relative L2 <= TF_LOGITS, median parameter-gradient cosine >= TF_COS_MED,
-# worst parameter's cosine >= TF_COS_MIN; and the MEAN |dloss| over the 100 states <= TF_LOSS_MEAN.
-TF_LOSS, TF_LOSS_MEAN, TF_LOGITS, TF_COS_MED, TF_COS_MIN = 3.0e-2, 2.0e-3, 8.0e-2, 0.99, 0.75
-
-
-def test_teacher_forced_r50_full_size_100_steps():
-    """BASELINE.json configs[1] (R50, 416x416, batch 8, dropout 0.1, Adam lr 1e-4) - 100 optimizer steps of the fp32 oracle
-    running as stock PyTorch on this GPU (oracle/torch_runner.py; equal to the pinned CPU oracle, tests/test_oracle_device.py);
-    before EVERY step the oracle's parameters and BatchNorm buffers are loaded into the HIP engine, which then computes the
-    same step's loss and gradients from the same batch and dropout masks.  Each of the 100 comparisons is a single
-    forward + backward from an identical state, so nothing compounds: the bounds are tight and hold in the transient of the
-    untrained head (steps 5-39) as everywhere else."""
+def teacher_forced(spec, size, word_len, steps, tag, every=1, dropout=0.1, lr=1e-4, batch=8):
+    """`steps` optimizer steps of the fp32 oracle running as stock PyTorch on this GPU (oracle/torch_runner.py; equal to the
+    pinned CPU oracle, tests/test_oracle_device.py); before every `every`-th step the oracle's parameters and BatchNorm buffers
+    are loaded into the HIP engine, which then computes the same step's loss and gradients from the same batch and dropout
+    masks.  Each comparison is a single forward + backward from an identical state, so nothing compounds.  Returns the rows."""
     from oracle.torch_runner import OracleTrainer, cosines, seed_of_step
-    clip, head = arch.specs_by_name("r50")
-    head = dataclasses.replace(head, dropout=0.1)
+    clip, head = arch.specs_by_name(spec)
+    head = dataclasses.replace(head, dropout=dropout, word_len=word_len)
     sd = arch.synthetic_state_dict(clip, head, 0)
     dev = torch.device("cuda:0")
-    ot = OracleTrainer(clip, head, sd, dev, mode="fp32", lr=1e-4)
+    ot = OracleTrainer(clip, head, sd, dev, mode="fp32", lr=lr)
     tr = NativeTrainer(clip, head, sd, dev, launch="eager")
     e = tr.engine
     rows = []
-    for t in range(100):
-        batch = synth.make_batch(8, 416, head.word_len, 0, t)
-        tr.load_model_state_dict(ot.state_dict())
-        img, word, mask = (x.to(dev) for x in batch)
-        pred, _, loss = e.forward(img, word, mask, training=True, seed=seed_of_step(t))
-        e.backward()
-        oloss, opred = ot.forward_backward(batch, seed_of_step(t))
-        cs = cosines({k: v for k, v in e.grads_param_layout().items()}, ot.grads())
-        worst = min(cs, key=cs.get)
-        vals = sorted(cs.values())
-        rows.append(dict(step=t, loss_hip=float(loss), loss_fp32=oloss, logits=float((pred.float() - opred).norm() / opred.norm()),
-                         cos_med=vals[len(vals) // 2], cos_min=cs[worst], cos_min_name=worst))
+    for t in range(steps):
+        batch_t = synth.make_batch(batch, size, head.word_len, 0, t)
+        if t % every == 0:
+            tr.load_model_state_dict(ot.state_dict())
+            img, word, mask = (x.to(dev) for x in batch_t)
+            pred, _, loss = e.forward(img, word, mask, training=True, seed=seed_of_step(t))
+            e.backward()
+        oloss, opred = ot.forward_backward(batch_t, seed_of_step(t))
+        if t % every == 0:
+            cs = cosines({k: v for k, v in e.grads_param_layout().items()}, ot.grads())
+            worst = min(cs, key=cs.get)
+            vals = sorted(cs.values())
+            rows.append(dict(step=t, loss_hip=float(loss), loss_fp32=oloss, logits=float((pred.float() - opred).norm() / opred.norm()),
+                             cos_med=vals[len(vals) // 2], cos_min=cs[worst], cos_min_name=worst))
         ot.update()
     if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
-        with open(os.path.join(ROOT, "gpurun_out", "teacher_forced_r50.json"), "w") as f:
+        with open(os.path.join(ROOT, "gpurun_out", "teacher_forced_%s.json" % tag), "w") as f:
             json.dump(rows, f)
     dl = [abs(r["loss_hip"] - r["loss_fp32"]) for r in rows]
-    print("teacher-forced: |dloss| max %.3e mean %.3e; logits max %.3e; grad cos median min %.4f; worst tensor min %.4f (%s)" % (
-        max(dl), sum(dl) / len(dl), max(r["logits"] for r in rows), min(r["cos_med"] for r in rows),
-        min(r["cos_min"] for r in rows), min(rows, key=lambda r: r["cos_min"])["cos_min_name"]))
+    print("teacher-forced %s: %d states, |dloss| max %.3e mean %.3e; logits max %.3e mean %.3e; grad cos median min %.4f; worst tensor min %.4f (%s)" % (
+        tag, len(rows), max(dl), sum(dl) / len(dl), max(r["logits"] for r in rows), sum(r["logits"] for r in rows) / len(rows),
+        min(r["cos_med"] for r in rows), min(r["cos_min"] for r in rows), min(rows, key=lambda r: r["cos_min"])["cos_min_name"]))
+    return rows, dl
+
+
+def assert_teacher_forced(rows, dl, mean_bound, loss=TF_LOSS, logits=TF_LOGITS, cos_med=TF_COS_MED, cos_min=TF_COS_MIN):
+    bad = [r for r, d in zip(rows, dl) if d > loss or r["logits"] > logits or r["cos_med"] < cos_med or r["cos_min"] < cos_min]
+    assert not bad, bad[:5]
+    assert sum(dl) / len(dl) <= mean_bound, sum(dl) / len(dl)
+
+
+def test_teacher_forced_r50_full_size_first_12_states():
+    """BASELINE.json configs[1] (R50, 416x416, batch 8, dropout 0.1, Adam lr 1e-4): the first 12 states of the teacher-forced
+    comparison (they include the violent steps of the untrained head: fp32 loss 0.90, 1.80, 1.46, 0.78, 1.11, 2.17, ...).  The
+    full 100 states, and 20 states each of configs[3] and configs[4], are in tests/test_parity_long_gpu.py (marker gpu_long)."""
+    rows, dl = teacher_forced("r50", 416, 17, 12, "r50_first12")
     fx = json.load(open(os.path.join(GOLDEN, "traj_r50_b8_s416_d0.1_lr0.0001.json")))["loss"]
     assert abs(rows[0]["loss_fp32"] - fx[0]) < 1e-4                  # the GPU teacher starts where the pinned CPU oracle starts
-    bad = [r for r, d in zip(rows, dl) if d > TF_LOSS or r["logits"] > TF_LOGITS or r["cos_med"] < TF_COS_MED or r["cos_min"] < TF_COS_MIN]
-    assert not bad, bad[:5]
-    assert sum(dl) / len(dl) <= TF_LOSS_MEAN, sum(dl) / len(dl)
-    assert rows[-1]["loss_fp32"] < 0.5 * rows[0]["loss_fp32"]          # the teacher's trajectory is a training run
+    assert_teacher_forced(rows, dl, mean_bound=8.0e-3)

@@ -96,20 +96,24 @@ class Ctx:
                     print("        %.5f %.2e %s" % (cos(e.grad_param_layout(k), v.grad), rel(e.grad_param_layout(k), v.grad), k))
 
 
-def main(spec="tiny", B=4, S=64):
+def main(spec="tiny", B=4, S=64, blocks=("layer2.0", "layer2.1")):
+    """blocks: the bottlenecks to check ("layerL.K"); block K > 0 gets the oracle's own output of blocks 0 .. K-1 as its input"""
     del RESULTS[:]
     c = Ctx(spec, B, S)
     e, t = c.eng, c.taps
     v = "backbone.visual"
     # ---- bottlenecks
-    for (blk, inp, stride, planes, has_ds) in [("layer2.0", "layer1", 2, e.clip.vision_width * 2, True),
-                                               ("layer2.1", None, 1, e.clip.vision_width * 2, False)]:
+    w = e.clip.vision_width
+    for blk in blocks:
+        li, bi = int(blk[5]), int(blk.split(".")[1])
+        planes = w * (1, 2, 4, 8)[li - 1]
         c.begin()
-        if inp is None:
-            with torch.no_grad():
-                x0 = O.bottleneck(r16(t["layer1"]), c.sd, v + ".layer2.0", 2, True, None)
-        else:
-            x0 = t[inp]
+        x0 = t["layer%d" % (li - 1)] if li > 1 else t["stem"]
+        with torch.no_grad():
+            for k in range(bi):                      # the oracle's own chain up to the block under test
+                x0 = O.bottleneck(r16(x0), c.sd, "%s.layer%d.%d" % (v, li, k), 2 if (li > 1 and k == 0) else 1, True, None)
+        stride = 2 if (li > 1 and bi == 0) else 1
+        has_ds = bi == 0
         xl = r16(x0).requires_grad_(True)
         ref = O.bottleneck(xl, c.leaf, "%s.%s" % (v, blk), stride, True, None)
         gout = rand_like(ref, 1)
@@ -117,7 +121,7 @@ def main(spec="tiny", B=4, S=64):
         xa = to_act(r16(x0))
         z = e._bottleneck(xa, "%s.%s" % (v, blk), planes, stride, has_ds)
         set_grad(z, gout)
-        c.finish("bottleneck " + blk, [("out", nhwc_to_nchw(z), ref), ("dx", None, None)][:1] , "%s.%s" % (v, blk))
+        c.finish("bottleneck " + blk, [("out", nhwc_to_nchw(z), ref)], "%s.%s" % (v, blk))
         print("      dx: rel %.2e cos %.5f" % record("bottleneck " + blk, "dx", grad_nchw(xa), xl.grad))
     # ---- attnpool
     c.begin()
@@ -211,4 +215,4 @@ def main(spec="tiny", B=4, S=64):
 
 
 if __name__ == "__main__":
-    main(*(sys.argv[1:2] or ["tiny"]), *[int(a) for a in sys.argv[2:4]])
+    main(*(sys.argv[1:2] or ["tiny"]), *[int(a) for a in sys.argv[2:4]], **({"blocks": tuple(sys.argv[4].split(","))} if len(sys.argv) > 4 else {}))
