@@ -20,6 +20,7 @@ extern "C" int cris_sizeof(const char* name) {
 #define S(n) if (!strcmp(name, #n)) return (int)sizeof(n)
     S(cris_conv_gemm_params);
     S(cris_wgrad_params);
+    S(cris_conv_gemm_group);
     S(cris_wgrad_group);
     S(cris_pack_desc);
     S(cris_bn_apply_params);

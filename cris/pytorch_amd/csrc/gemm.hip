@@ -42,8 +42,10 @@
 // first group takes the even ones), so a block holds two independent MFMA / LDS dependency chains per SIMD instead of one; the
 // second group's accumulators are added to the first's through LDS at the end (fixed order: even steps + odd steps) and the
 // first group runs the epilogue.  For the mid-size problems whose grids put barely one block on a CU.
+// `bid`: the tile of the problem this block computes, in the XCD-aware order of the launch (conv_gemm_kernel: one problem
+// per launch; conv_gemm_group_kernel: several independent problems, see cris_conv_gemm_group).
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, int MT_ = 32, int KS = 1>
-__global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const cris_conv_gemm_params p) {
+__device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, int bid, unsigned char* smem) {
     constexpr int WTM = BM / WAVES_M;          // wave tile rows
     constexpr int WTN = BN / WAVES_N;
     // v_mfma_f32_32x32x16_bf16: one 16-B A chunk + one 16-B B chunk per lane feed 32x32x16 MACs - half the LDS read
@@ -58,7 +60,6 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const cris_conv_gem
     constexpr int NB = BN / 32;
     constexpr int A_BYTES = BM * 128;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -75,13 +76,6 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const cris_conv_gem
     // fastest keeps ONE 128-column weight panel resident and streams the (much smaller per tile) activation rows once.
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     int tile_m, tile_n;
     if ((long)p.N * p.K > (1L << 20)) {
         tile_n = bid / tiles_m;
@@ -283,6 +277,28 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const cris_conv_gem
                 for (int r = 0; r < NR; ++r) acc[i][j][r] += xch[(i * FN + j) * NR + r];
     }
     gemm_epilogue<EPI, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, int MT_ = 32, int KS = 1>
+__global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const cris_conv_gemm_params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    conv_gemm_tile<BM, BN, WAVES_M, WAVES_N, STAGES, EPI, MT_, KS>(p, cris_xcd_logical_block(blockIdx.x, gridDim.x), smem);
+}
+
+// Several INDEPENDENT problems in one launch (cris_conv_gemm_group): the problem table travels by value in the kernel arguments
+// (scalar loads from the kernarg segment: the index is block-uniform), each block finds its problem from the prefix sums of the
+// tile counts.  What it buys: the mid-size layers (M <= 5408) put 1 - 3 blocks on a CU and spend 40 - 60 % of their 13 - 30 us in
+// launch latency, prologue and epilogue; q / k / v projections, the three f4_proj convolutions of the neck, a Bottleneck's
+// conv1 + downsample ... do not depend on each other, so their tiles share one grid, one dispatch and each other's tails.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI>
+__global__ __launch_bounds__(256) void conv_gemm_group_kernel(const cris_conv_gemm_group g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lb = cris_xcd_logical_block(blockIdx.x, gridDim.x);
+    int pi = 0;                                    // block-uniform; entries >= g.n hold the total block count (> lb)
+#pragma unroll
+    for (int i = 1; i < CRIS_GEMM_GROUP_MAX; ++i) pi += g.block_start[i] <= lb ? 1 : 0;
+    const cris_conv_gemm_params p = g.prob[pi];
+    conv_gemm_tile<BM, BN, WAVES_M, WAVES_N, STAGES, EPI>(p, lb - g.block_start[pi], smem);
 }
 
 // Skinny kernel (M <= FM*16 rows, 1x1 geometry: text encoder / per-sample vectors).  Such GEMMs are pure latency: one
@@ -612,6 +628,10 @@ extern "C" long cris_conv_gemm_ws_floats(const cris_conv_gemm_params* p, int var
     if (v != V_SKINNY9S) return 0;
     return (long)skinny_split_slices(*p) * cris_cdiv(p->N, 32) * (9 * 2 * 256);
 }
+extern "C" int cris_conv_gemm_plan(const cris_conv_gemm_params* p, int variant, int* epilogue) {
+    if (epilogue) *epilogue = epilogue_kind(*p);
+    return resolve_variant(*p, variant);
+}
 extern "C" int cris_conv_gemm_num_variants(void) { return V_COUNT; }
 extern "C" const char* cris_conv_gemm_variant_name(int v) {
     static const char* names[V_COUNT] = {"skinny1", "skinny9", "skinny9s", "128x64", "64x64", "64x128", "128x128", "8w256x256", "8w256x128", "8w128x256", "8w128x128", "64x64k2"};
@@ -624,8 +644,62 @@ static int set_lds(const void* kern, int bytes) {
 
 extern "C" int cris_conv_gemm(const cris_conv_gemm_params* pp, void* stream) { return cris_conv_gemm_variant(pp, -1, stream); }
 
-extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int variant, void* stream) {
-    const cris_conv_gemm_params& p = *pp;
+static int conv_gemm_check(const cris_conv_gemm_params& p);
+int cris_launch_gemm8_group(const cris_conv_gemm_group& g, int nblocks, int epi, hipStream_t s);       // gemm8.hip
+
+extern "C" int cris_conv_gemm_group_launch(const cris_conv_gemm_group* gp, int variant, void* stream) {
+    CRIS_CHECK_ARG(gp && gp->n > 0 && gp->n <= CRIS_GEMM_GROUP_MAX, "1 .. CRIS_GEMM_GROUP_MAX problems per launch");
+    CRIS_CHECK_ARG(variant == V_128x64 || variant == V_64x64 || variant == V_64x128 || variant == V_128x128 || variant == V_8W_128x128,
+                   "group launches run the 4-wave tiles or the 8-wave 128x128 tile");
+    if (gp->n == 1) return cris_conv_gemm_variant(&gp->prob[0], variant, stream);
+    cris_conv_gemm_group g = *gp;
+    static const int bm[V_COUNT] = {0, 0, 0, 128, 64, 64, 128, 256, 256, 128, 128, 64}, bn[V_COUNT] = {0, 0, 0, 64, 64, 128, 128, 256, 128, 256, 128, 64};
+    const int epi = epilogue_kind(g.prob[0]);
+    int start = 0;
+    for (int i = 0; i < g.n; ++i) {
+        const cris_conv_gemm_params& p = g.prob[i];
+        if (conv_gemm_check(p) != 0) return -1;
+        CRIS_CHECK_ARG(epilogue_kind(p) == epi, "the problems of a group must share the epilogue instantiation");
+        CRIS_CHECK_ARG(variant_applicable(variant, p), "tile variant not applicable to a problem of the group");
+        g.block_start[i] = start;
+        start += cris_cdiv(p.M, bm[variant]) * cris_cdiv(p.N, bn[variant]);
+    }
+    for (int i = g.n; i <= CRIS_GEMM_GROUP_MAX; ++i) g.block_start[i] = start;
+    hipStream_t s = (hipStream_t)stream;
+    if (variant == V_8W_128x128) return cris_launch_gemm8_group(g, start, epi, s);
+    constexpr int LDS_128x64 = ST_128x64 * (128 + 64) * 128, LDS_64x128 = ST_64x128 * (64 + 128) * 128;
+    constexpr int LDS_128x128 = ST_128x128 * (128 + 128) * 128, LDS_64x64 = ST_64x64 * (64 + 64) * 128;
+    typedef void (*kern_t)(const cris_conv_gemm_group);
+    static const kern_t k_128x64[3] = {conv_gemm_group_kernel<128, 64, 4, 1, ST_128x64, 0>, conv_gemm_group_kernel<128, 64, 4, 1, ST_128x64, 1>,
+                                       conv_gemm_group_kernel<128, 64, 4, 1, ST_128x64, 2>};
+    static const kern_t k_64x128[3] = {conv_gemm_group_kernel<64, 128, 2, 2, ST_64x128, 0>, conv_gemm_group_kernel<64, 128, 2, 2, ST_64x128, 1>,
+                                       conv_gemm_group_kernel<64, 128, 2, 2, ST_64x128, 2>};
+    static const kern_t k_128x128[3] = {conv_gemm_group_kernel<128, 128, 2, 2, ST_128x128, 0>, conv_gemm_group_kernel<128, 128, 2, 2, ST_128x128, 1>,
+                                        conv_gemm_group_kernel<128, 128, 2, 2, ST_128x128, 2>};
+    static const kern_t k_64x64[3] = {conv_gemm_group_kernel<64, 64, 2, 2, ST_64x64, 0>, conv_gemm_group_kernel<64, 64, 2, 2, ST_64x64, 1>,
+                                      conv_gemm_group_kernel<64, 64, 2, 2, ST_64x64, 2>};
+    static const int lds_ready = [&]() {
+        int rc = 0;
+        for (int e = 0; e < 3; ++e)
+            rc |= set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
+                  set_lds((const void*)k_128x128[e], LDS_128x128) | set_lds((const void*)k_64x64[e], LDS_64x64);
+        return rc;
+    }();
+    if (lds_ready != 0) {
+        cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, lds_ready);
+        return lds_ready;
+    }
+    switch (variant) {
+        case V_128x64: hipLaunchKernelGGL(k_128x64[epi], dim3(start), dim3(256), LDS_128x64, s, g); break;
+        case V_64x64: hipLaunchKernelGGL(k_64x64[epi], dim3(start), dim3(256), LDS_64x64, s, g); break;
+        case V_64x128: hipLaunchKernelGGL(k_64x128[epi], dim3(start), dim3(256), LDS_64x128, s, g); break;
+        default: hipLaunchKernelGGL(k_128x128[epi], dim3(start), dim3(256), LDS_128x128, s, g);
+    }
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+static int conv_gemm_check(const cris_conv_gemm_params& p) {
     CRIS_CHECK_ARG(p.A && p.Wt, "null operand");
     CRIS_CHECK_ARG(p.M > 0 && p.N > 0 && p.K > 0, "empty problem");
     CRIS_CHECK_ARG((p.C & 7) == 0 && (p.lda & 7) == 0 && (p.a_coff & 7) == 0, "A channels/ld/offset must be multiples of 8");
@@ -640,6 +714,12 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     CRIS_CHECK_ARG((size_t)p.Bn * p.H * p.W * p.lda * 2 < (1UL << 31) && ((size_t)p.N + 256) * p.ldb * 2 < (1UL << 31) &&
                        (!p.out || (size_t)p.M * p.ldc * 4 < (1UL << 31)) && (!p.resid || (size_t)p.M * p.ldr * 4 < (1UL << 31)),
                    "operand extent must stay below 2 GiB (32-bit buffer offsets)");
+    return 0;
+}
+
+extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int variant, void* stream) {
+    const cris_conv_gemm_params& p = *pp;
+    if (conv_gemm_check(p) != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     // <= 72 KB per block: two blocks (8 waves) share a CU's 160 KB LDS and hide each other's barriers / epilogues
     constexpr int LDS_128x64 = ST_128x64 * (128 + 64) * 128, LDS_64x128 = ST_64x128 * (64 + 128) * 128;
@@ -672,8 +752,11 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
         return lds_ready;
     }
     const int lean = epilogue_kind(p);
-    const int v = resolve_variant(p, variant);
+    int v = resolve_variant(p, variant);
     CRIS_CHECK_ARG(v >= 0, "tile variant not applicable to this problem");
+    // automatic choice without a workspace (a caller that predates the `ws` field): the single-pass skinny kernel (same rows
+    // per statistics partial as the split-K one) instead of an error
+    if (variant < 0 && v == V_SKINNY9S && !p.ws) v = V_SKINNY9;
     switch (v) {
         case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128:
             return cris_launch_gemm8(v - V_8W_256x256, p, lean, s);

@@ -60,8 +60,9 @@
 //   of 8 MFMAs per K-tile, 3 K-tile buffers (144 KB);  (1,1): 128x128, one phase of 8 MFMAs per K-tile, FIVE K-tile buffers
 //   (160 KB): the variant for problems of at most ~one tile per CU (mid-size layers), whose loop is bound by the operand
 //   latency - three K-tiles (96 KB) stay in flight per CU against one or two with the 4-wave tiles' rings
+// `bid`: the tile of the problem this block computes, in the XCD-aware order of the launch
 template <int PA, int PB, int EPI>
-__global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_params p) {
+__device__ __forceinline__ void conv_gemm8_tile(const cris_conv_gemm_params& p, int bid, unsigned char* smem) {
     constexpr int WTM = PA * 64, WTN = PB * 32;
     constexpr int BM = 2 * WTM, BN = 4 * WTN;
     constexpr int FM = PA * 2, FN = PB;
@@ -70,23 +71,15 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
     constexpr int NBUF = S4 ? 2 : S1 ? 5 : 3;
     constexpr bool DMA_IN_MFMA = (!S4) != ((G8_ABL & 128) != 0);      // where a phase issues its LDS-DMAs (see G8_ABL bit 7)
     constexpr int A_BYTES = BM * 128, TILE_BYTES = (BM + BN) * 128;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    // XCD-aware tile order, as in gemm.hip
+    // (XCD-aware tile order, as in gemm.hip: cris_xcd_logical_block in the kernels below)
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;
-    {
-        const int q = ntiles >> 3, r = ntiles & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
     // which index runs fastest inside an XCD's run of tiles (probe A/B, profiles/r03_gemm8_probe.md): the 256x256 tile keeps an
     // A panel and sweeps the (few) column tiles - the two blocks that share an activation panel run side by side on one L2,
     // 191 against 198 us at M 86528 / N 512 / K 2304; the 128x128 tile keeps a weight panel (35.5 against 39.8 us at
@@ -383,6 +376,24 @@ __global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_pa
     gemm_epilogue<EPI, 32, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * 2 + wm, lane);
 }
 
+template <int PA, int PB, int EPI>
+__global__ __launch_bounds__(512) void conv_gemm8_kernel(const cris_conv_gemm_params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    conv_gemm8_tile<PA, PB, EPI>(p, cris_xcd_logical_block(blockIdx.x, gridDim.x), smem);
+}
+
+// several independent problems on the 128x128 tile in one launch (cris_conv_gemm_group_launch, see gemm.hip)
+template <int EPI>
+__global__ __launch_bounds__(512) void conv_gemm8_group_kernel(const cris_conv_gemm_group g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lb = cris_xcd_logical_block(blockIdx.x, gridDim.x);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < CRIS_GEMM_GROUP_MAX; ++i) pi += g.block_start[i] <= lb ? 1 : 0;
+    const cris_conv_gemm_params p = g.prob[pi];
+    conv_gemm8_tile<1, 1, EPI>(p, lb - g.block_start[pi], smem);
+}
+
 static int set_lds8(const void* kern, int bytes) {
     return (int)hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
@@ -410,6 +421,21 @@ int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipS
     CRIS_CHECK_ARG(variant >= 0 && variant < 4, "unknown 8-wave variant");
     CRIS_CHECK_ARG((p.C & 63) == 0, "8-wave tiles need C % 64 == 0");
     hipLaunchKernelGGL(k[variant][epi], dim3(cris_cdiv(p.M, bm[variant]) * cris_cdiv(p.N, bn[variant])), dim3(512), lds[variant], s, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+int cris_launch_gemm8_group(const cris_conv_gemm_group& g, int nblocks, int epi, hipStream_t s) {
+    typedef void (*kern_t)(const cris_conv_gemm_group);
+    static const kern_t k[3] = {conv_gemm8_group_kernel<0>, conv_gemm8_group_kernel<1>, conv_gemm8_group_kernel<2>};
+    constexpr int LDS = 5 * (128 + 128) * 128;
+    static const int ready = set_lds8((const void*)k[0], LDS) | set_lds8((const void*)k[1], LDS) | set_lds8((const void*)k[2], LDS);
+    if (ready != 0) {
+        cris_set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed (%d)", __func__, ready);
+        return ready;
+    }
+    for (int i = 0; i < g.n; ++i) CRIS_CHECK_ARG((g.prob[i].C & 63) == 0, "8-wave tiles need C % 64 == 0");
+    hipLaunchKernelGGL(k[epi], dim3(nblocks), dim3(512), LDS, s, g);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -9,6 +9,17 @@
 #ifndef CRIS_FAST_EPILOGUE
 #define CRIS_FAST_EPILOGUE 1      // 0: always the general epilogue (A/B builds)
 #endif
+#ifndef CRIS_FAST_EPILOGUE_GEN
+#define CRIS_FAST_EPILOGUE_GEN 1  // 0: EPI 0 always takes the general form (A/B builds)
+#endif
+
+// XCD-aware block order: blocks b, b+8, b+16 .. run on the same XCD (round-robin dispatch); XCD x gets the CONTIGUOUS run of
+// logical blocks [x*total/8, (x+1)*total/8) so that its private L2 keeps the operand panel the run shares
+__device__ __forceinline__ int cris_xcd_logical_block(int bid, int total) {
+    const int q = total >> 3, r = total & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; rows are 128 B (64 bf16)
     return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
@@ -96,6 +107,119 @@ __device__ __forceinline__ void gemm_epilogue_fast32(const cris_conv_gemm_params
     }
 }
 
+// The same treatment for the GENERAL epilogue (EPI 0) of an interior wave tile of 32x32 fragments: per-column bias, ReLU /
+// QuickGELU, bf16 or fp32 residual and output, the head-split transposed copy, BatchNorm partials - the projections of the
+// decoder / attention pool / text encoder (bias + transposed copy) and the fp32 residual-stream writers.  Dropout stays on the
+// general form (three launches per step).  Same values as the general form: same operation order per element, f2bf() == the
+// hardware conversion on every finite value.  The (batch, token) position of a row for the transposed copy is carried along
+// the rows of the wave tile (one division per call instead of one per 4-row group); T_L >= 8 so that a step of 8 rows wraps
+// at most once.
+template <bool RES_F32, bool OUT_F32, int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_fast32_gen(const cris_conv_gemm_params& p, f32x16 (&acc)[FM][FN], int row0, int col0, int part,
+                                                         int lane) {
+    const int fr = lane & 31, fg = lane >> 5;
+    const bool has_res = p.resid != nullptr, has_out = p.out != nullptr, has_T = p.outT != nullptr;
+    constexpr unsigned RES = RES_F32 ? 4u : 2u, OES = OUT_F32 ? 4u : 2u;
+    const int act = p.act;
+    const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, has_out ? (int)((size_t)p.M * p.ldc * OES) : 0, CRIS_BUF_FLAGS);
+    const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.resid), 0,
+                                                                        has_res ? (int)((size_t)p.M * p.ldr * RES) : 0, CRIS_BUF_FLAGS);
+    unsigned vo[4], vr[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        vo[r] = has_out ? ((unsigned)(row0 + fg * 4 + r) * (unsigned)p.ldc + (unsigned)(p.c_coff + col0 + fr)) * OES : CRIS_OOB;
+        vr[r] = has_res ? ((unsigned)(row0 + fg * 4 + r) * (unsigned)p.ldr + (unsigned)(p.r_coff + col0 + fr)) * RES : CRIS_OOB;
+    }
+    // transposed copy: (batch, token) of this lane's first row
+    int tb0 = 0, tl0 = 0;
+    const bool t_pack = has_T && (p.T_L & 3) == 0;
+    if (has_T) {
+        const int m = row0 + fg * 4;
+        tb0 = m / p.T_L;
+        tl0 = m - tb0 * p.T_L;
+    }
+    const unsigned t_bstride = (unsigned)p.T_E * (unsigned)p.T_Lpad;           // elements between batches in one section
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int col = col0 + j * 32 + fr;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+        bf16_t* tcol = nullptr;
+        if (has_T) {
+            const int sec = col / p.T_E;
+            const int e_ = col - sec * p.T_E;
+            tcol = p.outT + (size_t)sec * p.T_sec_stride + (size_t)e_ * p.T_Lpad;
+        }
+        int tb = tb0, tl = tl0;
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            float rres[16];
+            if (has_res) {                          // wave-uniform: one branch per fragment, all 16 loads in flight together
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int sr = ((i * 32 + (e >> 2) * 8) * p.ldr + j * 32) * (int)RES;
+                    if constexpr (RES_F32) rres[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, vr[e & 3], sr, 0));
+                    else rres[e] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsR, vr[e & 3], sr, 0));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) rres[e] = 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int so = ((i * 32 + (e >> 2) * 8) * p.ldc + j * 32) * (int)OES;
+                float x = acc[i][j][e] + bias;
+                if (act == 1) x = fmaxf(x, 0.f);
+                else if (act == 2) x = x / (1.0f + __expf(-1.702f * x));
+                x += rres[e];
+                if (act == 3) x = fmaxf(x, 0.f);
+                acc[i][j][e] = x;
+                s1 += x;
+                if constexpr (OUT_F32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, vo[e & 3], so, 0);
+                else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf_hw(x), rsO, vo[e & 3], so, 0);
+            }
+            if (has_T) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    // rows (i*32 + g*8 + fg*4) .. +3 of this column: (tb, tl) is the position of the first of them
+                    if (t_pack) {                   // T_L % 4 == 0: the four rows are four consecutive tokens of one sample
+                        uint2 w;
+                        w.x = (uint32_t)f2bf_hw(acc[i][j][g * 4 + 0]) | ((uint32_t)f2bf_hw(acc[i][j][g * 4 + 1]) << 16);
+                        w.y = (uint32_t)f2bf_hw(acc[i][j][g * 4 + 2]) | ((uint32_t)f2bf_hw(acc[i][j][g * 4 + 3]) << 16);
+                        *reinterpret_cast<uint2*>(tcol + (size_t)((unsigned)tb * t_bstride + (unsigned)tl)) = w;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            int lr = tl + r, br = tb;
+                            if (lr >= p.T_L) { lr -= p.T_L; ++br; }
+                            tcol[(size_t)((unsigned)br * t_bstride + (unsigned)lr)] = f2bf_hw(acc[i][j][g * 4 + r]);
+                        }
+                    }
+                    tl += 8;                        // next 4-row group of this lane: 8 rows further
+                    if (tl >= p.T_L) { tl -= p.T_L; ++tb; }
+                }
+            }
+        }
+        if (p.colsum) {
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mu = s1 / (float)(FM * 32);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const float d = acc[i][j][e] - mu;
+                    q += d * d;
+                }
+            q += __shfl_xor(q, 32, 64);
+            if (fg == 0) {
+                p.colsum[(size_t)part * p.N + col] = s1;
+                p.colsq[(size_t)part * p.N + col] = q;
+            }
+        }
+    }
+}
+
 // Epilogue of one wave tile (FM x FN fragments of 16x16, C/D layout col = lane&15, row = (lane>>4)*4 + r) whose first
 // row / column are row0 / col0: bias, activation, dropout, residual, bf16|fp32 store, head-split transposed copy and the
 // BatchNorm statistics partial `part` (sum, M2 about the part mean over the FM*16 rows of this wave tile).
@@ -115,6 +239,15 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
         if (p.out && row0 + FM * 32 <= p.M && col0 + FN * 32 <= p.N && CRIS_FAST_EPILOGUE) {
             gemm_epilogue_fast32<EPI, FM, FN>(p, acc, row0, col0, part, lane);
             return;
+        }
+    }
+    if constexpr (EPI == 0 && MT == 32 && std::is_same<ACC, f32x16>::value) {
+        // interior wave tile, no dropout: the cheap general form (bias / activation / fp32 streams / transposed copy)
+        if (CRIS_FAST_EPILOGUE_GEN && row0 + FM * 32 <= p.M && col0 + FN * 32 <= p.N && p.drop_thresh == 0u && (!p.outT || p.T_L >= 8)) {
+            const bool rf = p.resid && p.resid_f32, of = p.out && p.out_f32;
+            if (!rf && !of) { gemm_epilogue_fast32_gen<false, false, FM, FN>(p, acc, row0, col0, part, lane); return; }
+            if (rf && of) { gemm_epilogue_fast32_gen<true, true, FM, FN>(p, acc, row0, col0, part, lane); return; }
+            if (!p.resid && of) { gemm_epilogue_fast32_gen<false, true, FM, FN>(p, acc, row0, col0, part, lane); return; }
         }
     }
     constexpr bool LEAN = EPI != 0;

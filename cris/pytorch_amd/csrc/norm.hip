@@ -1128,9 +1128,9 @@ extern "C" int cris_ln_fwd(const cris_ln_fwd_params* pp, void* stream) {
 }
 
 // V = 8-channel vectors per lane (C <= 512 V).  V = 4 serves every C <= 2048 and is what runs by default; the narrower instantiations
-// (CRIS_LN_BWD_V=1: V = 1 / 2 for C <= 512 / 1024) keep a quarter / half of the registers - the V = 4 kernel holds 238 VGPRs, two
-// waves per SIMD, for rows of which a C = 512 LayerNorm uses one vector.  Built in round 3 after the GPU budget was spent: not yet
-// run (the default path is unchanged); to be measured first thing next round together with a larger grid.
+// (V = 1 / 2 for C <= 512 / 1024; CRIS_LN_BWD_V=0 switches them off) keep a quarter / half of the registers - the V = 4 kernel holds
+// 238 VGPRs, two waves per SIMD, for rows of which a C = 512 LayerNorm uses one vector.  Measured in round 4 (call r04a): 12.188
+// against 12.280 ms per step with the default grid (a grid of 1024 blocks gives the gain back: 12.276); default since.
 template <int V>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p) {
     __shared__ float sg[2][64 * 8 * V];        // dgamma / dbeta block accumulators
@@ -1262,7 +1262,7 @@ extern "C" int cris_ln_bwd(const cris_ln_bwd_params* pp, void* stream) {
     CRIS_CHECK_ARG(p.dy || p.dypos || p.dout_f32, "no incoming gradient");
     CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 64 * 8 * LN_MAXV && (p.ldx & 7) == 0, "C must be a multiple of 8, <= 2048");
     CRIS_CHECK_ARG(!p.dx_accum || p.dx_f32, "accumulate only into fp32");
-    static const int narrow = cris_env_int("CRIS_LN_BWD_V", 0);
+    static const int narrow = cris_env_int("CRIS_LN_BWD_V", 1);
     const dim3 grid(ln_bwd_grid(p.rows));        // (= the rows of the partials table the caller sized with cris_ln_bwd_parts)
     if (narrow && p.C <= 512) hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, p);
     else if (narrow && p.C <= 1024) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, p);

@@ -65,6 +65,14 @@ class Act:
         return r._g, True
 
 
+class GemmGroup:
+    """forward (f) and backward (b) launch queues of one group of independent GEMM layers (Engine.group_begin)"""
+    __slots__ = ("f", "b")
+
+    def __init__(self):
+        self.f, self.b = ops.GemmQueue(), ops.GemmQueue()
+
+
 class Comm:
     """Cross-rank hooks used by SyncBN / gradient averaging (dist.py provides the RCCL implementation)."""
     world = 1
@@ -312,10 +320,14 @@ class Engine:
     # ------------------------------------------------------------------------------------------
     def gemm(self, x: Act, wname: str, N: int, *, k=1, pad=0, rows=None, bias: Optional[str] = None, out: Optional[Act] = None,
              out_f32=False, resid: Optional[Act] = None, drop: Drop = NO_DROP, stats=False, outT=None, geom: Optional[Geom] = None,
-             no_dgrad=False, stream_grad: Optional[Act] = None, w_transposed=False):
+             no_dgrad=False, stream_grad: Optional[Act] = None, w_transposed=False, group: Optional["GemmGroup"] = None,
+             group_bwd=True, variant=-1):
         """y = conv_k(x) with weight `wname` (rows n0:n1 of it when `rows`), optional bias / residual / dropout /
         BN statistics / transposed head-split copy.  `stream_grad`: fp32 residual-stream Act whose gradient is the
-        gradient of this layer's output (post dropout) - used for `x + dropout(linear(..))` branches."""
+        gradient of this layer's output (post dropout) - used for `x + dropout(linear(..))` branches.
+        `group` (see group_begin): the forward launch waits for group_end() and runs together with the group's other members;
+        with `group_bwd` its input-gradient GEMM does the same in backward (only when no other member writes x's gradient).
+        `variant`: tile variant forced for the forward and input-gradient launches (grouped launches share one tile)."""
         g = geom or Geom(x.Bn, x.H, x.W, x.C, k, k, 1, pad)
         Wf, Wd = self.WF[wname], self.WD.get(wname)
         Gw = self.G[wname]
@@ -336,7 +348,7 @@ class Engine:
         st = ops.conv_gemm(x.t, Wf, g, N, lda=x.ld, a_coff=x.coff, ldb=ldbF, bias=bias_t,
                            resid=None if resid is None else resid.t, ldr=None if resid is None else resid.ld,
                            r_coff=0 if resid is None else resid.coff, out=out.t, ldc=out.ld, c_coff=out.coff,
-                           stats=stats, drop=drop, **kw)
+                           stats=stats, drop=drop, variant=variant, queue=None if group is None else group.f, **kw)
         if not self.training:
             return (out, st) if stats else out
 
@@ -365,10 +377,31 @@ class Engine:
             if dT is not None:
                 tkw = dict(outT=dT["buf"], T_L=dT["L"], T_Lpad=dT["Lpad"], T_E=dT["E"], T_sec_stride=dT["sec_stride"])
             ops.conv_gemm(gy, wd, gD, Wd.shape[0], lda=gy_ld, a_coff=gy_coff, ldb=Wd.shape[1], out=gx, ldc=x.ld, c_coff=x.coff,
-                          resid=gx if acc else None, ldr=x.ld, r_coff=x.coff, **tkw)
+                          resid=gx if acc else None, ldr=x.ld, r_coff=x.coff, variant=variant,
+                          queue=group.b if (group is not None and group_bwd) else None, **tkw)
 
         self.tape.append(bwd)
         return (out, st) if stats else out
+
+    def group_begin(self) -> "GemmGroup":
+        """Open a group of INDEPENDENT GEMM layers: gemm(..., group=G) defers its forward launch to group_end(G), where the
+        members run as grouped launches (ops.GemmQueue: one launch per tile variant / epilogue kind present); in backward the
+        members' input-gradient GEMMs wait for the closure appended here, which runs after theirs."""
+        G = GemmGroup()
+        if self.training:
+            self.tape.append(G.b.flush)
+        return G
+
+    def group_end(self, G: "GemmGroup"):
+        G.f.flush()
+
+    @staticmethod
+    def _group_variant(site, default):
+        """tile variant forced on the members of a group whose own choices differ (CRIS_GROUP_VARIANT_<SITE> overrides; "auto":
+        every member keeps its own tile and only equal ones share a launch)"""
+        import os
+        v = os.environ.get("CRIS_GROUP_VARIANT_" + site.upper(), default)
+        return -1 if v == "auto" else v
 
     # ------------------------------------------------------------------------------------------
     # BatchNorm layer
@@ -534,10 +567,10 @@ class Engine:
     # network pieces
     # ------------------------------------------------------------------------------------------
     def _bottleneck(self, x: Act, p: str, planes: int, stride: int, has_ds: bool) -> Act:
-        a1 = self.conv_bn(x, p + ".conv1", p + ".bn1", planes)
-        a2 = self.conv_bn(a1, p + ".conv2", p + ".bn2", planes, k=3, pad=1, pool=stride > 1)
-        y3, st3 = self.gemm(a2, p + ".conv3.weight", planes * 4, stats=True)
         if has_ds:
+            # conv1 and the downsample convolution (model/clip.py:44-53) read the block's input and nothing of each other: one
+            # grouped launch forward; backward too when the downsample branch goes through the average pool (stride 2) - with
+            # stride 1 both input gradients accumulate into the SAME buffer, so they stay two launches there
             xi = x
             if stride > 1:
                 xi = self.new_act(x.Bn, x.H // 2, x.W // 2, x.C)
@@ -546,8 +579,17 @@ class Engine:
                     def bwd(xi=xi):
                         gx, acc = x.grad_target()
                         ops.avgpool2_bwd(xi.g, x.Bn, x.H, x.W, x.C, gx, lddx=x.ld, dxcoff=x.coff, accum=acc)
-                    self.tape.append(bwd)
-            yd, std = self.gemm(xi, p + ".downsample.0.weight", planes * 4, stats=True)
+                    self.tape.append(bwd)            # (backward: after the group's flush below, i.e. after conv1's dgrad wrote x.g)
+            G = self.group_begin()
+            y1, st1 = self.gemm(x, p + ".conv1.weight", planes, stats=True, group=G, group_bwd=stride > 1)
+            yd, std = self.gemm(xi, p + ".downsample.0.weight", planes * 4, stats=True, group=G, group_bwd=stride > 1)
+            self.group_end(G)
+            a1 = self.bn(y1, st1, p + ".bn1")
+        else:
+            a1 = self.conv_bn(x, p + ".conv1", p + ".bn1", planes)
+        a2 = self.conv_bn(a1, p + ".conv2", p + ".bn2", planes, k=3, pad=1, pool=stride > 1)
+        y3, st3 = self.gemm(a2, p + ".conv3.weight", planes * 4, stats=True)
+        if has_ds:
             return self.bn(y3, st3, p + ".bn3", relu=True, y2=yd, st2=std, pfx2=p + ".downsample.1")
         return self.bn(y3, st3, p + ".bn3", relu=True, ident=x)
 
@@ -582,7 +624,8 @@ class Engine:
         B, H, W, C = x.Bn, x.H, x.W, x.C
         T, G, Hn = H * W, self.clip.pos_grid, self.clip.vis_heads
         Cout = self.clip.embed_dim
-        yc, stc = self.gemm(x, p + ".connect.0.weight", Cout, stats=True)
+        G = self.group_begin()
+        yc, stc = self.gemm(x, p + ".connect.0.weight", Cout, stats=True, group=G, group_bwd=False)
         R = self.table(("bicubic", G, H, W), lambda: tables.bicubic_resize_matrix(G, H, W))
         posr = self.empty(T, C, dtype=F32)
         ops.posresize_fwd(R, self.P[p + ".positional_embedding"], T, G, C, posr)
@@ -597,9 +640,12 @@ class Engine:
                 ops.posresize_bwd(R, dposr, T, G, C, self.G[p + ".positional_embedding"])
             self.tape.append(bwd_tok)
         Tq, Tk, Tv = self.new_T(B, Hn, T), self.new_T(B, Hn, T), self.new_T(B, Hn, T)
-        q = self.gemm(tok, p + ".q_proj.weight", C, bias=p + ".q_proj.bias", outT=Tq)
-        k = self.gemm(tok, p + ".k_proj.weight", C, bias=p + ".k_proj.bias", outT=Tk)
-        vv = self.gemm(tok, p + ".v_proj.weight", C, bias=p + ".v_proj.bias", outT=Tv)
+        # q / k / v (+ the `connect` convolution queued above) are independent: grouped launches forward (model/clip.py:112-139);
+        # their three input gradients accumulate into ONE buffer (tok.g), so backward keeps them apart
+        q = self.gemm(tok, p + ".q_proj.weight", C, bias=p + ".q_proj.bias", outT=Tq, group=G, group_bwd=False)
+        k = self.gemm(tok, p + ".k_proj.weight", C, bias=p + ".k_proj.bias", outT=Tk, group=G, group_bwd=False)
+        vv = self.gemm(tok, p + ".v_proj.weight", C, bias=p + ".v_proj.bias", outT=Tv, group=G, group_bwd=False)
+        self.group_end(G)
         o, dOt = self.attention(q, k, vv, Tq["buf"], Tk["buf"], Tv["buf"], B, Hn, T, T)
         c = self.gemm(o, p + ".c_proj.weight", Cout, bias=p + ".c_proj.bias")
         self._patch_outT_on_dgrad(dOt)
@@ -714,9 +760,17 @@ class Engine:
         f3 = self.conv_bn(cat3, n + ".f3_cat.0", n + ".f3_cat.1", fo[1])
         # fusion 4
         cat4 = self.new_act(v4.Bn, v4.H, v4.W, 3 * fo[1])
-        fq5 = self.conv_bn(f5, n + ".f4_proj5.0", n + ".f4_proj5.1", fo[1], k=3, pad=1)
-        self.conv_bn(f4, n + ".f4_proj4.0", n + ".f4_proj4.1", fo[1], k=3, pad=1, out=cat4.slice(fo[1], fo[1]))
-        self.conv_bn(f3, n + ".f4_proj3.0", n + ".f4_proj3.1", fo[1], k=3, pad=1, out=cat4.slice(0, fo[1]))
+        # the three 3x3 convolutions of fusion 4 (model/layers.py:300-302) read f5 / f4 / f3 and write three buffers; their input
+        # gradients go to three buffers as well: one grouped launch each way, on the tile the two larger ones would pick alone
+        G = self.group_begin()
+        gv = self._group_variant("f4_proj", "8w128x128" if all(c % 64 == 0 for c in (f5.C, f4.C, f3.C, fo[1])) else "64x128")
+        y5p, s5p = self.gemm(f5, n + ".f4_proj5.0.weight", fo[1], k=3, pad=1, stats=True, group=G, variant=gv)
+        y4p, s4p = self.gemm(f4, n + ".f4_proj4.0.weight", fo[1], k=3, pad=1, stats=True, group=G, variant=gv)
+        y3p, s3p = self.gemm(f3, n + ".f4_proj3.0.weight", fo[1], k=3, pad=1, stats=True, group=G, variant=gv)
+        self.group_end(G)
+        fq5 = self.bn(y5p, s5p, n + ".f4_proj5.1")
+        self.bn(y4p, s4p, n + ".f4_proj4.1", out=cat4.slice(fo[1], fo[1]))
+        self.bn(y3p, s3p, n + ".f4_proj3.1", out=cat4.slice(0, fo[1]))
         self._upsample(fq5, cat4.slice(2 * fo[1], fo[1]))
         # aggregation + CoordConv (2 coordinate channels, zero padded to a multiple of 8)
         cc = self.new_act(v4.Bn, v4.H, v4.W, pad8(fo[1] + 2))
@@ -768,8 +822,12 @@ class Engine:
             # --- self attention ---
             v2, qk, _ = self.ln(vis, p + ".norm1", pos=vpos, pos_rows=HW, dx_stream=vis)
             T2, Tv = self.new_T(B, Hn, HW, secs=2), self.new_T(B, Hn, HW)
-            qkp = self.gemm(qk, p + ".self_attn.in_proj_weight", 2 * C, rows=(0, 2 * C), bias=p + ".self_attn.in_proj_bias", outT=T2)
-            vp = self.gemm(v2, p + ".self_attn.in_proj_weight", C, rows=(2 * C, 3 * C), bias=p + ".self_attn.in_proj_bias", outT=Tv)
+            # the q|k projection (of norm1(vis) + pos) and the v projection (of norm1(vis)) are independent, forward and backward
+            # (model/layers.py:202-207): one grouped launch each way
+            G = self.group_begin()
+            qkp = self.gemm(qk, p + ".self_attn.in_proj_weight", 2 * C, rows=(0, 2 * C), bias=p + ".self_attn.in_proj_bias", outT=T2, group=G)
+            vp = self.gemm(v2, p + ".self_attn.in_proj_weight", C, rows=(2 * C, 3 * C), bias=p + ".self_attn.in_proj_bias", outT=Tv, group=G)
+            self.group_end(G)
             o, dOt = self.attention(qkp.slice(0, C), qkp.slice(C, C), vp, T2["buf"][0], T2["buf"][1], Tv["buf"][0], B, Hn, HW, HW,
                                     drop=self.drop(i, 0))
             a = self.gemm(o, p + ".self_attn.out_proj.weight", C, bias=p + ".self_attn.out_proj.bias")
@@ -779,9 +837,12 @@ class Engine:
             _, qc, _ = self.ln(vis1, p + ".norm2", want_y=False, pos=vpos, pos_rows=HW, dx_stream=vis1)
             Tq, Tk, Tvv = self.new_T(B, Hn, HW), self.new_T(B, Hn, L), self.new_T(B, Hn, L)
             m = p + ".multihead_attn"
-            qx = self.gemm(qc, m + ".in_proj_weight", C, rows=(0, C), bias=m + ".in_proj_bias", outT=Tq)
-            kx = self.gemm(txtpos, m + ".in_proj_weight", C, rows=(C, 2 * C), bias=m + ".in_proj_bias", outT=Tk)
-            vx = self.gemm(txt, m + ".in_proj_weight", C, rows=(2 * C, 3 * C), bias=m + ".in_proj_bias", outT=Tvv)
+            # cross attention: q of the pixels, k / v of the words (model/layers.py:235-243) - three inputs, three gradient buffers
+            G = self.group_begin()
+            qx = self.gemm(qc, m + ".in_proj_weight", C, rows=(0, C), bias=m + ".in_proj_bias", outT=Tq, group=G)
+            kx = self.gemm(txtpos, m + ".in_proj_weight", C, rows=(C, 2 * C), bias=m + ".in_proj_bias", outT=Tk, group=G)
+            vx = self.gemm(txt, m + ".in_proj_weight", C, rows=(2 * C, 3 * C), bias=m + ".in_proj_bias", outT=Tvv, group=G)
+            self.group_end(G)
             o2, dOt2 = self.attention(qx, kx, vx, Tq["buf"][0], Tk["buf"][0], Tvv["buf"][0], B, Hn, HW, L, key_tokens=word,
                                       drop=self.drop(i, 2))
             a2 = self.gemm(o2, m + ".out_proj.weight", C, bias=m + ".out_proj.bias")

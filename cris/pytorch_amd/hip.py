@@ -32,6 +32,13 @@ class ConvGemmParams(C.Structure):
                 ("ws", P)]
 
 
+GEMM_GROUP_MAX = 12
+
+
+class ConvGemmGroup(C.Structure):
+    _fields_ = [("n", I), ("block_start", I * (GEMM_GROUP_MAX + 1)), ("prob", ConvGemmParams * GEMM_GROUP_MAX)]
+
+
 class WgradParams(C.Structure):
     _fields_ = [("dY", P), ("X", P), ("dW", P),
                 ("ldy", I), ("y_coff", I), ("N_ld", I),
@@ -197,7 +204,7 @@ class P2PParams(C.Structure):
 
 
 STRUCTS = {
-    "cris_conv_gemm_params": ConvGemmParams, "cris_wgrad_params": WgradParams, "cris_wgrad_group": WgradGroup, "cris_pack_desc": PackDesc,
+    "cris_conv_gemm_params": ConvGemmParams, "cris_conv_gemm_group": ConvGemmGroup, "cris_wgrad_params": WgradParams, "cris_wgrad_group": WgradGroup, "cris_pack_desc": PackDesc,
     "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
     "cris_ln_bwd_params": LnBwdParams, "cris_sum_entry": SumEntry, "cris_sum_group": SumGroup, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams, "cris_zero_ranges": ZeroRanges,
     "cris_sample_desc": SampleDesc, "cris_jpeg_info": JpegInfo, "cris_jpeg_image": JpegImage,
@@ -224,6 +231,8 @@ _SIGS = {
     "cris_conv_gemm_variant_stat_rows": (I, [P, I]),
     "cris_conv_gemm_ws_floats": (L, [P, I]),
     "cris_conv_gemm_num_variants": (I, []),
+    "cris_conv_gemm_plan": (I, [P, I, P]),
+    "cris_conv_gemm_group_launch": (I, [P, I, P]),
     "cris_conv_gemm_variant_name": (C.c_char_p, [I]),
     "cris_bn_partials_rows": (I, [I]),
     "cris_bn_finalize": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P, P]),

@@ -78,12 +78,82 @@ class Drop:
 NO_DROP = Drop(0.0, 0, 0)
 
 
+class GemmQueue:
+    """Independent forward / input-gradient GEMMs launched together (cris_conv_gemm_group_launch): conv_gemm(queue=q) fills the
+    parameter block (and allocates the statistics partials for the tile variant that will run) but defers the launch to
+    q.flush(), which issues one grouped launch per (tile variant, epilogue) present in the queue - longest reductions first.
+    The caller guarantees independence: no queued problem reads or accumulates into what another one writes.  Problems whose
+    own tile choice cannot be grouped (skinny kernels, the larger 8-wave tiles) are launched one by one at the flush.
+    CRIS_GEMM_GROUPS=0 launches every problem alone (A/B)."""
+
+    GROUPABLE = None          # variant ids a group launch can run (filled on first use)
+    enabled = os.environ.get("CRIS_GEMM_GROUPS", "1") != "0"
+
+    def __init__(self):
+        self.items = []        # (params, variant, epilogue, keep-alive tensors, flops, bytes, tag)
+
+    @classmethod
+    def groupable(cls):
+        if cls.GROUPABLE is None:
+            names = gemm_variants()
+            cls.GROUPABLE = {names.index(n) for n in ("128x64", "64x64", "64x128", "128x128", "8w128x128")}
+        return cls.GROUPABLE
+
+    def add(self, p, variant, keep, flops, nbytes, tag):
+        epi = C.c_int(0)
+        v = hip.load().cris_conv_gemm_plan(C.byref(p), variant, C.byref(epi))
+        if v < 0:
+            raise ValueError("GEMM tile variant %r cannot run this problem" % (variant,))
+        self.items.append((p, v, epi.value, keep, flops, nbytes, tag))
+
+    def __len__(self):
+        return len(self.items)
+
+    def flush(self):
+        items, self.items = self.items, []
+        if not items:
+            return
+        groups = {}
+        for it in items:
+            key = (it[1], it[2]) if (self.enabled and it[1] in self.groupable()) else ("solo", id(it))
+            groups.setdefault(key, []).append(it)
+        for key, its in groups.items():
+            if key[0] == "solo":
+                _launch_gemm(its[0][0], its[0][1], its[0][4], its[0][5], its[0][6])
+                continue
+            its.sort(key=lambda it: -it[0].K)                    # stable: longest reductions first
+            for i in range(0, len(its), hip.GEMM_GROUP_MAX):
+                chunk = its[i:i + hip.GEMM_GROUP_MAX]
+                if len(chunk) == 1:
+                    _launch_gemm(chunk[0][0], chunk[0][1], chunk[0][4], chunk[0][5], chunk[0][6])
+                    continue
+                grp = hip.ConvGemmGroup()
+                grp.n = len(chunk)
+                for j, it in enumerate(chunk):
+                    grp.prob[j] = it[0]
+                if KERNEL_TIMER is not None:
+                    KERNEL_TIMER.launch("conv_gemm", sum(it[4] for it in chunk), sum(it[5] for it in chunk), "cris_conv_gemm_group_launch",
+                                        C.byref(grp), key[0], tag="group of %d: %s" % (len(chunk), " + ".join(it[6] for it in chunk)))
+                else:
+                    hip.call("cris_conv_gemm_group_launch", C.byref(grp), key[0], _stream())
+
+
+def _launch_gemm(p, variant, flops, nbytes, tag):
+    if KERNEL_TIMER is not None:
+        # (classified by the problem, not by the kernel that runs it: M <= 144 linears are the text encoder's / per-sample vectors)
+        KERNEL_TIMER.launch("skinny_gemm" if (p.M <= 144 and p.KH == 1) else "conv_gemm", flops, nbytes, "cris_conv_gemm_variant",
+                            C.byref(p), variant, tag=tag)
+        return
+    hip.call("cris_conv_gemm_variant", C.byref(p), variant, _stream())
+
+
 def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None, act=0, resid=None, ldr=None, r_coff=0,
               out=None, ldc=None, c_coff=0, outT=None, T_L=0, T_Lpad=0, T_E=0, T_sec_stride=0, stats=False,
-              drop: Drop = NO_DROP, variant: int = -1):
+              drop: Drop = NO_DROP, variant: int = -1, queue: Optional[GemmQueue] = None):
     """out[M,N] = epi(A_im2col @ Wt^T).  A bf16 NHWC buffer (row stride lda), Wt bf16 [N][ldb].
     stats=True: also returns the BatchNorm statistics partials (Stats) of the output columns.
-    variant: tile variant (index or name, see gemm_variants()); -1 = the library's choice for the problem size."""
+    variant: tile variant (index or name, see gemm_variants()); -1 = the library's choice for the problem size.
+    queue: defer the launch to the queue's flush (grouped with the other independent problems waiting there)."""
     p = hip.ConvGemmParams()
     p.A, p.Wt, p.bias = ptr(A), ptr(Wt), ptr(bias)
     p.lda = lda if lda is not None else A.shape[-1]
@@ -120,13 +190,11 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     nws = hip.load().cris_conv_gemm_ws_floats(C.byref(p), variant)
     ws = torch.empty(nws, dtype=torch.float32, device=A.device) if nws else None       # (stream-ordered: freed after the launches)
     p.ws = ptr(ws)
-    if KERNEL_TIMER is not None:
-        # (classified by the problem, not by the kernel that runs it: M <= 144 linears are the text encoder's / per-sample vectors)
-        KERNEL_TIMER.launch("skinny_gemm" if (g.M <= 144 and g.KH == 1) else "conv_gemm", 2.0 * g.M * N * g.K,
-                            2.0 * (g.M * g.C + N * g.K + g.M * N), "cris_conv_gemm_variant", C.byref(p), variant,
-                            tag="M%d N%d K%d k%d" % (g.M, N, g.K, g.KH))
+    flops, nbytes, tag = 2.0 * g.M * N * g.K, 2.0 * (g.M * g.C + N * g.K + g.M * N), "M%d N%d K%d k%d" % (g.M, N, g.K, g.KH)
+    if queue is not None:
+        queue.add(p, variant, (A, Wt, bias, resid, out, outT, drop.dev, ws, st.t if st is not None else None), flops, nbytes, tag)
         return st
-    hip.call("cris_conv_gemm_variant", C.byref(p), variant, _stream())
+    _launch_gemm(p, variant, flops, nbytes, tag)
     return st
 
 
@@ -182,9 +250,9 @@ _WGRAD_FLUSH_BLOCKS = int(os.environ.get("CRIS_WGRAD_FLUSH_BLOCKS", "3072"))
 
 
 _WGRAD8_BLOCKS = int(os.environ.get("CRIS_WGRAD8_BLOCKS", "256"))    # 8-wave 256x256 tile: one block (128 KB of LDS) per CU
-# 1: the split reductions of the large layers (32 launches of ~6.6 us per step) are deferred to the queue's flush and run as
-# grouped launches (cris_wgrad_reduce_group).  Written after round 3's GPU budget was spent: default off until measured.
-_WGRAD_REDUCE_GROUP = os.environ.get("CRIS_WGRAD_REDUCE_GROUP", "0") == "1"
+# 1 (default since round 4, call r04a: 12.233 against 12.280 ms per step): the split reductions of the large layers (32 launches
+# of ~6.6 us per step) are deferred to the queue's flush and run as grouped launches (cris_wgrad_reduce_group); 0: one by one
+_WGRAD_REDUCE_GROUP = os.environ.get("CRIS_WGRAD_REDUCE_GROUP", "1") == "1"
 
 
 def wgrad_splits(M: int, N: int, K: int, tile: int = 128) -> int:

@@ -81,6 +81,24 @@ int cris_conv_gemm_variant_stat_rows(const cris_conv_gemm_params* p, int variant
 long cris_conv_gemm_ws_floats(const cris_conv_gemm_params* p, int variant);
 int cris_conv_gemm_num_variants(void);
 const char* cris_conv_gemm_variant_name(int variant);
+/* what cris_conv_gemm_variant(p, variant) would run: the resolved tile variant (>= 0; -1 when `variant` cannot run the problem)
+ * and, in *epilogue, the epilogue instantiation (0 general, 1 lean, 2 lean + bias / ReLU); host only */
+int cris_conv_gemm_plan(const cris_conv_gemm_params* p, int variant, int* epilogue);
+
+/* Up to CRIS_GEMM_GROUP_MAX INDEPENDENT forward / input-gradient problems in ONE launch (problem table passed by value in the
+ * kernel arguments; reference call sites: the q / k / v projections of nn.MultiheadAttention model/layers.py:202-207,235-243 and
+ * AttentionPool2d model/clip.py:112-139, the FPN's f4_proj3/4/5 model/layers.py:300-302, a Bottleneck's conv1 + downsample
+ * model/clip.py:44-53 - and their input-gradient twins).  No problem may read or accumulate into what another one writes.  All
+ * problems run the tile `variant` (one of the 4-wave tiles 128x64 / 64x64 / 64x128 / 128x128 or the 8-wave 128x128 tile,
+ * which needs C % 64 == 0 everywhere) and must share the epilogue instantiation (cris_conv_gemm_plan).  Results are bit-identical to
+ * cris_conv_gemm_variant(prob[i], variant) one by one.  block_start is filled by the launcher. */
+#define CRIS_GEMM_GROUP_MAX 12
+typedef struct {
+    int n;                                           /* problems in prob[] */
+    int block_start[CRIS_GEMM_GROUP_MAX + 1];        /* (out) first block of each problem */
+    cris_conv_gemm_params prob[CRIS_GEMM_GROUP_MAX];
+} cris_conv_gemm_group;
+int cris_conv_gemm_group_launch(const cris_conv_gemm_group* g, int variant, void* stream);
 
 /* Weight gradient in the GEMM layout: dW[n][tap*C + c] = sum_m dY[m, n] * X_im2col[m, tap*C + c]  (csrc/wgrad.hip).
  * Deterministic, no atomics: splits == 1 stores the whole reduction; splits > 1 stores one partial tile per split into the
@@ -123,7 +141,7 @@ typedef struct {
 } cris_wgrad_group;
 int cris_conv_wgrad_group(const cris_wgrad_group* g, void* stream);
 /* the split reductions (cris_wgrad_reduce) of up to CRIS_WGRAD_GROUP_MAX problems launched with defer_reduce, in ONE launch;
- * problems with splits == 1 are skipped.  (Written after round 3's GPU budget was spent: cross-compiled, not yet run.) */
+ * problems with splits == 1 are skipped (the native trainer's default since round 4: ops.WgradQueue). */
 int cris_wgrad_reduce_group(const cris_wgrad_group* g, void* stream);
 
 /* Batched weight packing (fp32 parameter layout -> bf16 GEMM layouts), one launch for a table of tensors.

@@ -41,6 +41,11 @@ class OracleTrainer:
         if self.device.type == "cuda":
             torch.backends.cudnn.allow_tf32 = False
             torch.backends.cuda.matmul.allow_tf32 = False
+            # the teacher must be reproducible: at the steep states of the untrained head (steps 3, 8, 10 of configs[1]) a
+            # run-to-run difference of its atomics-based backward kernels moved the 100-state mean |dloss| by several per cent
+            torch.backends.cudnn.deterministic = True
+            torch.backends.cudnn.benchmark = False
+            torch.use_deterministic_algorithms(True, warn_only=True)
 
     def _ctx(self):
         if self.mode == "fp32":

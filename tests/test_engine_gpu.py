@@ -294,4 +294,4 @@ def test_teacher_forced_r50_full_size_first_12_states():
     rows, dl = teacher_forced("r50", 416, 17, 12, "r50_first12")
     fx = json.load(open(os.path.join(GOLDEN, "traj_r50_b8_s416_d0.1_lr0.0001.json")))["loss"]
     assert abs(rows[0]["loss_fp32"] - fx[0]) < 1e-4                  # the GPU teacher starts where the pinned CPU oracle starts
-    assert_teacher_forced(rows, dl, mean_bound=8.0e-3)
+    assert_teacher_forced(rows, dl, mean_bound=6.0e-3, cos_min=0.85)          # measured: mean 3.9e-3 (max 2.1e-2 at step 3), worst tensor 0.933

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from cris.pytorch_amd import ops  # noqa: E402
+from cris.pytorch_amd import hip, ops  # noqa: E402
 from cris.pytorch_amd.ops import Geom, Drop  # noqa: E402
 from oracle import dropout_hash  # noqa: E402
 
@@ -325,6 +325,122 @@ def test_conv_gemm_transposed_store(L, B):
     got = outT.float().cpu().view(secs, B, Hh, 64, Lpad)
     assert torch.equal(got[..., :L], ref.contiguous())
     assert float(got[..., L:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("L,B,secs", [(676, 2, 2), (169, 3, 1), (17, 16, 3), (900, 1, 1)])
+def test_conv_gemm_general_epilogue_interior_tiles(L, B, secs):
+    """the general epilogue's fast form on interior wave tiles (gemm_epilogue_fast32_gen): bias + head-split transposed copy for
+    token counts with / without a multiple of 4 (packed 8-byte / 2-byte stores, batch wrap inside a wave tile), fp32 residual +
+    fp32 output, QuickGELU, fp32 output alone - against torch and against the transposed layout's definition"""
+    E = 128
+    M, K, N = B * L, 256, E * secs
+    x = rnd(M, K).to(BF).float()
+    w = (rnd(N, K, seed=1) / math.sqrt(K)).to(BF).float()
+    bias = rnd(N, seed=2)
+    Lpad, Hh = ops.pad32(L), E // 64
+    outT = torch.zeros(secs, B * Hh * 64, Lpad, dtype=BF, device=DEV)
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    for variant in ("64x64", "128x128"):
+        outT.zero_()
+        ops.conv_gemm(bf(x), bf(w), Geom.linear(M, K), N, bias=bias.to(DEV), out=out, outT=outT, T_L=L, T_Lpad=Lpad, T_E=E,
+                      T_sec_stride=B * Hh * 64 * Lpad, variant=variant)
+        check(out, x @ w.t() + bias, 6e-3, "bias + transposed copy (%s)" % variant)
+        y = out.float().cpu()
+        ref = y.view(B, L, secs, Hh, 64).permute(2, 0, 3, 4, 1)
+        got = outT.float().cpu().view(secs, B, Hh, 64, Lpad)
+        assert torch.equal(got[..., :L], ref.contiguous()), variant
+        assert float(got[..., L:].abs().max()) == 0.0
+        res32 = rnd(M, N, seed=3)
+        o32 = torch.empty(M, N, dtype=torch.float32, device=DEV)
+        ops.conv_gemm(bf(x), bf(w), Geom.linear(M, K), N, bias=bias.to(DEV), act=2, resid=res32.to(DEV), out=o32, variant=variant)
+        base = x @ w.t() + bias
+        check(o32, base * torch.sigmoid(1.702 * base) + res32, 3e-3, "quickgelu + fp32 stream (%s)" % variant)
+        ops.conv_gemm(bf(x), bf(w), Geom.linear(M, K), N, bias=bias.to(DEV), out=o32, variant=variant)
+        check(o32, base, 3e-3, "fp32 out (%s)" % variant)
+
+
+def _group_case(i, B, H, W, C_, N, k, epi):
+    """one problem of a group test: (kwargs for ops.conv_gemm, reference output or None)"""
+    x = rnd(B, H, W, C_, seed=10 + i).to(BF).float()
+    w = (rnd(N, C_, k, k, seed=20 + i) / math.sqrt(C_ * k * k)).to(BF).float()
+    g = Geom(B, H, W, C_, k, k, 1, k // 2)
+    kw = dict(A=bf(x), Wt=bf(pack_F(w)), g=g, N=N)
+    ref = conv_ref(x, w, 1, k // 2)
+    if epi == "bias":
+        b = rnd(N, seed=30 + i)
+        kw["bias"] = b.to(DEV)
+        ref = ref + b
+    elif epi == "resid":
+        r = rnd(g.M, N, seed=40 + i).to(BF).float()
+        kw["resid"] = bf(r)
+        ref = ref + r
+    return kw, ref
+
+
+@pytest.mark.parametrize("variant", ["64x64", "64x128", "128x64", "128x128", "8w128x128", -1])
+@pytest.mark.parametrize("epi", ["lean", "bias", "resid", "stats"])
+def test_conv_gemm_group_matches_single_launches(variant, epi):
+    """cris_conv_gemm_group_launch: several independent problems of different sizes in one launch - outputs (and BatchNorm
+    partials) bit-identical to launching each problem alone with the same tile, and right against torch"""
+    shapes = [(2, 26, 26, 64, 128, 3), (1, 13, 13, 128, 256, 1), (3, 10, 12, 64, 192, 3), (2, 7, 9, 192, 72, 1), (8, 1, 1, 128, 128, 1)]
+    single, grouped, refs = [], [], []
+    q = ops.GemmQueue()
+    for i, sh in enumerate(shapes):
+        kw, ref = _group_case(i, *sh, epi)
+        a, wt, g, N = kw.pop("A"), kw.pop("Wt"), kw.pop("g"), kw.pop("N")
+        o1 = torch.full((g.M, N), float("nan"), dtype=BF, device=DEV)
+        o2 = torch.full((g.M, N), float("nan"), dtype=BF, device=DEV)
+        s1 = ops.conv_gemm(a, wt, g, N, out=o1, stats=(epi == "stats"), variant=variant, **kw)
+        s2 = ops.conv_gemm(a, wt, g, N, out=o2, stats=(epi == "stats"), variant=variant, queue=q, **kw)
+        single.append((o1, s1))
+        grouped.append((o2, s2))
+        refs.append(ref)
+    assert len(q) == len(shapes)
+    q.flush()
+    assert len(q) == 0
+    for (o1, s1), (o2, s2), ref in zip(single, grouped, refs):
+        check(o2, ref, 6e-3, "grouped launch vs torch")
+        assert torch.equal(o1, o2)
+        if s1 is not None:
+            assert s1.rows_per_part == s2.rows_per_part and torch.equal(s1.t[:, :s1.nparts], s2.t[:, :s2.nparts])
+
+
+def test_conv_gemm_group_chunks_and_mixed_keys():
+    """more problems than CRIS_GEMM_GROUP_MAX, two epilogue kinds and a skinny problem in one queue: several launches, same results"""
+    q = ops.GemmQueue()
+    outs = []
+    for i in range(15):
+        kw, ref = _group_case(i, 1, 9 + i, 8, 64, 64 + 8 * (i % 3), 1, "bias" if i % 2 else "lean")
+        a, wt, g, N = kw.pop("A"), kw.pop("Wt"), kw.pop("g"), kw.pop("N")
+        o = torch.full((g.M, N), float("nan"), dtype=BF, device=DEV)
+        ops.conv_gemm(a, wt, g, N, out=o, queue=q, **kw)
+        outs.append((o, ref))
+    kw, ref = _group_case(99, 8, 1, 1, 1024, 520, 1, "bias")           # M = 8: the skinny kernel, launched alone at the flush
+    a, wt, g, N = kw.pop("A"), kw.pop("Wt"), kw.pop("g"), kw.pop("N")
+    o = torch.full((g.M, N), float("nan"), dtype=BF, device=DEV)
+    ops.conv_gemm(a, wt, g, N, out=o, queue=q, **kw)
+    outs.append((o, ref))
+    q.flush()
+    for o, ref in outs:
+        check(o, ref, 6e-3, "mixed queue")
+
+
+def test_conv_gemm_auto_variant_without_workspace():
+    """a C-ABI caller that does not know the `ws` field (NULL) still gets the text-encoder shapes computed: the automatic choice
+    falls back from the split-K skinny kernel to the single-pass one"""
+    M, K, N = 136, 2048, 512
+    x = rnd(M, K).to(BF).float()
+    w = (rnd(N, K, seed=1) / math.sqrt(K)).to(BF).float()
+    p = hip.ConvGemmParams()
+    xa, wa = bf(x), bf(w)
+    out = torch.empty(M, N, dtype=BF, device=DEV)
+    p.A, p.Wt, p.out = xa.data_ptr(), wa.data_ptr(), out.data_ptr()
+    p.lda, p.ldb, p.ldc = K, K, N
+    p.Bn, p.H, p.W, p.C, p.OH, p.OW, p.KH, p.KW, p.stride, p.pad = M, 1, 1, K, 1, 1, 1, 1, 1, 0
+    p.M, p.N, p.K = M, N, K
+    import ctypes
+    hip.call("cris_conv_gemm", ctypes.byref(p), torch.cuda.current_stream().cuda_stream)
+    check(out, x @ w.t(), 6e-3, "auto variant, ws = NULL")
 
 
 WGRAD_CASES = [
@@ -1102,21 +1218,17 @@ def test_syncbn_single_exchange_far_reference(d, tol):
     check(outs[3], torch.rsqrt(y.double().var(0, unbiased=False) + 1e-5), tol, "global invstd, reference %g std away" % d)
 
 
-@pytest.mark.skipif(os.environ.get("CRIS_TEST_NEXT") != "1", reason="code path written after the round's GPU budget was spent: "
-                    "not yet run on a GPU; CRIS_TEST_NEXT=1 includes it (first thing next round)")
-def test_layernorm_backward_narrow_instantiations():
-    """CRIS_LN_BWD_V=1 (read once per process, hence the subprocess): C <= 512 / <= 1024 run the 1- / 2-vector-per-lane
-    instantiations of the LayerNorm backward; the same checks as test_layernorm_variants must hold"""
+def test_layernorm_backward_wide_instantiation():
+    """CRIS_LN_BWD_V=0 (read once per process, hence the subprocess): every width on the V = 4 instantiation of the LayerNorm
+    backward (the default runs 1 / 2 channel vectors per lane for C <= 512 / 1024); the same checks as test_layernorm_variants"""
     import subprocess
     import sys
-    env = dict(os.environ, CRIS_LN_BWD_V="1")
+    env = dict(os.environ, CRIS_LN_BWD_V="0")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_layernorm_variants",
                         "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-1000:]
 
 
-@pytest.mark.skipif(os.environ.get("CRIS_TEST_NEXT") != "1", reason="code path written after the round's GPU budget was spent: "
-                    "not yet run on a GPU; CRIS_TEST_NEXT=1 includes it (first thing next round)")
 def test_conv_wgrad_deferred_grouped_reduction(monkeypatch):
     """CRIS_WGRAD_REDUCE_GROUP: the split reductions of large problems wait in the queue and run as one grouped launch at the
     flush; the result equals the immediate reduction bit for bit (same summation order)"""

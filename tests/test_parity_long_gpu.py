@@ -63,24 +63,26 @@ def test_teacher_forced_r50_full_size_100_steps():
     rows, dl = teacher_forced("r50", 416, 17, 100, "r50")
     fx = json.load(open(os.path.join(GOLDEN, "traj_r50_b8_s416_d0.1_lr0.0001.json")))["loss"]
     assert abs(rows[0]["loss_fp32"] - fx[0]) < 1e-4                  # the GPU teacher starts where the pinned CPU oracle starts
-    assert_teacher_forced(rows, dl, mean_bound=TF_R50_MEAN)
+    assert_teacher_forced(rows, dl, mean_bound=TF_R50_MEAN, cos_min=0.80)         # measured: worst tensor 0.870
     assert rows[-1]["loss_fp32"] < 0.5 * rows[0]["loss_fp32"]          # the teacher's trajectory is a training run
 
 
-# mean |dloss| bounds of the teacher-forced runs (fixed; measured values in profiles/parity_r04.md)
-TF_R50_MEAN, TF_R101_MEAN, TF_480_MEAN = 2.0e-3, 1.0e-2, 5.0e-3
+# mean |dloss| bounds of the teacher-forced runs (fixed; measured in round 4, profiles/parity_r04.md: R50 9.6e-4 over 100 states,
+# R101 2.7e-3 and 480 / 22 tokens 4.2e-3 over their first 20 states - the violent ones: the 100-state R50 mean is 2.2e-3 over
+# its first 40 states and 1.5e-4 over the last 60)
+TF_R50_MEAN, TF_R101_MEAN, TF_480_MEAN = 1.0e-3, 4.0e-3, 6.0e-3
 
 
 def test_teacher_forced_r101_20_states():
     """BASELINE.json configs[3] (R101, 416x416, batch 8): the first 20 states of its fp32 teacher's trajectory."""
     rows, dl = teacher_forced("r101", 416, 17, 20, "r101")
-    assert_teacher_forced(rows, dl, mean_bound=TF_R101_MEAN, cos_med=0.95, cos_min=0.60)
+    assert_teacher_forced(rows, dl, mean_bound=TF_R101_MEAN, cos_med=0.96, cos_min=0.85)        # measured: 0.9745 / 0.896
 
 
 def test_teacher_forced_r50_480_22_tokens_20_states():
     """BASELINE.json configs[4] (R50, 480x480, 22-token expressions, batch 8): the first 20 states."""
     rows, dl = teacher_forced("r50", 480, 22, 20, "r50_480")
-    assert_teacher_forced(rows, dl, mean_bound=TF_480_MEAN)
+    assert_teacher_forced(rows, dl, mean_bound=TF_480_MEAN, loss=6.0e-2)        # measured: max 4.1e-2 at step 3 (fp32 loss 2.09 between 1.44 and 1.19)
 
 
 def test_stage_isolated_parity_r50_full_size():

@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--lr", type=float, default=1e-4)
     ap.add_argument("--no-hip", action="store_true")
     ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--detail", default=None, help="a stage name: only that stage, one kind of storage point at a time")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device(args.device)
@@ -69,6 +70,9 @@ def main():
     configs = [("all", None, None)] + [("stage:" + s, None, s) for s in E.STAGES] + [("kind:" + k, v, None) for k, v in KIND_GROUPS.items()]
     # the head stages and the text encoder once more, split by kind of storage point (what to promote, if anything)
     configs += [("%s/%s" % (s, k), v, s) for s in ("text", "neck", "decoder", "proj") for k, v in KIND_GROUPS.items()]
+    if args.detail:
+        configs = [("all", None, None), ("stage:" + args.detail, None, args.detail)]
+        configs += [("%s/%s" % (args.detail, k), (k,), args.detail) for k in E.KINDS]
     rows = []
     for t in range(args.steps):
         batch = synth.make_batch(args.batch, args.size, head.word_len, 0, t)
