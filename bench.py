@@ -29,6 +29,41 @@ ALG_BYTES_PER_SAMPLE = 0.98e9      # bf16 contraction operands+outputs under per
 ADAM_BYTES_PER_STEP = 4.11e9
 MFMA_PEAK = 2500.0                 # TFLOP/s dense bf16 (MI355X_MICROARCH.md)
 HBM_PEAK = 8000.0                  # GB/s spec
+DUAL_CEILING = {("r50", 416): 4305.0, ("r101", 416): 3678.0, ("r50", 480): 3164.0}   # samples/s per GPU: per-layer max(MFMA, HBM) roofline
+
+
+def physical_cores():
+    """physical cores of the host (lscpu: sockets x cores per socket; SURVEY.md 8d asks for physical, not logical, CPUs)"""
+    import subprocess
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = dict((a.strip(), b.strip()) for a, b in (ln.split(":", 1) for ln in out.splitlines() if ":" in ln))
+        n = int(kv["Socket(s)"]) * int(kv["Core(s) per socket"])
+        if n > 0:
+            return n
+    except Exception:               # noqa: BLE001
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def gpu_state(dev_index=0):
+    """shader / memory clock, power and temperature of the GPU from rocm-smi (one call, ~0.1 s): logged at the start and the end
+    of a run so that a throttled box can be told from a regression (profiles/r03_kernel_stats_slow_box.csv)"""
+    import re
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", str(dev_index), "--showclocks", "--showpower", "--showtemp"], capture_output=True, text=True,
+                             timeout=20).stdout
+    except Exception as ex:         # noqa: BLE001
+        return {"error": repr(ex)[:80]}
+    st = {}
+    for key, pat in (("sclk_mhz", r"sclk clock level: \S+ \((\d+)Mhz\)"), ("mclk_mhz", r"mclk clock level: \S+ \((\d+)Mhz\)"),
+                     ("power_w", r"Power \(W\): ([0-9.]+)"), ("temp_junction_c", r"Sensor junction\) \(C\): ([0-9.]+)"),
+                     ("temp_memory_c", r"Sensor memory\) \(C\): ([0-9.]+)")):
+        m = re.search(pat, out)
+        if m:
+            st[key] = float(m.group(1))
+    return st
 
 
 def cpu_baseline(spec, batch, size, word_len, threads):
@@ -52,14 +87,20 @@ def cpu_baseline(spec, batch, size, word_len, threads):
             O.cris_forward(sd, clip, head, img1, word1, None, training=False)
         eval_ms = 1000.0 * (time.time() - t1) / n_eval
     leaf = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
-    t0 = time.time()
-    _, _, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=1)
-    loss.backward()
-    dt = time.time() - t0
-    return {"value": batch / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": "oracle port (the reference itself is absent on the GPU box): 1 train step (fwd+loss+bwd, fp32, no optimizer) "
-                      "at batch %d, %dx%d, L=%d: %.1f s; eval forward bs=1: 10 warm-up + %d timed iterations"
-                      % (batch, size, size, word_len, dt, n_eval),
+    dts = []
+    for it in range(2):                      # one warm-up step (allocator, thread pool, autograd graph caches), one timed
+        for v in leaf.values():
+            if v.is_floating_point():
+                v.grad = None
+        t0 = time.time()
+        _, _, loss = O.cris_forward(leaf, clip, head, img, word, mask, training=True, drop_seed=1)
+        loss.backward()
+        dts.append(time.time() - t0)
+    dt = dts[-1]
+    return {"value": batch / dt, "unit": "samples/s", "cores": threads, "cores_are": "physical (lscpu), one thread each", "kind": "port",
+            "sample": "oracle port (the reference itself is absent on the GPU box): 1 warm-up + 1 timed train step (fwd+loss+bwd, fp32, "
+                      "no optimizer) at batch %d, %dx%d, L=%d: %.1f s (warm-up %.1f s); eval forward bs=1: 10 warm-up + %d timed iterations"
+                      % (batch, size, size, word_len, dt, dts[0], n_eval),
             "eval_forward_bs1_ms": eval_ms}
 
 
@@ -253,6 +294,7 @@ def main():
     word_len = args.word_len if args.word_len is not None else (22 if args.size == 480 else head.word_len)
     head = dataclasses.replace(head, word_len=word_len)
     sd = arch.synthetic_state_dict(clip, head, 0)
+    smi0 = gpu_state(local) if rank == 0 else None
     tr = NativeTrainer(clip, head, sd, dev, comm=comm, sync_bn=world > 1, use_graph=not args.no_graph, launch=args.launch)
     del sd
     nb = 4
@@ -279,6 +321,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     loss_v = float(loss)
+    smi1 = gpu_state(local) if rank == 0 else None
     # per-kernel HIP-event timing needs individual launches: an extra instrumented EAGER pass right after the timed
     # region (the timed region itself replays the captured HIP graph - one host call per step)
     timer, timer_steps = None, 0
@@ -309,11 +352,16 @@ def main():
                                    % (args.spec.upper(), args.size, args.size, args.batch, head.word_len,
                                       "" if world == 1 else "; x%d GPUs = configs[2] recipe: SyncBN + gradient all-reduce over RCCL" % world),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first_loss, "final_loss": loss_v,
-                       "launch": tr.launch, "graph_error": tr.graph_error, "syncbn_exchange": tr.syncbn_exchange,
-                       "comm": type(comm).__name__ if comm is not None else None},
+                       "launch": tr.launch, "graph_captured": tr._graph is not None, "graph_error": tr.graph_error,
+                       "syncbn_exchange": tr.syncbn_exchange, "comm": type(comm).__name__ if comm is not None else None,
+                       "gpu_state_start": smi0, "gpu_state_end": smi1},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12),
                               "hbm_frac_alg": (sps / world * ALG_BYTES_PER_SAMPLE + steps_s * ADAM_BYTES_PER_STEP) / (HBM_PEAK * 1e9)},
         }
+        if (args.spec, args.size) in DUAL_CEILING and args.batch == 8:
+            # the per-layer dual (MFMA / HBM) roofline of SURVEY.md 8d for this configuration at 8 samples per GPU
+            out["step_roofline"]["dual_ceiling_samples_s_per_gpu"] = DUAL_CEILING[(args.spec, args.size)]
+            out["step_roofline"]["dual_ceiling_frac"] = sps / world / DUAL_CEILING[(args.spec, args.size)]
         if timer is not None:
             summ = timer.summary()
             dom = max(summ, key=lambda k: summ[k]["ms"])
@@ -325,17 +373,28 @@ def main():
                                "share_of_step": (d["ms"] / timer_steps) / (1000.0 * dt / args.steps)}
             # HBM bytes per launch of the same kernel from the PMC passes of tools/gpu_pmc.sh (rocprofv3 --pmc FETCH_SIZE /
             # WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction): a committed measurement, not taken live
-            for pmf, pmk in (("r03_hbm_traffic.json", "conv_gemm (all tile kernels)"), ("r02_hbm_traffic.json", "conv_gemm_kernel")):
+            # ONE set of launches for both figures: every launch of a forward / input-gradient TILE kernel (the convolution
+            # GEMMs and the linears of M > 16 rows that run on them) - what the PMC summary's family entry covers.  Per launch
+            # both are averages over that set; traffic_ratio compares the two per STEP (a grouped launch is one launch of
+            # several problems, so launch counts of different builds are not comparable, bytes per step are)
+            fam = timer.tile_family()
+            for pmf in ("r04_hbm_traffic.json", "r03_hbm_traffic.json"):
                 try:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", pmf)))["kernels"][pmk]
+                    pj = json.load(open(os.path.join(ROOT, "profiles", pmf)))
+                    pm = pj["kernels"]["conv_gemm (all tile kernels)"]
+                    pmc_steps = pj.get("steps") or 5          # (r03's file: 2 set-up + 1 warm-up + 2 timed steps)
                     out["roofline"]["traffic"] = pm["traffic_bytes_per_launch"]
-                    out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc, eager launches)" % pmf
-                    out["roofline"]["algorithmic_bytes_per_launch"] = d["bytes"] / d["launches"]
+                    out["roofline"]["traffic_source"] = "profiles/%s (rocprofv3 --pmc, eager launches; average over the %d launches per step of the tile kernels)" % (pmf, round(pm["launches"] / pmc_steps))
+                    out["roofline"]["algorithmic_bytes_per_launch"] = fam["bytes"] / max(fam["launches"], 1)
+                    out["roofline"]["algorithmic_launch_set"] = "the %d launches per step of the tile kernels in this run" % round(fam["launches"] / timer_steps)
+                    t_step, a_step = pm["traffic_bytes_per_launch"] * pm["launches"] / pmc_steps, fam["bytes"] / timer_steps
+                    out["roofline"]["traffic_per_step"], out["roofline"]["algorithmic_bytes_per_step"] = t_step, a_step
+                    out["roofline"]["traffic_ratio"] = t_step / a_step
                     break
                 except Exception:               # noqa: BLE001
                     pass
             # where the parity measurements of this path are (a pointer, not a measurement of this run)
-            out["config"]["parity"] = "profiles/parity_r03.md (teacher-forced 100-step test + stock-PyTorch autocast study), tests/test_engine_gpu.py"
+            out["config"]["parity"] = "profiles/parity_r04.md (teacher-forced runs of configs[1] / [3] / [4], per-stage bf16 error budget), tests/test_parity_long_gpu.py"
             out["roofline"]["timing"] = "HIP events around each launch, %d-step eager pass after the timed region" % timer_steps
             out["kernels"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                   "launches_per_step": v["launches"] / timer_steps} for k, v in summ.items()}
@@ -348,7 +407,7 @@ def main():
                         kn, tag, v["launches"] / timer_steps, v["ms"] / timer_steps, 1e3 * v["ms"] / v["launches"],
                         v["flops"] / (v["ms"] * 1e-3) / 1e12, v["bytes"] / (v["ms"] * 1e-3) / 1e9))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.spec, args.batch, args.size, head.word_len, min(os.cpu_count() or 1, 64))
+            out["cpu_baseline"] = cpu_baseline(args.spec, args.batch, args.size, head.word_len, physical_cores())
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -32,6 +32,7 @@ extern "C" int cris_sizeof(const char* name) {
     S(cris_attn_params);
     S(cris_adam_desc);
     S(cris_p2p_params);
+    S(cris_p2p_link);
     S(cris_zero_ranges);
     S(cris_sample_desc);
     S(cris_jpeg_info);

@@ -3,6 +3,8 @@
 // partial row per block that a second small launch sums in block order - no atomics, results are deterministic.
 #include "common.h"
 #include "../../../include/cris_hip.h"
+#include "p2p_ll.h"
+#include <string.h>
 
 // ------------------------------------------------------------------------------------------------
 // BN coefficients
@@ -86,6 +88,20 @@ __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__
     }
 }
 
+// The arithmetic of the single-exchange SyncBN, shared by the separate pack / unpack kernels and by the finalize kernel that
+// exchanges in place: explicit roundings (no FMA contraction left to the compiler), so every form gives the same bits.
+//   pack:    S1 = sum - n c,  S2 = M2 + n (mean_l - c)^2        (moments about the reference c = running mean)
+//   unpack:  global sum = S1 + N c,  M2 about the global mean = max(S2 - S1^2 / N, 0)
+__device__ __forceinline__ void bn_sync_pack_vals(float total, float m2, float mean_l, float ref, float n, float& s1, float& s2) {
+    const float d = __fsub_rn(mean_l, ref);
+    s1 = __fmaf_rn(-n, ref, total);
+    s2 = __fmaf_rn(__fmul_rn(n, d), d, m2);
+}
+__device__ __forceinline__ void bn_sync_unpack_vals(float s1, float s2, float ref, float count, float& gsum, float& gm2) {
+    gsum = __fmaf_rn(count, ref, s1);
+    gm2 = fmaxf(__fsub_rn(s2, __fdiv_rn(__fmul_rn(s1, s1), count)), 0.f);
+}
+
 // merge + coefficients in ONE launch: block = 16 channels x PL part lanes (coalesced 64-B rows).  Two passes over the partial
 // list (sum, M2 about the part mean; all parts rows_per_part rows, the last one what is left of count_local):
 //   mean = sum_i S_i / n,   M2 = sum_i [ M2_i + n_i (S_i / n_i - mean)^2 ]
@@ -100,7 +116,8 @@ __global__ __launch_bounds__(16 * PL) void bn_finalize_kernel(const float* psum,
                                    float count, const float* gamma, const float* beta, float* rmean, float* rvar,
                                    float momentum, float eps, int C, float* scale, float* shift, float* mean_o,
                                    float* invstd_o, float* merged /* optional [2*C]: local (sum, M2) for SyncBN */,
-                                   const float* global_stats /* optional [2*C]: (sum, M2 about the global mean) */) {
+                                   const float* global_stats /* optional [2*C]: (sum, M2 about the global mean) */,
+                                   const cris_p2p_link link /* world > 1: SyncBN, the exchange happens in here */) {
     __shared__ float sh[PL][17];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -153,9 +170,29 @@ __global__ __launch_bounds__(16 * PL) void bn_finalize_kernel(const float* psum,
             mean_o[c] = mean;               // local mean, needed to re-centre M2 about the global mean
             return;
         }
+        if (link.world > 1) {
+            // SyncBatchNorm in this launch: the arithmetic of bn_sync_pack / rank-order sum / bn_sync_unpack / the
+            // global_stats branch below, expression for expression (the two paths give the same bits), with the exchange done by
+            // the lane that owns the channel: moments about the running mean (identical on every rank) out, sums over ranks in
+            const int gen = p2p_link_gen(link);
+            float s1, s2, gsum, gm2;
+            bn_sync_pack_vals(total, m2, mean, rm0, count_local, s1, s2);
+            p2p_ll_send(link, gen, c, s1);
+            p2p_ll_send(link, gen, C + c, s2);
+            bool bad = false;
+            s1 = p2p_ll_recv_sum(link, gen, c, bad);
+            s2 = p2p_ll_recv_sum(link, gen, C + c, bad);
+            bn_sync_unpack_vals(s1, s2, rm0, count, gsum, gm2);
+            mean = __fdiv_rn(gsum, count);
+            m2 = gm2;
+            if (bad) {                                                      // a missing peer must not pass silently
+                mean = __int_as_float(0x7fc00000);
+                if (link.err) link.err[0] = 1;
+            }
+        }
     } else {
         if (pl != 0 || c >= C) return;
-        mean = global_stats[c] / count;
+        mean = __fdiv_rn(global_stats[c], count);
         m2 = global_stats[C + c];
     }
     const float var = fmaxf(m2 / count, 0.f);
@@ -172,13 +209,17 @@ __global__ __launch_bounds__(16 * PL) void bn_finalize_kernel(const float* psum,
     }
 }
 
-__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int nparts, int ncol, float* __restrict__ out) {
+// `link.world > 1` (SyncBatchNorm backward): the column sums are this rank's (sum g, sum g xhat): they are added into `local_acc`
+// (the gradient arena's d beta / d gamma block), exchanged, and the sums over all ranks are written to `out`
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int nparts, int ncol, float* __restrict__ out,
+                                                           float* __restrict__ local_acc, const cris_p2p_link link) {
     __shared__ float sh[16][17];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
+    const bool sync = link.world > 1;
     // latency-bound (a few blocks, a few loads each): the value to add to and this lane's rows are all requested up front
     float o = 0.f;
-    if (pl == 0 && c < ncol) o = out[c];
+    if (pl == 0 && c < ncol) o = sync ? (local_acc ? local_acc[c] : 0.f) : out[c];
     float a = 0.f;
     if (c < ncol) {
         for (int i0 = pl; i0 < nparts; i0 += 64) {
@@ -195,19 +236,36 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     if (pl == 0 && c < ncol) {
 #pragma unroll
         for (int j = 1; j < 16; ++j) a += sh[j][cl];
-        out[c] = o + a;
+        if (!sync) {
+            out[c] = o + a;
+        } else {
+            const float loc = 0.f + a;                  // (what the plain form leaves in a zeroed `out`)
+            if (local_acc) local_acc[c] = o + 1.0f * loc;   // (the axpy the exchange-by-collective path runs: dst += 1 * src)
+            const int gen = p2p_link_gen(link);
+            p2p_ll_send(link, gen, c, loc);
+            bool bad = false;
+            const float g = p2p_ll_recv_sum(link, gen, c, bad);
+            out[c] = bad ? __int_as_float(0x7fc00000) : g;
+            if (bad && link.err) link.err[0] = 1;
+        }
     }
 }
+static cris_p2p_link cris_no_link() {
+    cris_p2p_link l;
+    memset(&l, 0, sizeof(l));
+    return l;
+}
 void cris_launch_sum_partials(const float* part, int nparts, int ncol, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, stream, part, nparts, ncol, out);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, stream, part, nparts, ncol, out, (float*)nullptr,
+                       cris_no_link());
 }
 // rows the caller must allocate for a partials buffer of `nparts` parts (room for the level-1 merge output of long lists)
 extern "C" int cris_bn_partials_rows(int nparts) { return nparts > BN_MERGE_MIN ? nparts + BN_MERGE_SLICES : nparts; }
 
-extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
-                                float count, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                                float momentum, float eps, int C, float* scale, float* shift, float* mean, float* invstd,
-                                float* merged, const float* global_stats, void* stream) {
+static int bn_finalize_launch(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
+                              float count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                              float momentum, float eps, int C, float* scale, float* shift, float* mean, float* invstd,
+                              float* merged, const float* global_stats, const cris_p2p_link& link, void* stream) {
     CRIS_CHECK_ARG((global_stats || (psum && pm2 && nparts > 0 && rows_per_part > 0)) && gamma && beta && mean && C > 0 && count > 0.f, "bad args");
     CRIS_CHECK_ARG(merged || (scale && shift && invstd), "bad args");
     CRIS_CHECK_ARG(global_stats || ((double)(nparts - 1) * rows_per_part < count_local && (double)nparts * rows_per_part >= count_local),
@@ -229,13 +287,42 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
     if (!global_stats && nparts > BN_WIDE_MIN)
         hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3(cris_cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
                            count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
-                           merged, global_stats);
+                           merged, global_stats, link);
     else
         hipLaunchKernelGGL(bn_finalize_kernel<16>, dim3(cris_cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
                            count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,
-                           merged, global_stats);
+                           merged, global_stats, link);
     CRIS_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local,
+                                float count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                float momentum, float eps, int C, float* scale, float* shift, float* mean, float* invstd,
+                                float* merged, const float* global_stats, void* stream) {
+    return bn_finalize_launch(psum, pm2, nparts, rows_per_part, count_local, count, gamma, beta, running_mean, running_var, momentum, eps,
+                              C, scale, shift, mean, invstd, merged, global_stats, cris_no_link(), stream);
+}
+
+static int p2p_link_check(const cris_p2p_link& l, int n, const char* fn) {
+    if (l.world <= 1) return 0;
+    if (!l.boxes || l.world > 64 || l.rank < 0 || l.rank >= l.world || l.slot < 0 || l.slot >= l.slots || n > l.max_floats) {
+        cris_set_error("%s: bad mailbox link (world %d rank %d slot %d / %d, %d values for a capacity of %d)", fn, l.world, l.rank, l.slot,
+                       l.slots, n, l.max_floats);
+        return -1;
+    }
+    return 0;
+}
+
+extern "C" int cris_bn_finalize_sync(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local, float count,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                     float eps, int C, float* scale, float* shift, float* mean, float* invstd, const cris_p2p_link* link,
+                                     void* stream) {
+    CRIS_CHECK_ARG(link && psum && pm2, "null argument");
+    CRIS_CHECK_ARG(link->world <= 1 || (running_mean && running_var), "the exchange takes its moments about the running mean");
+    if (p2p_link_check(*link, 2 * C, __func__)) return -1;
+    return bn_finalize_launch(psum, pm2, nparts, rows_per_part, count_local, count, gamma, beta, running_mean, running_var, momentum, eps,
+                              C, scale, shift, mean, invstd, nullptr, nullptr, *link, stream);
 }
 
 // SyncBN in ONE exchange: every rank shifts its local (sum, M2 about the local mean) to moments about a reference c that is
@@ -245,17 +332,18 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
 __global__ void bn_sync_pack_kernel(float* merged, const float* mean_local, const float* ref, float n_local, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float r = ref[c];
-    const float d = mean_local[c] - r;
-    merged[c] = merged[c] - n_local * r;
-    merged[C + c] = merged[C + c] + n_local * d * d;
+    float s1, s2;
+    bn_sync_pack_vals(merged[c], merged[C + c], mean_local[c], ref[c], n_local, s1, s2);
+    merged[c] = s1;
+    merged[C + c] = s2;
 }
 __global__ void bn_sync_unpack_kernel(float* merged, const float* ref, float count_global, int C) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const float s1 = merged[c], s2 = merged[C + c];
-    merged[c] = s1 + count_global * ref[c];                    // global sum
-    merged[C + c] = fmaxf(s2 - s1 * s1 / count_global, 0.f);   // M2 about the global mean
+    float gsum, gm2;
+    bn_sync_unpack_vals(merged[c], merged[C + c], ref[c], count_global, gsum, gm2);
+    merged[c] = gsum;                                          // global sum
+    merged[C + c] = gm2;                                       // M2 about the global mean
 }
 extern "C" int cris_bn_sync_pack(float* merged, const float* mean_local, const float* ref, float n_local, int C, void* stream) {
     CRIS_CHECK_ARG(merged && mean_local && ref && C > 0, "bad args");
@@ -823,7 +911,7 @@ extern "C" long cris_bn_bwd_ws_floats(const cris_bn_bwd_params* p) {
     return (long)bn_bwd_geometry(p->Bn * p->H * p->W, p->C).rbs * (p->y2 ? 4 : 2) * p->C;
 }
 
-extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
+static int bn_bwd_reduce_launch(const cris_bn_bwd_params* pp, float* local_sums, const cris_p2p_link& link, void* stream) {
     const cris_bn_bwd_params& p = *pp;
     CRIS_CHECK_ARG(p.dz && p.y && p.mean && p.invstd && p.sums && p.part, "null operand");
     CRIS_CHECK_ARG((p.C & 7) == 0 && p.C <= 8192, "C");
@@ -844,13 +932,22 @@ extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) {
     CRIS_LAUNCH_CHECK();
     // the row blocks' partial rows, summed in block order (deterministic) into the [2C] ([4C]) sums (+=)
     const int ncol = (p.y2 ? 4 : 2) * p.C;
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, g.rbs, ncol, p.sums);
+    if (p2p_link_check(link, ncol, __func__)) return -1;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, g.rbs, ncol, p.sums,
+                       local_sums, link);
     CRIS_LAUNCH_CHECK();
     if (p.mul && p.dmul) {
         hipLaunchKernelGGL(bn_dmul_kernel, dim3(p.Bn * cris_cdiv(p.C >> 3, 8)), dim3(256), 0, (hipStream_t)stream, p);
         CRIS_LAUNCH_CHECK();
     }
     return 0;
+}
+
+extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) { return bn_bwd_reduce_launch(pp, nullptr, cris_no_link(), stream); }
+
+extern "C" int cris_bn_bwd_reduce_sync(const cris_bn_bwd_params* pp, float* local_sums, const cris_p2p_link* link, void* stream) {
+    CRIS_CHECK_ARG(pp && link, "null argument");
+    return bn_bwd_reduce_launch(pp, local_sums, *link, stream);
 }
 
 // (a channel-chunked apply geometry, and letting its blocks add up the reduce kernel's partial rows themselves to save the

@@ -16,16 +16,15 @@
 // step t+2 after this rank has joined every exchange of step t+1, i.e. after it finished reading step t.
 #include "common.h"
 #include "../../../include/cris_hip.h"
+#include "p2p_ll.h"
 #include <string.h>
 
 #define P2P_MAXV 32                      // 256 threads x 32 = 8192 floats per exchange at most
-#define P2P_SPIN_LIMIT (1L << 25)      // several seconds of polling: a peer that never arrives raises an error instead of hanging the GPU
 
-static inline size_t p2p_data_floats(int world, int slots, int max_floats) { return (size_t)2 * slots * world * max_floats; }
-
+// the flag-protocol region described above, then (256-byte aligned) the LL words of p2p_ll.h
 extern "C" size_t cris_p2p_mailbox_bytes(int world, int slots, int max_floats) {
     if (world <= 0 || slots <= 0 || max_floats <= 0) return 0;
-    return p2p_data_floats(world, slots, max_floats) * 4 + (size_t)2 * slots * world * 4;
+    return p2p_ll_offset(world, slots, max_floats) + p2p_ll_bytes(world, slots, max_floats);
 }
 
 extern "C" int cris_p2p_alloc(size_t bytes, void** dev_ptr) {
@@ -169,6 +168,29 @@ extern "C" int cris_p2p_allreduce_sum(const cris_p2p_params* pp, void* stream) {
     CRIS_CHECK_ARG(p.n > 0 && p.n <= p.max_floats && p.slot >= 0 && p.slot < p.slots, "n / slot out of the mailbox geometry");
     CRIS_CHECK_ARG(p.n <= 256 * P2P_MAXV, "at most 8192 floats per exchange");
     hipLaunchKernelGGL(p2p_allreduce_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+// In-place sum of a vector through the LL words (p2p_ll.h): every thread sends and sums the values it owns - no flags, no
+// fences, any number of blocks.  The start-up self-test of the words the BatchNorm kernels use (norm.hip).
+__global__ __launch_bounds__(256) void p2p_ll_allreduce_kernel(const cris_p2p_link link, float* data, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int gen = p2p_link_gen(link);
+    p2p_ll_send(link, gen, i, data[i]);
+    bool bad = false;
+    const float s = p2p_ll_recv_sum(link, gen, i, bad);
+    data[i] = bad ? __int_as_float(0x7fc00000) : s;
+    if (bad && link.err) link.err[0] = 1;
+}
+
+extern "C" int cris_p2p_ll_allreduce_sum(const cris_p2p_link* lp, float* data, int n, void* stream) {
+    CRIS_CHECK_ARG(lp && data && lp->boxes, "null operand");
+    const cris_p2p_link& l = *lp;
+    CRIS_CHECK_ARG(l.world >= 1 && l.world <= 64 && l.rank >= 0 && l.rank < l.world, "rank / world");
+    CRIS_CHECK_ARG(n > 0 && n <= l.max_floats && l.slot >= 0 && l.slot < l.slots, "n / slot out of the mailbox geometry");
+    hipLaunchKernelGGL(p2p_ll_allreduce_kernel, dim3(cris_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, l, data, n);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -19,50 +19,72 @@ import torch.distributed as dist
 
 
 class PeerMailboxes:
-    """The SyncBN exchange as one kernel over peer-mapped mailboxes instead of an RCCL collective per BatchNorm layer
-    (csrc/p2p.hip, include/cris_hip.h cris_p2p_*).  Every rank allocates an uncached mailbox, the 64-byte IPC handles travel
-    once through torch.distributed, every rank maps every peer's mailbox.  `self_test()` runs a few exchanges with known data
-    and a short poll limit; the trainer switches to the mailboxes only when that passed on EVERY rank."""
+    """The SyncBN exchange over peer-mapped mailboxes instead of an RCCL collective per BatchNorm layer (csrc/p2p.hip,
+    csrc/p2p_ll.h, include/cris_hip.h cris_p2p_*): every rank allocates an uncached mailbox, the 64-byte IPC handles travel once
+    through the communicator's host channel, every rank maps every peer's mailbox.  Construction happens in three steps so
+    that a failure on ONE rank cannot leave the ranks in different collectives (the caller - TorchDistComm.enable_p2p - runs
+    the same sequence of all-gathers on every rank whatever happens locally): `alloc_and_export()` (local, may raise) ->
+    all-gather of (error, handle) -> `import_peers(handles)` (local, may raise) -> all-gather of errors -> barrier.
+    `self_test()` runs a few exchanges with known data and a short poll limit, on both protocols (the flag-protocol kernel and
+    the LL words the BatchNorm kernels use); the trainer switches to the mailboxes only when that passed on EVERY rank."""
 
     def __init__(self, rank, world, device, slots, max_floats):
         from . import hip
         self.hip, self.lib = hip, hip.load()
-        self.rank, self.world, self.slots, self.max_floats = rank, world, slots, max_floats
-        nbytes = self.lib.cris_p2p_mailbox_bytes(world, slots, max_floats)
+        self.rank, self.world, self.slots, self.max_floats, self.device = rank, world, slots, max_floats, device
+        self.own, self.peers, self.boxes, self.err = None, [], None, None
+
+    def alloc_and_export(self):
+        """allocate this rank's mailbox; returns its 64-byte IPC handle"""
+        nbytes = self.lib.cris_p2p_mailbox_bytes(self.world, self.slots, self.max_floats)
         own = ctypes.c_void_p()
-        hip.check(self.lib.cris_p2p_alloc(nbytes, ctypes.byref(own)), "cris_p2p_alloc")
+        self.hip.check(self.lib.cris_p2p_alloc(nbytes, ctypes.byref(own)), "cris_p2p_alloc")
         self.own = own.value
         handle = (ctypes.c_ubyte * 64)()
-        hip.check(self.lib.cris_p2p_export(self.own, handle), "cris_p2p_export")
-        handles = [None] * world
-        dist.all_gather_object(handles, bytes(handle))
-        self.peers, ptrs = [], []
+        self.hip.check(self.lib.cris_p2p_export(self.own, handle), "cris_p2p_export")
+        return bytes(handle)
+
+    def import_peers(self, handles):
+        ptrs = []
         for q, h in enumerate(handles):
-            if q == rank:
+            if q == self.rank:
                 ptrs.append(self.own)
                 continue
             peer = ctypes.c_void_p()
             buf = (ctypes.c_ubyte * 64).from_buffer_copy(h)
-            hip.check(self.lib.cris_p2p_import(buf, ctypes.byref(peer)), "cris_p2p_import")
+            self.hip.check(self.lib.cris_p2p_import(buf, ctypes.byref(peer)), "cris_p2p_import")
             self.peers.append(peer.value)
             ptrs.append(peer.value)
-        self.boxes = torch.tensor(ptrs, dtype=torch.int64, device=device)
-        self.err = torch.zeros(1, dtype=torch.int32, device=device)
-        dist.barrier()                              # nobody writes into a mailbox that is not mapped yet
+        self.boxes = torch.tensor(ptrs, dtype=torch.int64, device=self.device)
+        self.err = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def link(self, slot, gen_dev=None, gen_host=0, spin_limit=0):
+        """the hip.P2PLink naming exchange `slot` of the step (what cris_bn_finalize_sync / cris_bn_bwd_reduce_sync take)"""
+        assert 0 <= slot < self.slots
+        l = self.hip.P2PLink()
+        l.boxes, l.err = self.boxes.data_ptr(), self.err.data_ptr()
+        l.gen_dev = None if gen_dev is None else gen_dev.data_ptr()
+        l.gen_host, l.rank, l.world = gen_host, self.rank, self.world
+        l.slot, l.slots, l.max_floats, l.spin_limit = slot, self.slots, self.max_floats, spin_limit
+        return l
 
     def self_test(self, spin_limit=1 << 19):
-        """three generations of one exchange with known data (rank r contributes r + 1 + i/7): True when every sum is right and
-        no peer was reported missing.  The poll limit is short (a fraction of a second), so a mapping that does not
-        propagate stores fails here instead of stalling the first training step."""
+        """three generations of one exchange with known data (rank r contributes r + 1 + i/7) on each protocol: True when every
+        sum is right and no peer was reported missing.  The poll limit is short (a fraction of a second), so a mapping that
+        does not propagate stores fails here instead of stalling the first training step."""
         n = min(self.max_floats, 1000)
         idx = torch.arange(n, device=self.boxes.device, dtype=torch.float32) / 7.0
         want = sum(float(q + 1) for q in range(self.world)) + self.world * idx
         ok = True
-        for gen in range(3):
-            t = (float(self.rank + 1) + idx + float(gen)).contiguous()
-            self.allreduce_sum(t, self.slots - 1, gen_host=1000 + gen, spin_limit=spin_limit)
-            torch.cuda.synchronize()
-            ok = ok and bool(torch.allclose(t, want + self.world * float(gen), rtol=0, atol=1e-3)) and int(self.err.item()) == 0
+        for proto in ("flags", "ll"):
+            for gen in range(3):
+                t = (float(self.rank + 1) + idx + float(gen)).contiguous()
+                if proto == "flags":
+                    self.allreduce_sum(t, self.slots - 1, gen_host=1000 + gen, spin_limit=spin_limit)
+                else:
+                    self.ll_allreduce_sum(t, self.slots - 1, gen_host=1000 + gen, spin_limit=spin_limit)
+                torch.cuda.synchronize()
+                ok = ok and bool(torch.allclose(t, want + self.world * float(gen), rtol=0, atol=1e-3)) and int(self.err.item()) == 0
         self.err.zero_()
         return ok
 
@@ -77,6 +99,12 @@ class PeerMailboxes:
         # not through hip.call: the caller (ops.torch_op) already puts this exchange on a command list being recorded
         self.hip.check(self.lib.cris_p2p_allreduce_sum(ctypes.byref(prm), torch.cuda.current_stream().cuda_stream),
                        "cris_p2p_allreduce_sum")
+
+    def ll_allreduce_sum(self, t, slot, gen_dev=None, gen_host=0, spin_limit=0):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() <= self.max_floats and slot < self.slots
+        l = self.link(slot, gen_dev=gen_dev, gen_host=gen_host, spin_limit=spin_limit)
+        self.hip.check(self.lib.cris_p2p_ll_allreduce_sum(ctypes.byref(l), t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream),
+                       "cris_p2p_ll_allreduce_sum")
 
     def close(self):
         for p in self.peers:
@@ -100,19 +128,31 @@ class TorchDistComm:
         # gradient messages and stall the compute stream
         self.grad_group = dist.new_group(ranks=list(range(self.world)))
         self.capturable = dist.get_backend() == "nccl"       # RCCL kernels can be captured into a HIP graph; gloo cannot
-        self.p2p, self._gen_dev, self._slot = None, None, 0
+        self.p2p, self._gen_dev, self._slot, self._fused = None, None, 0, False
 
     def enable_p2p(self, slots, max_floats, gen_dev):
-        """Route allreduce_sum (the SyncBN exchanges) through peer mailboxes; `gen_dev` = the trainer's device step counter.
-        Collective.  Returns None when the mailboxes are in use, else the reason they are not (allocation / IPC mapping /
-        self-test failed on some rank: every rank then keeps the RCCL collectives)."""
-        err, box = None, None
+        """Route the SyncBN exchanges through peer mailboxes; `gen_dev` = the trainer's device step counter.  Collective: every
+        rank runs the SAME sequence of host all-gathers whatever fails locally (a rank whose allocation or mapping fails
+        reports it in the next all-gather instead of leaving the sequence).  Returns None when the mailboxes are in use, else
+        the reason they are not (allocation / IPC mapping / self-test failed on some rank: every rank then keeps the RCCL
+        collectives and frees what it had allocated or mapped)."""
+        import os
+        box, err, handle = None, None, None
         try:
             box = PeerMailboxes(self.rank, self.world, self.device, slots + 1, max_floats)     # (+1: the self-test's slot)
-        except Exception as ex:              # noqa: BLE001 - e.g. IPC handles not importable between these devices
+            handle = box.alloc_and_export()
+        except Exception as ex:              # noqa: BLE001 - e.g. no fine-grained memory, no IPC export
             err = "rank %d: %r" % (self.rank, ex)
-        errs = [e for e in self.all_gather_object(err) if e]
+        got = self.all_gather_object((err, handle))                 # 1: everybody's handle or error
+        errs = [e for e, _ in got if e]
         if not errs:
+            try:
+                box.import_peers([h for _, h in got])
+            except Exception as ex:          # noqa: BLE001 - e.g. IPC handles not importable between these devices
+                err = "rank %d: %r" % (self.rank, ex)
+        errs = errs or [e for e in self.all_gather_object(err) if e]     # 2: mapping errors (every rank saw the same step-1 list, so all skip or none)
+        if not errs:
+            # (this all-gather is also the barrier "nobody writes into a mailbox that is not mapped yet")
             ok = box.self_test()
             errs = ["rank %d: self-test failed" % q for q, o in enumerate(self.all_gather_object(ok)) if not o]
         if errs:
@@ -123,7 +163,16 @@ class TorchDistComm:
                     pass
             return "; ".join(errs)[:300]
         self.p2p, self._gen_dev = box, gen_dev
+        # CRIS_SYNCBN_FUSED=0: the exchange stays a kernel of its own between the BatchNorm launches (round 3's form)
+        self._fused = os.environ.get("CRIS_SYNCBN_FUSED", "1") == "1"
         return None
+
+    def next_link(self):
+        if self.p2p is None or not self._fused:
+            return None
+        slot = self._slot                            # exchange number inside the step, fixed at schedule time
+        self._slot += 1
+        return self.p2p.link(slot, gen_dev=self._gen_dev)
 
     def begin_step(self):
         self._slot = 0
@@ -214,6 +263,9 @@ class RcclComm:
 
     def allreduce_sum_op(self, t):
         return lambda: self.allreduce_sum(t)
+
+    def next_link(self):
+        return None
 
     # --- gradient exchange: own communicator + side stream inside the library ---
     def allreduce_async(self, t):

@@ -93,6 +93,11 @@ class Comm:
         """The exchange of `t` as a callable bound NOW (schedule time) - what ops.torch_op runs and a command list replays."""
         return lambda: self.allreduce_sum(t)
 
+    def next_link(self):
+        """hip.P2PLink of the next SyncBN exchange of the step when the peer mailboxes are in use (the BatchNorm kernels then
+        exchange inside their own launches), else None (exchange by allreduce_sum_op)"""
+        return None
+
 
 class Engine:
     def __init__(self, clip: ClipSpec, head: HeadSpec, params: Dict[str, torch.Tensor], buffers: Dict[str, torch.Tensor],
@@ -415,9 +420,14 @@ class Engine:
             ops.bn_eval_coeffs(gamma, beta, rm, rv, BN_EPS, C, scale, shift)
             return scale, shift, mean, invstd, count
         if self.sync_bn:
-            # SyncBatchNorm (train.py:97-98): ONE all-reduce of [S1 | S2] (moments about the running mean, which every rank
+            # SyncBatchNorm (train.py:97-98): ONE exchange of [S1 | S2] (moments about the running mean, which every rank
             # holds identically) instead of torch's all_gather of (mean, invstd, count)
             gcount = count * self.comm.world
+            link = self.comm.next_link()
+            if link is not None:
+                # peer mailboxes: the exchange happens INSIDE the finalize launch (one launch, as without SyncBN)
+                ops.bn_finalize(st, count, gcount, gamma, beta, rm, rv, BN_MOM, BN_EPS, C, scale, shift, mean, invstd, link=link)
+                return scale, shift, mean, invstd, gcount
             merged = self.zeros(2 * C)
             ops.bn_finalize(st, count, count, gamma, beta, None, None, BN_MOM, BN_EPS, C, None, None, mean, None, merged=merged)
             ops.bn_sync_pack(merged, mean, rm, count, C)
@@ -457,7 +467,10 @@ class Engine:
             # [dbeta | dgamma] (and the paired downsample block) are contiguous in the arena
             nblk = 4 * C if y2 is not None else 2 * C
             arena_block = self.grad_arena[Gb.storage_offset():Gb.storage_offset() + nblk]
-            if self.sync_bn:
+            link = self.comm.next_link() if self.sync_bn else None
+            if link is not None:
+                sums = self.empty(nblk, dtype=F32)          # sums over all ranks, written by the summation launch itself
+            elif self.sync_bn:
                 sums = self.zeros(nblk)
             else:
                 sums = arena_block
@@ -481,7 +494,8 @@ class Engine:
                        mean2=mean2, invstd2=inv2, scale2=sc2, dy2=dy2, lddy2=None if y2 is None else y2.ld,
                        dy2_coff=0 if y2 is None else y2.coff, mul=mul, dmul=dmul, dident=did,
                        lddi=None if ident is None else ident.ld, di_coff=0 if ident is None else ident.coff,
-                       dident_accum=bool(did_acc), between=between if self.sync_bn else None)
+                       dident_accum=bool(did_acc), between=between if (self.sync_bn and link is None) else None,
+                       link=link, local_sums=arena_block if link is not None else None)
 
         self.tape.append(bwd)
         return out

@@ -133,7 +133,7 @@ class GemmQueue:
                     grp.prob[j] = it[0]
                 if KERNEL_TIMER is not None:
                     KERNEL_TIMER.launch("conv_gemm", sum(it[4] for it in chunk), sum(it[5] for it in chunk), "cris_conv_gemm_group_launch",
-                                        C.byref(grp), key[0], tag="group of %d: %s" % (len(chunk), " + ".join(it[6] for it in chunk)))
+                                        C.byref(grp), key[0], tag="group of %d: %s" % (len(chunk), " + ".join(it[6] for it in chunk)), tile=True)
                 else:
                     hip.call("cris_conv_gemm_group_launch", C.byref(grp), key[0], _stream())
 
@@ -141,8 +141,9 @@ class GemmQueue:
 def _launch_gemm(p, variant, flops, nbytes, tag):
     if KERNEL_TIMER is not None:
         # (classified by the problem, not by the kernel that runs it: M <= 144 linears are the text encoder's / per-sample vectors)
+        v = hip.load().cris_conv_gemm_plan(C.byref(p), variant, None)
         KERNEL_TIMER.launch("skinny_gemm" if (p.M <= 144 and p.KH == 1) else "conv_gemm", flops, nbytes, "cris_conv_gemm_variant",
-                            C.byref(p), variant, tag=tag)
+                            C.byref(p), variant, tag=tag, tile=gemm_variants()[v] not in ("skinny1", "skinny9", "skinny9s"))
         return
     hip.call("cris_conv_gemm_variant", C.byref(p), variant, _stream())
 
@@ -209,14 +210,30 @@ class KernelTimer:
 
     def __init__(self):
         self.records = []        # (name, flops, bytes, start_event, end_event)
+        self.tile_flags = []     # per record: ran on a tile kernel
 
-    def launch(self, name, flops, nbytes, fn, *args, tag=""):
+    def launch(self, name, flops, nbytes, fn, *args, tag="", tile=False):
+        """tile: the launch runs one of the forward / input-gradient TILE kernels (conv_gemm_kernel / conv_gemm8_kernel and
+        their grouped forms) - the family whose memory-side traffic the PMC passes report (tile_family())"""
         s = torch.cuda.current_stream()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(s)
         hip.call(fn, *args, s.cuda_stream)
         e1.record(s)
         self.records.append((name, flops, nbytes, e0, e1, tag))
+        self.tile_flags.append(bool(tile))
+
+    def tile_family(self):
+        """{launches, ms, flops, bytes} over every launch of a tile kernel, whatever the problem's class - the same set of
+        launches the PMC summary's "conv_gemm (all tile kernels)" entry covers"""
+        d = dict(launches=0, ms=0.0, flops=0.0, bytes=0.0)
+        for (name, fl, nb, e0, e1, _), t in zip(self.records, self.tile_flags):
+            if t:
+                d["launches"] += 1
+                d["ms"] += e0.elapsed_time(e1)
+                d["flops"] += fl
+                d["bytes"] += nb
+        return d
 
     def by_shape(self):
         """{(kernel, shape tag): {launches, ms, flops, bytes}} - which problem shapes the time goes to"""
@@ -440,7 +457,14 @@ class Stats:
 
 
 def bn_finalize(st: Optional[Stats], count_local, count, gamma, beta, rmean, rvar, momentum, eps, C_, scale, shift, mean, invstd,
-                merged=None, global_stats=None):
+                merged=None, global_stats=None, link=None):
+    """link (hip.P2PLink): SyncBatchNorm - the statistics exchange happens inside this launch (cris_bn_finalize_sync)"""
+    if link is not None:
+        assert merged is None and global_stats is None and st is not None
+        hip.call("cris_bn_finalize_sync", ptr(st[0]), ptr(st[1]), st.nparts, st.rows_per_part, float(count_local), float(count),
+                 ptr(gamma), ptr(beta), ptr(rmean), ptr(rvar), float(momentum), float(eps), C_, ptr(scale), ptr(shift), ptr(mean),
+                 ptr(invstd), C.byref(link), _stream())
+        return
     hip.call("cris_bn_finalize", ptr(st[0]) if st is not None else None, ptr(st[1]) if st is not None else None,
              st.nparts if st is not None else 0, st.rows_per_part if st is not None else 0, float(count_local), float(count),
              ptr(gamma), ptr(beta),
@@ -488,8 +512,10 @@ def bn_apply(y, scale, shift, z, Bn, H, W, C_, *, ldy=None, y_coff=0, ldz=None, 
 def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, lddz=None, dz_coff=0, ldy=None, y_coff=0,
            lddy=None, dy_coff=0, relu=True, pool=False, z=None, ldz=None, z_coff=0, y2=None, ldy2=None, y2_coff=0, mean2=None,
            invstd2=None, scale2=None, dy2=None, lddy2=None, dy2_coff=0, mul=None, dmul=None, dident=None, lddi=None,
-           di_coff=0, dident_accum=False, between=None):
-    """reduce + apply.  `between(sums)` (optional) runs between the two launches (SyncBN all-reduce)."""
+           di_coff=0, dident_accum=False, between=None, link=None, local_sums=None):
+    """reduce + apply.  `between(sums)` (optional) runs between the two launches (SyncBN all-reduce by a collective); with
+    `link` (hip.P2PLink) the summation launch itself adds this rank's sums into `local_sums` and exchanges them
+    (cris_bn_bwd_reduce_sync): `sums` then receives the sums over all ranks."""
     p = hip.BnBwdParams()
     p.dz, p.lddz, p.dz_coff = ptr(dz), lddz if lddz is not None else dz.shape[-1], dz_coff
     if z is not None:
@@ -512,9 +538,12 @@ def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, 
     s = _stream()
     part = torch.empty(hip.load().cris_bn_bwd_ws_floats(C.byref(p)), dtype=torch.float32, device=dz.device)
     p.part = ptr(part)
-    hip.call("cris_bn_bwd_reduce", C.byref(p), s)
-    if between is not None:
-        between(sums)
+    if link is not None:
+        hip.call("cris_bn_bwd_reduce_sync", C.byref(p), ptr(local_sums), C.byref(link), s)
+    else:
+        hip.call("cris_bn_bwd_reduce", C.byref(p), s)
+        if between is not None:
+            between(sums)
     hip.call("cris_bn_bwd_apply", C.byref(p), s)
 
 

@@ -99,7 +99,11 @@ class NativeTrainer:
                 and torch.device(device).type == "cuda" and hasattr(self.comm, "enable_p2p")):
             cmax = max(e.P[pfx + ".weight"].numel() for pfx in e.bn_prefixes)
             why = self.comm.enable_p2p(slots=2 * len(e.bn_prefixes) + 8, max_floats=4 * cmax, gen_dev=self.step_dev)
-            self.syncbn_exchange = "p2p mailboxes" if why is None else "collective (mailboxes refused: %s)" % why
+            if why is None:
+                fused = getattr(self.comm, "_fused", False)
+                self.syncbn_exchange = "p2p mailboxes, exchanged inside the BatchNorm launches" if fused else "p2p mailboxes, one exchange kernel per BatchNorm"
+            else:
+                self.syncbn_exchange = "collective (mailboxes refused: %s)" % why
         if launch is None:
             launch = os.environ.get("CRIS_LAUNCH")
         if launch is None:

@@ -479,6 +479,34 @@ typedef struct {
 } cris_p2p_params;
 int cris_p2p_allreduce_sum(const cris_p2p_params* p, void* stream);
 
+/* The same mailboxes reached from INSIDE other kernels ("LL" words: value and generation in one 8-byte store, csrc/p2p_ll.h; the
+ * LL region lies behind the flag-protocol region and is included in cris_p2p_mailbox_bytes).  A link names one exchange of the
+ * step; the kernels that take one exchange the values they own themselves:
+ *   cris_bn_finalize_sync      SyncBatchNorm forward in ONE launch: merge the local partials, moments about the running mean
+ *                              to every peer, rank-order sum, scale / shift + running statistics (replaces cris_bn_finalize +
+ *                              cris_bn_sync_pack + exchange + cris_bn_sync_unpack + cris_bn_finalize; same arithmetic)
+ *   cris_bn_bwd_reduce_sync    SyncBatchNorm backward: the reduce launch, then ONE launch that adds up the partial rows, adds the
+ *                              local sums into `local_sums` (this rank's d beta / d gamma) and leaves the sums over all ranks in
+ *                              p->sums for cris_bn_bwd_apply (replaces sum + axpy + exchange)
+ *   cris_p2p_ll_allreduce_sum  plain in-place sum of a vector (start-up self-test of the LL words)
+ * Reference semantics: torch.nn.SyncBatchNorm as installed by train.py:97-98. */
+typedef struct {
+    void* const* boxes;       /* DEVICE array [world]: every rank's mailbox as mapped in this process (own one at [rank]) */
+    int* err;                 /* device int set to 1 if a peer never arrived (results are then NaN); or NULL */
+    const int* gen_dev;       /* device step counter (graph / command-list replay) or NULL -> gen_host */
+    int gen_host;
+    int rank, world;          /* world <= 1: no exchange (the kernels behave like their plain forms) */
+    int slot, slots;          /* which exchange of the step this is; exchanges per step the mailbox was sized for */
+    int max_floats;           /* vector capacity the mailbox was sized for */
+    int spin_limit;           /* polls before a missing peer is reported; 0 = the default (~seconds) */
+} cris_p2p_link;
+int cris_p2p_ll_allreduce_sum(const cris_p2p_link* link, float* data, int n, void* stream);
+int cris_bn_finalize_sync(const float* psum, const float* pm2, int nparts, int rows_per_part, float count_local, float count,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                          float eps, int C, float* scale, float* shift, float* mean, float* invstd, const cris_p2p_link* link,
+                          void* stream);
+int cris_bn_bwd_reduce_sync(const cris_bn_bwd_params* p, float* local_sums, const cris_p2p_link* link, void* stream);
+
 /* ---- Data-parallel exchanges on library-owned RCCL communicators (csrc/comm.hip) ---------------------------------------
  * What the reference gets from `dist.init_process_group("nccl")` + `DistributedDataParallel` + `SyncBatchNorm`
  * (train.py:80-102; SURVEY.md 8b "comm entry points"), without torch.distributed on the data path.  One cris_comm per

@@ -27,23 +27,27 @@ def _prim_worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from cris.pytorch_amd.dist import PeerMailboxes
+        from cris.pytorch_amd.dist import TorchDistComm
         dev = torch.device("cuda:0")
         torch.cuda.set_device(dev)
-        box = PeerMailboxes(rank, world, dev, slots=4, max_floats=1000)
-        ok = True
+        comm = TorchDistComm(dev)
         gen = torch.zeros(1, dtype=torch.int32, device=dev)
+        why = comm.enable_p2p(slots=4, max_floats=1000, gen_dev=gen)        # allocation, IPC mapping, self-test of both protocols
+        assert why is None, why
+        box = comm.p2p
+        ok = True
         for step in range(6):                                   # generations 0..5: both parities, every slot reused
             gen.fill_(step)
             for slot, n in enumerate((1, 64, 999, 1000)):
-                g = torch.Generator().manual_seed(100 * step + slot)
-                full = torch.randn(world, n, generator=g)
-                t = full[rank].clone().to(dev)
-                box.allreduce_sum(t, slot, gen_dev=gen if step % 2 else None, gen_host=step)
-                want = full[0].clone()
-                for r in range(1, world):
-                    want = want + full[r]                       # rank order, like the kernel
-                ok = ok and torch.equal(t.cpu(), want)
+                for proto in (box.allreduce_sum, box.ll_allreduce_sum):      # the flag-protocol kernel, then the LL words
+                    g = torch.Generator().manual_seed(100 * step + slot)
+                    full = torch.randn(world, n, generator=g)
+                    t = full[rank].clone().to(dev)
+                    proto(t, slot, gen_dev=gen if step % 2 else None, gen_host=step)
+                    want = full[0].clone()
+                    for r in range(1, world):
+                        want = want + full[r]                   # rank order, like the kernels
+                    ok = ok and torch.equal(t.cpu(), want)
         torch.cuda.synchronize()
         ok = ok and int(box.err.item()) == 0
         dist.barrier()
@@ -68,9 +72,12 @@ def test_peer_mailbox_allreduce_two_ranks_one_gpu():
 
 
 def _train_worker(rank, world, port, p2p, launch, q):
+    """p2p: False = exchange through torch.distributed; "kernel" = mailboxes, the exchange a kernel of its own between the
+    BatchNorm launches (CRIS_SYNCBN_FUSED=0); True = mailboxes, the exchange inside the BatchNorm launches (the default)"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CRIS_SYNCBN_P2P"] = "1" if p2p else "0"
+    os.environ["CRIS_SYNCBN_FUSED"] = "0" if p2p == "kernel" else "1"
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cris.pytorch_amd import arch, synth
@@ -82,7 +89,7 @@ def _train_worker(rank, world, port, p2p, launch, q):
         head = dataclasses.replace(head, dropout=0.0)      # mask indices are rank-local: compare without dropout
         tr = NativeTrainer(clip, head, arch.synthetic_state_dict(clip, head, 0), dev, comm=TorchDistComm(dev), sync_bn=True,
                            launch=launch)
-        assert (tr.comm.p2p is not None) == p2p
+        assert (tr.comm.p2p is not None) == bool(p2p)
         losses = []
         for step in range(4):
             img, word, mask = (t.to(dev) for t in synth.make_batch(4, 64, 9, rank, step))
@@ -90,16 +97,25 @@ def _train_worker(rank, world, port, p2p, launch, q):
             losses.append(float(loss))
         torch.cuda.synchronize()
         err = int(tr.comm.p2p.err.item()) if p2p else 0
-        q.put((rank, losses, err))
+        import hashlib
+        h = hashlib.sha256()
+        for k in sorted(tr.engine.P):
+            h.update(tr.engine.P[k].detach().cpu().numpy().tobytes())
+        for k in sorted(tr.engine.Bf):
+            h.update(tr.engine.Bf[k].detach().cpu().numpy().tobytes())
+        q.put((rank, losses, err, h.hexdigest()))
     finally:
         dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("launch", ["eager", "cmdlist"])
 def test_trainer_with_peer_mailboxes_equals_torch_distributed_exchange(launch):
+    """two ranks, four optimizer steps: the SyncBN exchange through torch.distributed, through the mailbox kernel, and INSIDE the
+    BatchNorm launches (the default) - bit-identical losses, and bit-identical parameters and running statistics at the end (two
+    ranks: a + b in either order; the pack / unpack arithmetic is the same code in all three forms)"""
     ctx = mp.get_context("spawn")
     out = {}
-    for p2p in (False, True):
+    for p2p in (False, "kernel", True):
         q = ctx.Queue()
         port = _free_port()
         procs = [ctx.Process(target=_train_worker, args=(r, 2, port, p2p, launch, q)) for r in range(2)]
@@ -110,7 +126,9 @@ def test_trainer_with_peer_mailboxes_equals_torch_distributed_exchange(launch):
             p.join(120)
             assert p.exitcode == 0
         out[p2p] = res
-    for (_, la, _), (_, lb, err) in zip(out[False], out[True]):
-        assert err == 0
-        for a, b in zip(la, lb):
-            assert abs(a - b) < 1e-2, (la, lb)          # same arithmetic up to the summation order of the exchange
+    for mode in ("kernel", True):
+        for (_, la, _, ha), (_, lb, err, hb) in zip(out[False], out[mode]):
+            assert err == 0
+            assert la == lb, (mode, la, lb)
+            assert ha == hb, "parameters / running statistics differ from the torch.distributed run (%r)" % (mode,)
+    assert out[True][0][3] == out[True][1][3]                  # and both ranks hold the same model

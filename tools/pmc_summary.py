@@ -18,7 +18,9 @@ def short(name):
     return name.split("(")[0].split("<")[0].replace("void ", "")
 
 
-def main(fetch_db, write_db, out):
+def main(fetch_db, write_db, out, steps=0):
+    """steps: training steps the traced command ran (set-up + warm-up + timed): per-step figures = totals / steps"""
+    steps = int(steps)
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     res = {}
     for k in sorted(set(f) | set(w)):
@@ -36,7 +38,7 @@ def main(fetch_db, write_db, out):
         else:
             res[key] = {"launches": nf, "fetch_bytes_per_launch": fpl, "write_bytes_per_launch": wpl}
     # the forward / input-gradient GEMM family as one entry (4-wave tiles + 8-wave tiles): what bench.py's roofline line quotes
-    fam = [res[k] for k in ("conv_gemm_kernel", "conv_gemm8_kernel") if k in res]
+    fam = [res[k] for k in ("conv_gemm_kernel", "conv_gemm8_kernel", "conv_gemm_group_kernel", "conv_gemm8_group_kernel") if k in res]
     if fam:
         n = sum(a["launches"] for a in fam)
         res["conv_gemm (all tile kernels)"] = {
@@ -45,12 +47,15 @@ def main(fetch_db, write_db, out):
             "write_bytes_per_launch": sum(a["write_bytes_per_launch"] * a["launches"] for a in fam) / n}
     for a in res.values():
         a["traffic_bytes_per_launch"] = a["fetch_bytes_per_launch"] + a["write_bytes_per_launch"]
-    json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported; eager launches, %s" % fetch_db, "kernels": res},
-              open(out, "w"), indent=1)
+    total = sum(a["traffic_bytes_per_launch"] * a["launches"] for k, a in res.items() if k != "conv_gemm (all tile kernels)")
+    json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported; eager launches, %s" % fetch_db,
+               "steps": steps, "total_bytes_per_step": total / steps if steps else None, "kernels": res}, open(out, "w"), indent=1)
+    if steps:
+        print("whole step: %.2f GB memory-side traffic per step (%d steps traced)" % (total / steps / 1e9, steps))
     for k, a in sorted(res.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"] * kv[1]["launches"])[:12]:
         print("%-28s n=%5d fetch/launch %8.2f MB write/launch %8.2f MB" % (k, a["launches"], a["fetch_bytes_per_launch"] / 1e6,
                                                                              a["write_bytes_per_launch"] / 1e6))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3])
+    main(*sys.argv[1:5])
