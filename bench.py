@@ -161,7 +161,11 @@ def module_path(args, rank, world, dev):
         model = nn.parallel.DistributedDataParallel(model.cuda(), device_ids=[dev.index], find_unused_parameters=True)   # :100-102
     else:
         model = model.cuda()
-    optimizer = torch.optim.Adam(param_list, lr=cfg.base_lr, weight_decay=0.0)             # train.py:105-107
+    if args.optimizer == "cris":
+        from cris.pytorch_amd import optim as cris_optim                                   # the optional one-line change
+        optimizer = cris_optim.Adam(param_list, lr=cfg.base_lr, weight_decay=0.0)
+    else:
+        optimizer = torch.optim.Adam(param_list, lr=cfg.base_lr, weight_decay=0.0)         # train.py:105-107
     scaler = torch.amp.GradScaler("cuda")                                                 # train.py:111
     nb = 4
     batches = [tuple(t.to(dev) for t in synth.make_batch(args.batch, args.size, word_len, rank, s)) for s in range(nb)]
@@ -215,7 +219,8 @@ def module_path(args, rank, world, dev):
                                    "GradScaler, fp16 autocast outside / bf16 HIP engine inside, trainMetricGPU + .item() syncs%s), "
                                    "CRIS-R50 %dx%d, per-GPU bs=%d, %d-token text, batches resident in HBM"
                                    % ("; SyncBatchNorm + DistributedDataParallel" if world > 1 else "", args.size, args.size, args.batch, word_len),
-                       "path": "module", "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first,
+                       "path": "module", "optimizer": "cris.pytorch_amd.optim.Adam (fused update: %s)" % optimizer._usable() if args.optimizer == "cris" else "torch.optim.Adam",
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first,
                        "final_loss": r[0], "grad_scale": float(scaler.get_scale())},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12)}}))
     if world > 1:
@@ -246,6 +251,9 @@ def main():
                          "star names - build_segmenter(args) -> torch.optim.Adam over its two groups -> GradScaler, driven by the "
                          "reference's loop body (engine/engine.py:37-73: fp16 autocast, scaled backward, scaler.step / update, "
                          "trainMetricGPU + .item() syncs); N > 1: SyncBatchNorm + DistributedDataParallel as train.py:97-102")
+    ap.add_argument("--optimizer", default="torch", choices=["torch", "cris"],
+                    help="--path module: torch = torch.optim.Adam as train.py:105 builds it (the unchanged loop); cris = "
+                         "cris.pytorch_amd.optim.Adam, the optional one-line replacement whose step() is the library's fused update")
     ap.add_argument("--launch-check", action="store_true",
                     help="exercise only the multi-rank launch protocol (spawn, rendezvous, barrier, max-over-ranks, one JSON "
                          "line from rank 0) without touching a GPU - what tests/test_bench_launch.py runs on the CPU")

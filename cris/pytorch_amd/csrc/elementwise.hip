@@ -898,8 +898,13 @@ __device__ __forceinline__ void adam_pack_tile(const cris_adam_desc& d, int lb, 
 
 template <int PT>
 __global__ __launch_bounds__(256) void adam_kernel(const cris_adam_desc* __restrict__ tab, int n_desc, float beta1, float beta2, float eps,
-                                                   float wd, float bc1, float bc2, float gscale, const int* __restrict__ step_dev) {
+                                                   float wd, float bc1, float bc2, float gscale, const int* __restrict__ step_dev,
+                                                   const float* __restrict__ loss_scale_dev, const float* __restrict__ skip_dev) {
     extern __shared__ __attribute__((aligned(16))) unsigned char adam_smem[];
+    // torch.amp.GradScaler semantics on the device (cris_adam_step_amp): the whole update is skipped when the scaler found a
+    // non-finite gradient, and the gradients still carry the loss scale - no host synchronisation, no separate unscale pass
+    if (skip_dev && skip_dev[0] != 0.f) return;
+    if (loss_scale_dev) gscale = gscale / loss_scale_dev[0];
     if (step_dev) {                       // step count lives on the device (HIP-graph replay): bias corrections from it,
         __shared__ float s_bc[2];         // in double precision like torch.optim.Adam's host arithmetic (1 - beta**t)
         if (threadIdx.x == 0) {
@@ -981,12 +986,12 @@ extern "C" int cris_unpack_grads(const cris_adam_desc* dev_table, int n_desc, in
     CRIS_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
-                              float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
-                              int pack_taps, void* stream) {
+extern "C" int cris_adam_step_amp(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
+                                  float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
+                                  const float* loss_scale_dev, const float* skip_dev, int pack_taps, void* stream) {
     CRIS_CHECK_ARG(dev_table && n_desc > 0 && total_blocks > 0, "empty table");
     CRIS_CHECK_ARG(pack_taps == 1 || pack_taps == 9, "a table holds tensors packed with 1 tap (and unpacked ones) or with 9 taps");
-    typedef void (*adam_fn)(const cris_adam_desc*, int, float, float, float, float, float, float, float, const int*);
+    typedef void (*adam_fn)(const cris_adam_desc*, int, float, float, float, float, float, float, float, const int*, const float*, const float*);
     const adam_fn k9 = adam_kernel<9>, k1 = adam_kernel<1>;
     constexpr int LDS9 = AP_TN(9) * AP_LROW(9) * 2, LDS1 = AP_TN(1) * AP_LROW(1) * 2;
     static const int ready = (int)hipFuncSetAttribute((const void*)k9, hipFuncAttributeMaxDynamicSharedMemorySize, LDS9);
@@ -995,7 +1000,25 @@ extern "C" int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int t
         return ready;
     }
     hipLaunchKernelGGL(pack_taps == 9 ? k9 : k1, dim3(total_blocks), dim3(256), pack_taps == 9 ? LDS9 : LDS1, (hipStream_t)stream, dev_table,
-                       n_desc, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale, step_dev);
+                       n_desc, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale, step_dev, loss_scale_dev, skip_dev);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
+                              float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
+                              int pack_taps, void* stream) {
+    return cris_adam_step_amp(dev_table, n_desc, total_blocks, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2, grad_scale, step_dev,
+                              nullptr, nullptr, pack_taps, stream);
+}
+
+// counter[0] += 1 unless skip[0] != 0: the optimizer's step count under a GradScaler that may skip the step (found_inf)
+__global__ void counter_advance_unless_kernel(int32_t* counter, const float* skip) {
+    if (!(skip && skip[0] != 0.f)) counter[0] += 1;
+}
+extern "C" int cris_counter_advance_unless(int32_t* counter, const float* skip, void* stream) {
+    CRIS_CHECK_ARG(counter, "null counter");
+    hipLaunchKernelGGL(counter_advance_unless_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, skip);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(16 * PL) void bn_finalize_kernel(const float* psum,
             mean_o[c] = mean;               // local mean, needed to re-centre M2 about the global mean
             return;
         }
-        if (link.world > 1) {
+        if (link.world > 0) {
             // SyncBatchNorm in this launch: the arithmetic of bn_sync_pack / rank-order sum / bn_sync_unpack / the
             // global_stats branch below, expression for expression (the two paths give the same bits), with the exchange done by
             // the lane that owns the channel: moments about the running mean (identical on every rank) out, sums over ranks in
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     __shared__ float sh[16][17];
     const int cl = threadIdx.x & 15, pl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    const bool sync = link.world > 1;
+    const bool sync = link.world > 0;        // (a world of ONE still goes through the mailbox: tools/dist1_check.py measures the exchange's cost that way)
     // latency-bound (a few blocks, a few loads each): the value to add to and this lane's rows are all requested up front
     float o = 0.f;
     if (pl == 0 && c < ncol) o = sync ? (local_acc ? local_acc[c] : 0.f) : out[c];
@@ -305,7 +305,7 @@ extern "C" int cris_bn_finalize(const float* psum, const float* pm2, int nparts,
 }
 
 static int p2p_link_check(const cris_p2p_link& l, int n, const char* fn) {
-    if (l.world <= 1) return 0;
+    if (l.world <= 0) return 0;
     if (!l.boxes || l.world > 64 || l.rank < 0 || l.rank >= l.world || l.slot < 0 || l.slot >= l.slots || n > l.max_floats) {
         cris_set_error("%s: bad mailbox link (world %d rank %d slot %d / %d, %d values for a capacity of %d)", fn, l.world, l.rank, l.slot,
                        l.slots, n, l.max_floats);
@@ -319,7 +319,7 @@ extern "C" int cris_bn_finalize_sync(const float* psum, const float* pm2, int np
                                      float eps, int C, float* scale, float* shift, float* mean, float* invstd, const cris_p2p_link* link,
                                      void* stream) {
     CRIS_CHECK_ARG(link && psum && pm2, "null argument");
-    CRIS_CHECK_ARG(link->world <= 1 || (running_mean && running_var), "the exchange takes its moments about the running mean");
+    CRIS_CHECK_ARG(link->world <= 0 || (running_mean && running_var), "the exchange takes its moments about the running mean");
     if (p2p_link_check(*link, 2 * C, __func__)) return -1;
     return bn_finalize_launch(psum, pm2, nparts, rows_per_part, count_local, count, gamma, beta, running_mean, running_var, momentum, eps,
                               C, scale, shift, mean, invstd, nullptr, nullptr, *link, stream);

@@ -148,6 +148,15 @@ class Engine:
         N, Cin, taps, Cpad = lay
         return g.view(N, taps, Cpad)[:, :, :Cin].permute(0, 2, 1).reshape(self.P[name].shape)
 
+    def grad_param_view(self, name):
+        """the same as a VIEW of the arena, never a copy (raises where the layout does not allow one): what the drop-in module
+        hands out as `.grad` when cris.pytorch_amd.optim.Adam reads the arena directly"""
+        g, lay = self.G[name], self.gemm_layout(name)
+        if lay is None or (lay[2] == 1 and lay[3] == lay[1]):
+            return g.view(self.P[name].shape)
+        N, Cin, taps, Cpad = lay
+        return g.view(N, taps, Cpad)[:, :, :Cin].permute(0, 2, 1).view(self.P[name].shape)
+
     def grads_param_layout(self):
         return {k: self.grad_param_layout(k) for k in self.G}
 
@@ -638,8 +647,8 @@ class Engine:
         B, H, W, C = x.Bn, x.H, x.W, x.C
         T, G, Hn = H * W, self.clip.pos_grid, self.clip.vis_heads
         Cout = self.clip.embed_dim
-        G = self.group_begin()
-        yc, stc = self.gemm(x, p + ".connect.0.weight", Cout, stats=True, group=G, group_bwd=False)
+        grp = self.group_begin()
+        yc, stc = self.gemm(x, p + ".connect.0.weight", Cout, stats=True, group=grp, group_bwd=False)
         R = self.table(("bicubic", G, H, W), lambda: tables.bicubic_resize_matrix(G, H, W))
         posr = self.empty(T, C, dtype=F32)
         ops.posresize_fwd(R, self.P[p + ".positional_embedding"], T, G, C, posr)
@@ -656,10 +665,10 @@ class Engine:
         Tq, Tk, Tv = self.new_T(B, Hn, T), self.new_T(B, Hn, T), self.new_T(B, Hn, T)
         # q / k / v (+ the `connect` convolution queued above) are independent: grouped launches forward (model/clip.py:112-139);
         # their three input gradients accumulate into ONE buffer (tok.g), so backward keeps them apart
-        q = self.gemm(tok, p + ".q_proj.weight", C, bias=p + ".q_proj.bias", outT=Tq, group=G, group_bwd=False)
-        k = self.gemm(tok, p + ".k_proj.weight", C, bias=p + ".k_proj.bias", outT=Tk, group=G, group_bwd=False)
-        vv = self.gemm(tok, p + ".v_proj.weight", C, bias=p + ".v_proj.bias", outT=Tv, group=G, group_bwd=False)
-        self.group_end(G)
+        q = self.gemm(tok, p + ".q_proj.weight", C, bias=p + ".q_proj.bias", outT=Tq, group=grp, group_bwd=False)
+        k = self.gemm(tok, p + ".k_proj.weight", C, bias=p + ".k_proj.bias", outT=Tk, group=grp, group_bwd=False)
+        vv = self.gemm(tok, p + ".v_proj.weight", C, bias=p + ".v_proj.bias", outT=Tv, group=grp, group_bwd=False)
+        self.group_end(grp)
         o, dOt = self.attention(q, k, vv, Tq["buf"], Tk["buf"], Tv["buf"], B, Hn, T, T)
         c = self.gemm(o, p + ".c_proj.weight", Cout, bias=p + ".c_proj.bias")
         self._patch_outT_on_dgrad(dOt)

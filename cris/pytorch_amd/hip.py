@@ -296,6 +296,8 @@ _SIGS = {
     "cris_zero_bytes": (I, [P, C.c_size_t, P]),
     "cris_zero_many": (I, [P, P]),
     "cris_adam_step": (I, [P, I, I, F, F, F, F, F, F, F, P, I, P]),
+    "cris_adam_step_amp": (I, [P, I, I, F, F, F, F, F, F, F, P, P, P, I, P]),
+    "cris_counter_advance_unless": (I, [P, P, P]),
     "cris_adam_blocks": (I, [P]),
     "cris_adam_block_elems": (I, []),
     "cris_unpack_grads": (I, [P, I, I, P]),

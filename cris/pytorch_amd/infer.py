@@ -92,6 +92,8 @@ class InferEngine(Engine):
              no_dgrad=False, **kw):
         if self.training or not self.fold_bn or not stats:
             return super().gemm(x, wname, N, k=k, pad=pad, stats=stats, geom=geom, out=out, no_dgrad=no_dgrad, **kw)
+        for name in ("group", "group_bwd", "variant"):      # launch grouping / tile hints of the training schedule: the folded
+            kw.pop(name, None)                              # launch is issued by bn(), alone, on the tile the library picks
         assert not kw, "a convolution in front of a BatchNorm has no bias / residual / dropout / transposed copy: %r" % (kw,)
         g = geom or Geom(x.Bn, x.H, x.W, x.C, k, k, 1, pad)
         ph = out if out is not None else Act(None, g.Bn, g.OH, g.OW, N)

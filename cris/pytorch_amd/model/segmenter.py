@@ -14,6 +14,7 @@ by `cris_unpack_grads`), so DDP's bucketed all-reduce, GradScaler's unscale / in
 `.grad` tensors.  There is no eager / CPU fallback: without the HIP library or off the GPU, forward raises.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -74,6 +75,7 @@ class _CrisStep(torch.autograd.Function):
         eng = module._engine
         ctx.module = module
         ctx.direct = len(params) == 1 and params[0] is module._anchor
+        ctx.step_id = module._steps                 # the engine keeps ONE step's saved state (tape / captured buffers)
         st = module._graph_step(img, word, mask, seed)
         ctx.graph = st
         if st is not None:                       # replayed HIP graph: outputs are the capture's static buffers (fresh aliases)
@@ -88,6 +90,10 @@ class _CrisStep(torch.autograd.Function):
     def backward(ctx, _gpred, _gmsk, gloss):
         module = ctx.module
         eng = module._engine
+        if ctx.step_id != module._steps:
+            raise RuntimeError("CRIS (HIP path): backward of a training forward whose saved state a NEWER training forward has "
+                               "overwritten - the engine keeps the activations of one step (call backward before the next "
+                               "training forward; losses of several forwards cannot be back-propagated together)")
         gscale = gloss.detach().reshape(1).to(torch.float32).contiguous()        # GradScaler's factor arrives here
         st = ctx.graph
         if st is not None:
@@ -106,8 +112,13 @@ class _CrisStep(torch.autograd.Function):
 
 
 class CRIS(nn.Module):
+    _instances = weakref.WeakSet()          # live modules (cris.pytorch_amd.optim.Adam looks its parameters' owner up here)
+
     def __init__(self, cfg):
         super().__init__()
+        CRIS._instances.add(self)
+        self._grad_views = False            # set by cris.pytorch_amd.optim.Adam: `.grad` = views of the gradient arena, no conversion pass
+        self._grad_views_active = False
         clip_sd = load_clip_state_dict(_cfg_get(cfg, "clip_pretrain"))
         self.clip_spec = arch.clip_spec_from_state_dict(clip_sd)
         self.head_spec = head_spec_from_cfg(cfg)
@@ -136,12 +147,32 @@ class CRIS(nn.Module):
     def _grad_params(self):
         return [(n, p) for n, p in self.named_parameters() if n != "backbone.logit_scale"]
 
+    def _apply(self, fn, *args, **kwargs):
+        self._plist = None                   # .cuda() / .to() / .float(): the parameter tensors may move
+        return super()._apply(fn, *args, **kwargs)
+
+    def _fast_key(self, device):
+        """what can change the engine between two forwards, without walking the module tree (two traversals of the 600
+        submodules cost ~1.5 ms of host time per step - time in which the GPU idles under the reference's loop): the device, the
+        storage of the first and last parameter (a move re-allocates all of them; in-place loads keep them), the kind of the
+        BatchNorm modules (convert_sync_batchnorm replaces them all), whether a process group exists, the gradient mode"""
+        if getattr(self, "_plist", None) is None:
+            self._plist = list(self.parameters())
+        pl = self._plist
+        return (str(device), pl[0].data_ptr(), pl[-1].data_ptr(), len(pl), type(self.backbone.visual.bn1),
+                dist.is_available() and dist.is_initialized(), bool(self._grad_views))
+
     def _ensure_engine(self, device):
+        fk = self._fast_key(device)
+        if self._engine is not None and fk == getattr(self, "_engine_fast_key", None):
+            return self._engine
+        self._engine_fast_key = fk
         params = {n: p.data for n, p in self.named_parameters()}
         buffers = {n: b for n, b in self.named_buffers() if n.endswith(("running_mean", "running_var"))}
         sync = (any(isinstance(m, nn.SyncBatchNorm) for m in self.modules()) and dist.is_available()
                 and dist.is_initialized() and dist.get_world_size() > 1)
-        key = (str(device), sync, tuple(p.data_ptr() for p in params.values()), tuple(b.data_ptr() for b in buffers.values()))
+        views = bool(self._grad_views) and not sync and not (dist.is_available() and dist.is_initialized())
+        key = (str(device), sync, views, tuple(p.data_ptr() for p in params.values()), tuple(b.data_ptr() for b in buffers.values()))
         if self._engine is not None and key == self._engine_key:
             return self._engine
         for n, p in params.items():
@@ -157,9 +188,14 @@ class CRIS(nn.Module):
         e = self._engine
         srcs, dsts, lays = [], [], []
         self._grad_out = {}
+        self._grad_views_active = views
         for n, p in self._grad_params():
             lay = e.gemm_layout(n)
-            if lay is not None and not (lay[2] == 1 and lay[3] == lay[1]):
+            if views:
+                # gradients stay where the engine wrote them: a 3x3 / padded convolution weight's `.grad` is a strided view of
+                # its GEMM-layout block [n][tap][cpad] (no conversion pass; in-place ops on `.grad` act on the arena)
+                self._grad_out[n] = e.grad_param_view(n)
+            elif lay is not None and not (lay[2] == 1 and lay[3] == lay[1]):
                 d = torch.empty_like(p.data)
                 srcs.append(e.G[n]); dsts.append(d); lays.append(lay)
                 self._grad_out[n] = d
@@ -181,14 +217,25 @@ class CRIS(nn.Module):
         return not any(p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None) for p in self._step_params)
 
     def _assign_grads(self, grads):
-        """gradient semantics of autograd's accumulation on `.grad`: None -> the new gradient; an existing tensor -> += (gradient
-        accumulation over several backward passes); the engine's own buffer left in place by zero_grad(set_to_none=False) already
-        holds the new values"""
+        """gradient semantics of autograd's accumulation on `.grad`: None -> the new gradient (the engine's own buffer, no copy);
+        an existing tensor -> += (gradient accumulation over several backward passes).  `.grad` is never the engine's buffer
+        here: _release_engine_grads() has replaced such a reference by a copy before the forward overwrote the buffer."""
         for p_, g in zip(self._step_params, grads):
             if p_.grad is None:
                 p_.grad = g
-            elif p_.grad is not g:
+            else:
                 p_.grad.add_(g)
+
+    def _release_engine_grads(self):
+        """Direct-gradient mode hands the engine's persistent buffers out as `.grad`.  A training forward clears and re-uses
+        them, so whatever they still mean to the caller must be saved first: a parameter whose `.grad` is still the engine's
+        buffer - zero_grad(set_to_none=False) leaves it in place (zeroed), and so does a loop that accumulates gradients over
+        several micro-batches without any zero_grad - gets a copy instead; the coming backward then adds to the copy like
+        autograd's AccumulateGrad would.  The default loop (zero_grad() sets `.grad` to None) never copies."""
+        bufs = self._step_grads
+        for p_, g in zip(self._step_params, bufs):
+            if p_.grad is g:
+                p_.grad = g.clone()
 
     def _export_grads(self):
         if self._unpack is not None:
@@ -272,16 +319,21 @@ class CRIS(nn.Module):
                 self._step_params = [p for _, p in self._grad_params()]
                 self._step_nbt = [m.num_batches_tracked for m in self.modules()
                                   if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.num_batches_tracked is not None]
+                self._step_grads = [self._grad_out[n] for n, _ in self._grad_params()]
                 self._anchor = torch.zeros(1, device=img.device, requires_grad=True)
                 self._step_cache_key = self._engine_key
             if self._direct_grads():
+                self._release_engine_grads()
                 pred, msk, loss = _CrisStep.apply(self, img, word, mask, seed, self._anchor)
             else:
                 pred, msk, loss = _CrisStep.apply(self, img, word, mask, seed, *self._step_params)
             # the running BatchNorm statistics were updated in place by the HIP kernels; keep torch's counters in step
             if self._step_nbt:
                 torch._foreach_add_(self._step_nbt, 1)
-            return pred.detach(), msk, loss
+            # (graph replay: pred / msk / loss are the capture's static buffers.  The loss gets a copy - a list of losses or a
+            # deferred .item() must not change under the caller; pred and msk (0.35 MB each at 416x416, batch 8) stay aliases
+            # that the NEXT training forward overwrites - the reference's loop consumes them before it, engine/engine.py:60-70)
+            return pred.detach(), msk, loss.clone()
         with torch.no_grad():
             if os.environ.get("CRIS_EVAL_FOLD", "1") == "1":
                 return self._eval_forward_folded(img, word)

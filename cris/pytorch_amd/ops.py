@@ -880,16 +880,18 @@ class AdamTable:
     def refreshes_packs(self):
         return any(pk is not None for pk in self.packs)
 
-    def step(self, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, step_dev=None):
-        """step_dev: optional int32 device tensor holding the 1-based step count (graph replay); else a host counter"""
+    def step(self, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, step_dev=None, loss_scale_dev=None, skip_dev=None):
+        """step_dev: optional int32 device tensor holding the 1-based step count (graph replay); else a host counter.
+        loss_scale_dev / skip_dev: GradScaler's scale and found_inf (device fp32 scalars): gradients are divided by the scale
+        inside the update, a non-zero found_inf skips it (cris_adam_step_amp)"""
         self.step_count += 1
         bc1 = 1.0 - beta1 ** self.step_count
         bc2 = 1.0 - beta2 ** self.step_count
         for taps in (9, 1):
             t = self.tables[taps]
             if t.n:
-                hip.call("cris_adam_step", ptr(t.dev), t.n, t.total_blocks, beta1, beta2, eps, weight_decay, bc1, bc2,
-                         grad_scale, ptr(step_dev), taps, _stream())
+                hip.call("cris_adam_step_amp", ptr(t.dev), t.n, t.total_blocks, beta1, beta2, eps, weight_decay, bc1, bc2,
+                         grad_scale, ptr(step_dev), ptr(loss_scale_dev), ptr(skip_dev), taps, _stream())
 
 
 class UnpackTable:

@@ -1,0 +1,143 @@
+"""Optional optimizer for the drop-in module: `cris.pytorch_amd.optim.Adam` is a `torch.optim.Adam` whose `step()` runs the
+library's fused update (`cris_adam_step_amp`) when every parameter it holds belongs to ONE engine-backed
+`cris.pytorch_amd.model.CRIS` in a single process - the one-line change at the reference's train.py:105
+
+    optimizer = cris.pytorch_amd.optim.Adam(param_list, lr=args.base_lr, weight_decay=args.weight_decay)
+
+Everything else of the loop stays as it is (engine/engine.py:48-57: `scaler.scale(loss).backward()`, `scaler.step(optimizer)`,
+`scaler.update()`, `MultiStepLR.step()`).  What changes underneath:
+  * the update reads the engine's gradient arena directly (weight gradients in the GEMM layout): `.grad` of a 3x3 convolution
+    weight becomes a strided VIEW of that arena instead of a converted copy, so no conversion pass runs and in-place
+    operations on `.grad` (gradient clipping, GradScaler's inf check) act on what the update reads;
+  * one or two kernel launches update all 449 tensors and rewrite the bf16 GEMM-operand copies from the new values - no
+    re-pack of the weights in the next forward, no per-parameter Python in `step()`;
+  * GradScaler hands its scale and found_inf over as device scalars (`_step_supports_amp_scaling`): the gradients are unscaled
+    inside the update and a step with a non-finite gradient is skipped on the device, without a host synchronisation.
+With parameters of anything else (or under DistributedDataParallel, whose averaged gradients live in its own buckets) the
+class IS torch.optim.Adam: `step()` falls through to the parent, and `_step_supports_amp_scaling` reads False.
+`state_dict()` / `load_state_dict()` keep torch.optim.Adam's format (exp_avg / exp_avg_sq / step per parameter), so the
+reference's checkpoints (train.py:159-174,192-207) move both ways."""
+import torch
+import torch.distributed as dist
+
+from . import hip, ops
+
+
+class Adam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **kw):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+        self._cris = None            # the bound module (decided at the first step)
+        self._cris_checked = False
+        self._tab = None
+        self._bind()
+
+    # ------------------------------------------------------------------------------------------------
+    def _bind(self):
+        """find the CRIS module that owns all of this optimizer's parameters; tell it to expose gradients as arena views"""
+        from .model.segmenter import CRIS
+        mine = {id(p) for g in self.param_groups for p in g["params"]}
+        for m in list(CRIS._instances):
+            own = {id(p) for p in m.parameters()}
+            if mine and mine <= own:
+                self._cris = m
+                m._grad_views = True          # (an engine built before this is rebuilt by the next forward: the flag is part of its key)
+                return
+        self._cris = None
+
+    def _usable(self):
+        m = self._cris
+        if m is None or m._engine is None or not getattr(m, "_grad_views_active", False):
+            return False
+        if dist.is_available() and dist.is_initialized():
+            return False                                  # DDP averages into its own buckets: the arena holds local gradients
+        g = self.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            return False
+        return all(gr["betas"] == g["betas"] and gr["eps"] == g["eps"] and gr["weight_decay"] == g["weight_decay"] for gr in self.param_groups)
+
+    @property
+    def _step_supports_amp_scaling(self):
+        return self._usable()
+
+    def _table(self):
+        m, e = self._cris, self._cris._engine
+        key = (m._engine_key,)
+        if self._tab is not None and self._tab_key == key:
+            return self._tab
+        by_id = {id(p): n for n, p in m.named_parameters()}
+        names, lrs, plist = [], [], []
+        for g in self.param_groups:
+            for p in g["params"]:
+                n = by_id[id(p)]
+                if n == "backbone.logit_scale":        # never receives a gradient (unused by the reference's forward, too)
+                    continue
+                names.append(n)
+                lrs.append(float(g["lr"]))
+                plist.append(p)
+        tab = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], lrs, layouts=[e.gemm_layout(n) for n in names],
+                            packs=[e.pack_info.get(n) for n in names])
+        dev = e.P[names[0]].device
+        self._step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        # torch's own per-parameter state IS the table's: state_dict() / load_state_dict() of the parent class then work as usual
+        step0 = 0
+        for i, p in enumerate(plist):
+            st = self.state.get(p)
+            if st and "exp_avg" in st:                  # state loaded (or stepped) before the first fused step: carry it over
+                tab.m[i].copy_(st["exp_avg"].to(dev))
+                tab.v[i].copy_(st["exp_avg_sq"].to(dev))
+                step0 = max(step0, int(float(st["step"])))
+            self.state[p] = {"step": torch.tensor(float(step0)), "exp_avg": tab.m[i], "exp_avg_sq": tab.v[i]}
+        self._step_dev.fill_(step0)
+        self._tab, self._tab_key, self._tab_params, self._tab_lrs = tab, key, plist, list(lrs)
+        return tab
+
+    def _sync_state_steps(self):
+        if self._tab is not None:
+            t = float(int(self._step_dev.item()))
+            for p in self._tab_params:
+                self.state[p]["step"] = torch.tensor(t)
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def step(self, closure=None):
+        if not self._usable():
+            return super().step(closure)
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        tab = self._table()
+        lrs = [float(g["lr"]) for g in self.param_groups for p in g["params"] if p in self.state]
+        if lrs != self._tab_lrs:                          # a scheduler moved the learning rates (train.py:108-110, once per epoch)
+            tab.set_lrs(lrs)
+            self._tab_lrs = lrs
+        g0 = self.param_groups[0]
+        scale, found = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)     # set by GradScaler.step
+        if found is not None:
+            found = found.to(torch.float32).reshape(1)
+        if scale is not None:
+            scale = scale.to(torch.float32).reshape(1)
+        s = torch.cuda.current_stream().cuda_stream
+        hip.call("cris_counter_advance_unless", self._step_dev.data_ptr(), hip.ptr(found), s)
+        tab.step(beta1=g0["betas"][0], beta2=g0["betas"][1], eps=g0["eps"], weight_decay=g0["weight_decay"], grad_scale=1.0,
+                 step_dev=self._step_dev, loss_scale_dev=scale, skip_dev=found)
+        self._cris._engine.packs_current = tab.refreshes_packs      # the update rewrote the bf16 operand copies
+        return loss
+
+    def state_dict(self):
+        self._sync_state_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self._tab is not None:                         # the parent replaced the state tensors by loaded copies: back into the table
+            step = 0
+            for i, p in enumerate(self._tab_params):
+                st = self.state.get(p)
+                if st and "exp_avg" in st:
+                    self._tab.m[i].copy_(st["exp_avg"])
+                    self._tab.v[i].copy_(st["exp_avg_sq"])
+                    step = max(step, int(float(st["step"])))
+                self.state[p] = {"step": torch.tensor(float(step)), "exp_avg": self._tab.m[i], "exp_avg_sq": self._tab.v[i]}
+            self._step_dev.fill_(step)
+            self._tab_lrs = None

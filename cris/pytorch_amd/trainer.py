@@ -94,8 +94,8 @@ class NativeTrainer:
         # SyncBN statistics: 142 exchanges of a few KB per step, all on the critical path.  Default: peer-mapped mailboxes, one
         # kernel per exchange (dist.PeerMailboxes) - when allocation, IPC mapping and a self-test with known data succeed on
         # EVERY rank; otherwise (and with CRIS_SYNCBN_P2P=0, or a communicator without mailboxes) the RCCL collectives.
-        self.syncbn_exchange = "none" if not (self.comm.world > 1 and e.sync_bn) else "collective"
-        if (self.comm.world > 1 and e.sync_bn and os.environ.get("CRIS_SYNCBN_P2P", "1") == "1"
+        self.syncbn_exchange = "none" if not e.sync_bn else "collective"
+        if (e.sync_bn and os.environ.get("CRIS_SYNCBN_P2P", "1") == "1"          # (world 1 + CRIS_FORCE_DIST: the exchange with itself)
                 and torch.device(device).type == "cuda" and hasattr(self.comm, "enable_p2p")):
             cmax = max(e.P[pfx + ".weight"].numel() for pfx in e.bn_prefixes)
             why = self.comm.enable_p2p(slots=2 * len(e.bn_prefixes) + 8, max_floats=4 * cmax, gen_dev=self.step_dev)

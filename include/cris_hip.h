@@ -450,6 +450,14 @@ typedef struct {
 int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
                    float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
                    int pack_taps, void* stream);
+/* The same update under torch.amp.GradScaler, decided on the device (what `scaler.step(optimizer)` does for an optimizer with
+ * `_step_supports_amp_scaling`; engine/engine.py:56): loss_scale_dev (optional) = the scaler's scale, the gradients are divided
+ * by it inside the update; skip_dev (optional) = the scaler's found_inf, != 0 skips the whole update (parameters, moments and
+ * operand copies untouched).  cris_counter_advance_unless keeps a device step count that does not advance on a skipped step. */
+int cris_adam_step_amp(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
+                       float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,
+                       const float* loss_scale_dev, const float* skip_dev, int pack_taps, void* stream);
+int cris_counter_advance_unless(int32_t* counter, const float* skip, void* stream);
 int cris_adam_blocks(const cris_adam_desc* d);       /* blocks one descriptor occupies (host: block_start prefix sums) */
 int cris_adam_block_elems(void);
 /* dst (param layout, desc.p) <- src (GEMM layout, desc.g) for a table of tensors; block_start as for cris_adam_step */
@@ -495,7 +503,7 @@ typedef struct {
     int* err;                 /* device int set to 1 if a peer never arrived (results are then NaN); or NULL */
     const int* gen_dev;       /* device step counter (graph / command-list replay) or NULL -> gen_host */
     int gen_host;
-    int rank, world;          /* world <= 1: no exchange (the kernels behave like their plain forms) */
+    int rank, world;          /* world <= 0: no exchange (the kernels behave like their plain forms); 1: the exchange with itself */
     int slot, slots;          /* which exchange of the step this is; exchanges per step the mailbox was sized for */
     int max_floats;           /* vector capacity the mailbox was sized for */
     int spin_limit;           /* polls before a missing peer is reported; 0 = the default (~seconds) */

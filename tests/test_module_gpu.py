@@ -92,6 +92,144 @@ def test_module_graph_replay_equals_the_eager_schedule():
         assert all(torch.equal(sg[k], se[k]) for k in sg)
 
 
+def _accumulate(direct, zero_style, steps=4):
+    """two micro-batches per optimizer step (backward twice, then step), the gradient handed over directly or through autograd"""
+    import os
+    os.environ["CRIS_MODULE_DIRECT_GRAD"] = "1" if direct else "0"
+    try:
+        dev = torch.device("cuda:0")
+        model, groups = build_segmenter(NS(**TINY))
+        clip, head = arch.specs_by_name("tiny")
+        model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+        model = model.to(dev).train()
+        opt = torch.optim.Adam(groups, lr=1e-4, weight_decay=0.0)
+        out = []
+        for step in range(steps):
+            if zero_style == "none":
+                opt.zero_grad(set_to_none=True)
+            elif zero_style == "zeros":
+                opt.zero_grad(set_to_none=False)
+            for micro in range(2):
+                img, word, mask = _batch(2 * step + micro, dev)
+                _, _, loss = model(img, word, mask)
+                (0.5 * loss).backward()
+            g = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+            opt.step()
+            if zero_style == "never":                  # accumulate over everything: only the first step's gradients are compared
+                out.append(g)
+                break
+            out.append(g)
+        torch.cuda.synchronize()
+        return out
+    finally:
+        os.environ.pop("CRIS_MODULE_DIRECT_GRAD", None)
+
+
+@pytest.mark.parametrize("zero_style", ["none", "zeros", "never"])
+def test_module_gradient_accumulation_direct_equals_autograd(zero_style):
+    """with the gradients handed to `.grad` directly (single process default) a second backward without zero_grad
+    must ADD to the first one, whatever zero_grad style the loop uses - the engine's buffers are re-used by every forward.
+    Reference: autograd's own accumulation (CRIS_MODULE_DIRECT_GRAD=0)."""
+    a, b = _accumulate(True, zero_style), _accumulate(False, zero_style)
+    assert len(a) == len(b)
+    for ga, gb in zip(a, b):
+        assert ga.keys() == gb.keys()
+        for k in ga:
+            assert torch.equal(ga[k], gb[k]), k
+
+
+def test_module_backward_of_a_superseded_forward_is_refused():
+    """the engine keeps one step's activations: backward of a forward that a newer training forward has overwritten raises"""
+    dev = torch.device("cuda:0")
+    model, _ = build_segmenter(NS(**TINY))
+    clip, head = arch.specs_by_name("tiny")
+    model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+    model = model.to(dev).train()
+    _, _, l0 = model(*_batch(0, dev))
+    _, _, l1 = model(*_batch(1, dev))
+    with pytest.raises(RuntimeError, match="NEWER training forward"):
+        l0.backward()
+    l1.backward()                                       # the latest one is fine
+    kept = float(l1)
+    _, _, l2 = model(*_batch(2, dev))
+    assert float(l1) == kept                            # a loss value kept from a previous step does not change under the caller
+
+
+def _loop(opt_cls, steps=5, scaler=True, seed_state=None):
+    dev = torch.device("cuda:0")
+    model, groups = build_segmenter(NS(**TINY))
+    clip, head = arch.specs_by_name("tiny")
+    model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+    model = model.to(dev).train()
+    opt = opt_cls(groups, lr=1e-4, weight_decay=0.0)
+    sc = torch.amp.GradScaler("cuda") if scaler else None
+    losses = []
+    for step in range(steps):
+        img, word, mask = _batch(step, dev)
+        with torch.autocast("cuda"):
+            _, _, loss = model(img, word, mask)
+        opt.zero_grad()
+        if sc is not None:
+            sc.scale(loss).backward()
+            sc.step(opt)
+            sc.update()
+        else:
+            loss.backward()
+            opt.step()
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    return losses, model, opt, sc
+
+
+def test_optional_fused_adam_matches_torch_adam_under_the_reference_loop():
+    """cris.pytorch_amd.optim.Adam in place of torch.optim.Adam (the one-line change at train.py:105), everything else of the
+    loop unchanged (fp16 autocast, GradScaler): same losses as torch's Adam up to the optimizer's fp32 rounding; the fused path
+    really ran (gradients are arena views, operand copies current after the step, no re-pack), the state_dict has torch's
+    format and round-trips through torch.optim.Adam"""
+    from cris.pytorch_amd import optim
+    la, ma, oa, _ = _loop(optim.Adam)
+    lb, mb, ob, _ = _loop(torch.optim.Adam)
+    assert oa._usable() and ma._grad_views_active and ma._unpack is None
+    assert ma._engine.packs_current                                   # the update rewrote the bf16 operand copies
+    w = "neck.f2_v_proj.0.weight"                                      # a 3x3 convolution: `.grad` is a strided view of the arena
+    g = dict(ma.named_parameters())[w].grad
+    assert not g.is_contiguous() and g.shape == dict(ma.named_parameters())[w].shape
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 1e-2, (la, lb)
+    sd = oa.state_dict()
+    assert sd["state"][0]["step"] == 5.0 and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    ob.load_state_dict(sd)                                            # torch's Adam takes it
+    oa.load_state_dict(ob.state_dict())                               # and back
+    assert int(oa._step_dev.item()) == 5
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    worst = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
+    assert worst < 2e-3, worst                                        # five steps of lr 1e-4: the two runs took the same steps
+
+
+def test_optional_fused_adam_skips_the_step_on_found_inf():
+    """GradScaler's contract for `_step_supports_amp_scaling` optimizers: found_inf != 0 -> nothing changes, the step count
+    does not advance; the gradients are divided by grad_scale inside the update"""
+    from cris.pytorch_amd import optim
+    _, model, opt, _ = _loop(optim.Adam, steps=2, scaler=False)
+    dev = torch.device("cuda:0")
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    step0 = int(opt._step_dev.item())
+    img, word, mask = _batch(7, dev)
+    _, _, loss = model(img, word, mask)
+    opt.zero_grad()
+    (loss * 1024.0).backward()
+    opt.grad_scale, opt.found_inf = torch.full((), 1024.0, device=dev), torch.ones((), device=dev)
+    opt.step()
+    assert int(opt._step_dev.item()) == step0
+    after = model.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in before if "num_batches_tracked" not in k and "running" not in k)
+    opt.found_inf = torch.zeros((), device=dev)
+    opt.step()                                                        # now it is taken, with the gradients divided by 1024
+    assert int(opt._step_dev.item()) == step0 + 1
+    moved = max(float((before[k] - after[k]).abs().max()) for k in before if k.endswith("weight") and "bn" not in k)
+    assert 0 < moved < 5e-4                                           # |Adam step| <= lr = 1e-4 (not 1024x that)
+
+
 def test_module_eval_and_checkpoint_reload():
     dev = torch.device("cuda:0")
     model, _ = build_segmenter(NS(**TINY))
