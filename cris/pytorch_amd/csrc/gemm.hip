@@ -519,7 +519,8 @@ int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipS
 // which epilogue instantiation a problem takes: 0 general, 1 lean, 2 lean + bias / ReLU (see gemm_epilogue)
 static int epilogue_kind(const cris_conv_gemm_params& p) {
     const bool plain = p.drop_thresh == 0u && !p.outT && p.out && !p.out_f32 && !(p.resid && p.resid_f32);
-    return !plain ? 0 : (!p.bias && p.act == 0) ? 1 : (p.act == 0 || p.act == 1 || p.act == 3) ? 2 : 0;
+    if (plain && !p.bias && p.act == 0) return p.bnr_y ? 3 : 1;          // 3: lean + BatchNorm-backward partials
+    return !plain ? 0 : (p.act == 0 || p.act == 1 || p.act == 3) ? 2 : 0;
 }
 
 static bool variant_applicable(int v, const cris_conv_gemm_params& p) {
@@ -655,6 +656,7 @@ extern "C" int cris_conv_gemm_group_launch(const cris_conv_gemm_group* gp, int v
     cris_conv_gemm_group g = *gp;
     static const int bm[V_COUNT] = {0, 0, 0, 128, 64, 64, 128, 256, 256, 128, 128, 64}, bn[V_COUNT] = {0, 0, 0, 64, 64, 128, 128, 256, 128, 256, 128, 64};
     const int epi = epilogue_kind(g.prob[0]);
+    CRIS_CHECK_ARG(epi < 3, "BatchNorm-backward partials are not available in grouped launches");
     int start = 0;
     for (int i = 0; i < g.n; ++i) {
         const cris_conv_gemm_params& p = g.prob[i];
@@ -707,6 +709,10 @@ static int conv_gemm_check(const cris_conv_gemm_params& p) {
     CRIS_CHECK_ARG(p.K == p.KH * p.KW * p.C, "K != KH*KW*C");
     CRIS_CHECK_ARG(p.M == p.Bn * p.OH * p.OW, "M != Bn*OH*OW");
     CRIS_CHECK_ARG(p.out || p.outT || p.colsum, "no output");
+    CRIS_CHECK_ARG(!p.bnr_y || (epilogue_kind(p) == 3 && p.colsum && p.colsq && p.bnr_mean && p.bnr_invstd && p.bnr_scale && p.bnr_shift &&
+                                (p.bnr_ldy & 7) == 0 && (size_t)p.M * p.bnr_ldy * 2 < (1UL << 31)),
+                   "BatchNorm-backward partials need the lean epilogue, both tables and the four coefficient vectors");
+    CRIS_CHECK_ARG(p.stat_ld == 0 || p.stat_ld >= p.N, "stat_ld < N");
     CRIS_CHECK_ARG(!p.outT || ((p.T_E & 63) == 0 && p.T_L > 0 && (p.T_Lpad & 3) == 0 && p.T_Lpad >= p.T_L && p.M % p.T_L == 0),
                    "bad transposed-store geometry");
     CRIS_CHECK_ARG((uintptr_t)p.A % 16 == 0 && (uintptr_t)p.Wt % 16 == 0, "operands must be 16-byte aligned");
@@ -726,24 +732,25 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     constexpr int LDS_128x128 = ST_128x128 * (128 + 128) * 128, LDS_64x64 = ST_64x64 * (64 + 64) * 128;
     typedef void (*kern_t)(const cris_conv_gemm_params);
     // [variant][epilogue: 0 general, 1 lean, 2 lean + bias / ReLU]
-    static const kern_t k_128x64[3] = {conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 0>, conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 1>,
-                                       conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 2>};
-    static const kern_t k_64x128[3] = {conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 0>, conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 1>,
-                                       conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 2>};
-    static const kern_t k_128x128[3] = {conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 0>, conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 1>,
-                                        conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 2>};
+    static const kern_t k_128x64[4] = {conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 0>, conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 1>,
+                                       conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 2>, conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 3>};
+    static const kern_t k_64x128[4] = {conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 0>, conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 1>,
+                                       conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 2>, conv_gemm_kernel<64, 128, 2, 2, ST_64x128, 3>};
+    static const kern_t k_128x128[4] = {conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 0>, conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 1>,
+                                        conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 2>, conv_gemm_kernel<128, 128, 2, 2, ST_128x128, 3>};
     // (measured alternatives for this variant: 16x16x32 MFMA with four accumulators 19.50 vs 19.39 ms/step, a 2-stage ring
     // with 5 blocks per CU 20.00 ms/step - neither helps)
-    static const kern_t k_64x64[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 0>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 1>,
-                                      conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 2>};
+    static const kern_t k_64x64[4] = {conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 0>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 1>,
+                                      conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 2>, conv_gemm_kernel<64, 64, 2, 2, ST_64x64, 3>};
     // 64x64 with the K-steps split over two wave groups: two-deep ring per group = 64 KB, two blocks (16 waves) per CU
     constexpr int ST_K2 = 2, LDS_64x64K2 = 2 * ST_K2 * (64 + 64) * 128;
     static const kern_t k_64x64k2[3] = {conv_gemm_kernel<64, 64, 2, 2, ST_K2, 0, 32, 2>, conv_gemm_kernel<64, 64, 2, 2, ST_K2, 1, 32, 2>,
                                         conv_gemm_kernel<64, 64, 2, 2, ST_K2, 2, 32, 2>};
     static const int lds_ready = [&]() {
         int rc = 0;
-        for (int e = 0; e < 3; ++e)
-            rc |= set_lds((const void*)k_64x64k2[e], LDS_64x64K2) | set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
+        for (int e = 0; e < 3; ++e) rc |= set_lds((const void*)k_64x64k2[e], LDS_64x64K2);
+        for (int e = 0; e < 4; ++e)
+            rc |= set_lds((const void*)k_128x64[e], LDS_128x64) | set_lds((const void*)k_64x128[e], LDS_64x128) |
                   set_lds((const void*)k_128x128[e], LDS_128x128) | set_lds((const void*)k_64x64[e], LDS_64x64);
         return rc;
     }();
@@ -757,6 +764,8 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     // automatic choice without a workspace (a caller that predates the `ws` field): the single-pass skinny kernel (same rows
     // per statistics partial as the split-K one) instead of an error
     if (variant < 0 && v == V_SKINNY9S && !p.ws) v = V_SKINNY9;
+    CRIS_CHECK_ARG(!p.bnr_y || v == V_128x64 || v == V_64x64 || v == V_64x128 || v == V_128x128 || v == V_8W_128x128,
+                   "BatchNorm-backward partials: the 4-wave tiles and the 8-wave 128x128 tile only (cris_conv_gemm_plan tells which variant runs)");
     switch (v) {
         case V_8W_256x256: case V_8W_256x128: case V_8W_128x256: case V_8W_128x128:
             return cris_launch_gemm8(v - V_8W_256x256, p, lean, s);
@@ -780,6 +789,7 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
             hipLaunchKernelGGL(k_64x64[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(256), LDS_64x64, s, p);
             break;
         case V_64x64_K2:
+            CRIS_CHECK_ARG(lean < 3, "the K-split 64x64 tile has no BatchNorm-backward epilogue");
             hipLaunchKernelGGL(k_64x64k2[lean], dim3(cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64)), dim3(512), LDS_64x64K2, s, p);
             break;
         case V_64x128:

@@ -401,6 +401,15 @@ static int set_lds8(const void* kern, int bytes) {
 // launcher used by cris_conv_gemm (gemm.hip): variant 0 = 256x256, 1 = 256x128, 2 = 128x256, 3 = 128x128; epi as in gemm.hip
 int cris_launch_gemm8(int variant, const cris_conv_gemm_params& p, int epi, hipStream_t s) {
     typedef void (*kern_t)(const cris_conv_gemm_params);
+    if (epi == 3) {                               // lean + BatchNorm-backward partials: the 128x128 tile only
+        static const kern_t k3 = conv_gemm8_kernel<1, 1, 3>;
+        static const int ready3 = set_lds8((const void*)k3, 5 * (128 + 128) * 128);
+        CRIS_CHECK_ARG(ready3 == 0, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        CRIS_CHECK_ARG(variant == 3 && (p.C & 63) == 0, "BatchNorm-backward partials: 8-wave 128x128 tile only, C % 64 == 0");
+        hipLaunchKernelGGL(k3, dim3(cris_cdiv(p.M, 128) * cris_cdiv(p.N, 128)), dim3(512), 5 * (128 + 128) * 128, s, p);
+        CRIS_LAUNCH_CHECK();
+        return 0;
+    }
     static const kern_t k[4][3] = {
         {conv_gemm8_kernel<2, 2, 0>, conv_gemm8_kernel<2, 2, 1>, conv_gemm8_kernel<2, 2, 2>},
         {conv_gemm8_kernel<2, 1, 0>, conv_gemm8_kernel<2, 1, 1>, conv_gemm8_kernel<2, 1, 2>},

@@ -41,22 +41,41 @@ __device__ __forceinline__ void gemm_epilogue_fast32(const cris_conv_gemm_params
                                                      int lane) {
     const int fr = lane & 31, fg = lane >> 5;
     const bool has_res = p.resid != nullptr;
+    constexpr bool bnr = EPI == 3;          // lean + BatchNorm-backward partials (cris_hip.h: bnr_y): an instantiation of its own,
+                                            // so that the plain lean kernels keep their register count (128x128: 244 -> two waves per SIMD)
     const int act = EPI == 2 ? p.act : 0;
+    const int sld = p.stat_ld ? p.stat_ld : p.N;
     const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, (int)((size_t)p.M * p.ldc * 2), CRIS_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.resid), 0,
                                                                         has_res ? (int)((size_t)p.M * p.ldr * 2) : 0, CRIS_BUF_FLAGS);
-    unsigned vo[4], vr[4];
+    const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bnr_y), 0,
+                                                                        bnr ? (int)((size_t)p.M * p.bnr_ldy * 2) : 0, CRIS_BUF_FLAGS);
+    unsigned vo[4], vr[4], vy[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         vo[r] = ((unsigned)(row0 + fg * 4 + r) * (unsigned)p.ldc + (unsigned)(p.c_coff + col0 + fr)) * 2u;
         vr[r] = has_res ? ((unsigned)(row0 + fg * 4 + r) * (unsigned)p.ldr + (unsigned)(p.r_coff + col0 + fr)) * 2u : CRIS_OOB;
+        vy[r] = bnr ? ((unsigned)(row0 + fg * 4 + r) * (unsigned)p.bnr_ldy + (unsigned)(p.bnr_coff + col0 + fr)) * 2u : CRIS_OOB;
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const float bias = (EPI == 2 && p.bias) ? p.bias[col0 + j * 32 + fr] : 0.f;
         float s1 = 0.f;
+        float b_mean = 0.f, b_inv = 0.f, b_sc = 0.f, b_sh = 0.f, b0 = 0.f, b1 = 0.f;
+        if (bnr) {
+            const int c = col0 + j * 32 + fr;
+            b_mean = p.bnr_mean[c]; b_inv = p.bnr_invstd[c]; b_sc = p.bnr_scale[c]; b_sh = p.bnr_shift[c];
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
+            float yv[16];
+            if (bnr) {                              // wave-uniform: the pre-BatchNorm values of this fragment, 16 loads in flight
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int sy = ((i * 32 + (e >> 2) * 8) * p.bnr_ldy + j * 32) * 2;
+                    yv[e] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsY, vy[e & 3], sy, 0));
+                }
+            }
             // the residual of a whole 32x32 fragment is requested before its first use: one memory round trip per fragment
             // instead of one per 4-row group (a branch around the loads would put a wait behind each group)
             float rres[16];
@@ -84,10 +103,23 @@ __device__ __forceinline__ void gemm_epilogue_fast32(const cris_conv_gemm_params
                 }
                 acc[i][j][e] = x;
                 s1 += x;
-                __builtin_amdgcn_raw_buffer_store_b16((short)f2bf_hw(x), rsO, vo[e & 3], so, 0);
+                const bf16_t xb = f2bf_hw(x);
+                __builtin_amdgcn_raw_buffer_store_b16((short)xb, rsO, vo[e & 3], so, 0);
+                if (bnr) {                          // as bn_bwd_reduce_fast_kernel (MASK 2) on the STORED gradient
+                    const float g = (yv[e] * b_sc + b_sh) > 0.f ? bf2f(xb) : 0.f;
+                    b0 += g;
+                    b1 += g * ((yv[e] - b_mean) * b_inv);
+                }
             }
         }
-        if (p.colsum) {
+        if (bnr) {
+            b0 += __shfl_xor(b0, 32, 64);
+            b1 += __shfl_xor(b1, 32, 64);
+            if (fg == 0) {
+                p.colsum[(size_t)part * sld + col0 + j * 32 + fr] = b0;
+                p.colsq[(size_t)part * sld + col0 + j * 32 + fr] = b1;
+            }
+        } else if (p.colsum) {
             s1 += __shfl_xor(s1, 32, 64);
             const float mu = s1 / (float)(FM * 32);
             float q = 0.f;
@@ -100,8 +132,8 @@ __device__ __forceinline__ void gemm_epilogue_fast32(const cris_conv_gemm_params
                 }
             q += __shfl_xor(q, 32, 64);
             if (fg == 0) {
-                p.colsum[(size_t)part * p.N + col0 + j * 32 + fr] = s1;
-                p.colsq[(size_t)part * p.N + col0 + j * 32 + fr] = q;
+                p.colsum[(size_t)part * sld + col0 + j * 32 + fr] = s1;
+                p.colsq[(size_t)part * sld + col0 + j * 32 + fr] = q;
             }
         }
     }
@@ -213,8 +245,9 @@ __device__ __forceinline__ void gemm_epilogue_fast32_gen(const cris_conv_gemm_pa
                 }
             q += __shfl_xor(q, 32, 64);
             if (fg == 0) {
-                p.colsum[(size_t)part * p.N + col] = s1;
-                p.colsq[(size_t)part * p.N + col] = q;
+                const int sld = p.stat_ld ? p.stat_ld : p.N;
+                p.colsum[(size_t)part * sld + col] = s1;
+                p.colsq[(size_t)part * sld + col] = q;
             }
         }
     }
@@ -228,6 +261,8 @@ __device__ __forceinline__ void gemm_epilogue_fast32_gen(const cris_conv_gemm_pa
 // convolution GEMMs per training step runs; the general form (EPI 0) costs thousands of instructions per wave.
 // EPI 2: the lean case plus a per-column bias and ReLU before (act 1) or after (act 3) the residual - the convolutions of
 // the inference path, whose BatchNorms are folded into weights and bias (cris/pytorch_amd/infer.py).
+// EPI 3: the lean case of an input-gradient GEMM whose output is the gradient of relu(bn(y)): instead of the forward statistics
+// the colsum / colsq tables receive the BatchNorm-backward partial sums (cris_hip.h: bnr_y).
 template <int EPI, int MT, int FM, int FN, typename ACC>
 __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, ACC (&acc)[FM][FN], int row0, int col0, int part,
                                               int lane) {
@@ -251,7 +286,7 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
         }
     }
     constexpr bool LEAN = EPI != 0;
-    constexpr bool BIAS_ACT = EPI != 1;                        // bias / activation compiled in
+    constexpr bool BIAS_ACT = EPI == 0 || EPI == 2;            // bias / activation compiled in
     constexpr int NG = MT == 16 ? 1 : 4;
     const int fr = lane & (MT - 1), fg = lane / MT;
     const bool has_drop = !LEAN && p.drop_thresh > 0u;
@@ -333,7 +368,41 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 }
             }
         }
-        if (p.colsum) {
+        if constexpr (EPI == 3) {
+            // BatchNorm-backward partials of an edge tile (see gemm_epilogue_fast32): rows / columns outside the problem hold 0
+            const int sld = p.stat_ld ? p.stat_ld : p.N;
+            const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.bnr_y), 0,
+                                                                                (int)((size_t)p.M * p.bnr_ldy * 2), CRIS_BUF_FLAGS);
+            const int cc = cvalid ? col : 0;
+            const float b_mean = p.bnr_mean[cc], b_inv = p.bnr_invstd[cc], b_sc = p.bnr_scale[cc], b_sh = p.bnr_shift[cc];
+            float b0 = 0.f, b1 = 0.f;
+#pragma unroll
+            for (int ig = 0; ig < FM * NG; ++ig) {
+                const int i = ig / NG, g = ig % NG;
+                const int rowb = row0 + i * MT + (MT == 16 ? fg * 4 : g * 8 + fg * 4);
+                float yv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = rowb + r;
+                    const unsigned off = (cvalid && m < p.M) ? ((unsigned)m * (unsigned)p.bnr_ldy + (unsigned)(p.bnr_coff + col)) * 2u : CRIS_OOB;
+                    yv[r] = bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(rsY, off, 0, 0));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xs = bf2f(f2bf(vals[ig][r]));                   // the stored gradient (0 outside the problem)
+                    const float gg = (yv[r] * b_sc + b_sh) > 0.f ? xs : 0.f;
+                    b0 += gg;
+                    b1 += gg * ((yv[r] - b_mean) * b_inv);
+                }
+            }
+            if (MT == 16) { b0 += __shfl_xor(b0, 16, 64); b1 += __shfl_xor(b1, 16, 64); }
+            b0 += __shfl_xor(b0, 32, 64);
+            b1 += __shfl_xor(b1, 32, 64);
+            if (fg == 0 && cvalid && part_cnt > 0) {
+                p.colsum[(size_t)part * sld + col] = b0;
+                p.colsq[(size_t)part * sld + col] = b1;
+            }
+        } else if (p.colsum) {
             // BatchNorm statistics, robust + deterministic: per wave row-block (sum, M2 about the block mean);
             // cris_bn_finalize merges the blocks with Chan's formula.  No atomics, no E[x^2]-E[x]^2 cancellation.
             float s1 = 0.f;
@@ -357,8 +426,9 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
             if (MT == 16) q += __shfl_xor(q, 16, 64);
             q += __shfl_xor(q, 32, 64);
             if (fg == 0 && cvalid && part_cnt > 0) {          // parts = ceil(M / rows-per-part): none beyond the last row
-                p.colsum[(size_t)part * p.N + col] = s1;
-                p.colsq[(size_t)part * p.N + col] = q;
+                const int sld = p.stat_ld ? p.stat_ld : p.N;
+                p.colsum[(size_t)part * sld + col] = s1;
+                p.colsq[(size_t)part * sld + col] = q;
             }
         }
     }

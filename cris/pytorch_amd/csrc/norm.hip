@@ -945,6 +945,26 @@ static int bn_bwd_reduce_launch(const cris_bn_bwd_params* pp, float* local_sums,
 
 extern "C" int cris_bn_bwd_reduce(const cris_bn_bwd_params* pp, void* stream) { return bn_bwd_reduce_launch(pp, nullptr, cris_no_link(), stream); }
 
+static int bn_bwd_sum_launch(const cris_bn_bwd_params* pp, int nparts, float* local_sums, const cris_p2p_link& link, void* stream) {
+    const cris_bn_bwd_params& p = *pp;
+    CRIS_CHECK_ARG(p.sums && p.part && nparts > 0 && (p.C & 7) == 0, "bad args");
+    CRIS_CHECK_ARG(!p.y2 && !p.mul, "partial rows from a GEMM epilogue exist for the plain conv -> BatchNorm -> ReLU chain only");
+    const int ncol = 2 * p.C;
+    if (p2p_link_check(link, ncol, __func__)) return -1;
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(cris_cdiv(ncol, 16)), dim3(256), 0, (hipStream_t)stream, p.part, nparts, ncol, p.sums,
+                       local_sums, link);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int cris_bn_bwd_sum(const cris_bn_bwd_params* pp, int nparts, void* stream) {
+    CRIS_CHECK_ARG(pp, "null argument");
+    return bn_bwd_sum_launch(pp, nparts, nullptr, cris_no_link(), stream);
+}
+extern "C" int cris_bn_bwd_sum_sync(const cris_bn_bwd_params* pp, int nparts, float* local_sums, const cris_p2p_link* link, void* stream) {
+    CRIS_CHECK_ARG(pp && link, "null argument");
+    return bn_bwd_sum_launch(pp, nparts, local_sums, *link, stream);
+}
+
 extern "C" int cris_bn_bwd_reduce_sync(const cris_bn_bwd_params* pp, float* local_sums, const cris_p2p_link* link, void* stream) {
     CRIS_CHECK_ARG(pp && link, "null argument");
     return bn_bwd_reduce_launch(pp, local_sums, *link, stream);

@@ -390,9 +390,16 @@ class Engine:
             dT = self._dgrad_outT
             if dT is not None:
                 tkw = dict(outT=dT["buf"], T_L=dT["L"], T_Lpad=dT["Lpad"], T_E=dT["E"], T_sec_stride=dT["sec_stride"])
-            ops.conv_gemm(gy, wd, gD, Wd.shape[0], lda=gy_ld, a_coff=gy_coff, ldb=Wd.shape[1], out=gx, ldc=x.ld, c_coff=x.coff,
-                          resid=gx if acc else None, ldr=x.ld, r_coff=x.coff, variant=variant,
-                          queue=group.b if (group is not None and group_bwd) else None, **tkw)
+            q = group.b if (group is not None and group_bwd) else None
+            src = x.aux.get("bn_src")
+            if src is not None and ops.BNR_FUSE and not acc and q is None and dT is None and x.root is x:
+                # x = relu(bn(y)) and this layer is its ONLY consumer (Engine.bn(single_consumer=True)): the gradient written
+                # here is complete, so the epilogue also produces the BatchNorm backward's partial sums (sum g, sum g xhat)
+                src["parts"] = ops.conv_gemm(gy, wd, gD, Wd.shape[0], lda=gy_ld, a_coff=gy_coff, ldb=Wd.shape[1], out=gx, ldc=x.ld,
+                                             c_coff=x.coff, variant=variant, bnr=src)
+            else:
+                ops.conv_gemm(gy, wd, gD, Wd.shape[0], lda=gy_ld, a_coff=gy_coff, ldb=Wd.shape[1], out=gx, ldc=x.ld, c_coff=x.coff,
+                              resid=gx if acc else None, ldr=x.ld, r_coff=x.coff, variant=variant, queue=q, **tkw)
 
         self.tape.append(bwd)
         return (out, st) if stats else out
@@ -449,8 +456,10 @@ class Engine:
         return scale, shift, mean, invstd, count
 
     def bn(self, y: Act, st, pfx: str, *, relu=True, pool=False, ident: Optional[Act] = None, y2: Optional[Act] = None, st2=None,
-           pfx2: Optional[str] = None, mul=None, out: Optional[Act] = None, want_stats=False):
-        """z = [pool](relu(bn(y) [+ bn2(y2)] [+ ident]) [* mul]); training statistics come from the conv epilogue."""
+           pfx2: Optional[str] = None, mul=None, out: Optional[Act] = None, want_stats=False, single_consumer=False):
+        """z = [pool](relu(bn(y) [+ bn2(y2)] [+ ident]) [* mul]); training statistics come from the conv epilogue.
+        single_consumer: the caller promises that z feeds exactly ONE gemm layer - that layer's input-gradient GEMM may then
+        produce this BatchNorm's backward partial sums in its epilogue (model/clip.py:47-50: bn1 -> conv2, bn2 -> conv3)."""
         C = y.C
         count = float(y.M)
         scale, shift, mean, invstd, gcount = self._bn_coeffs(pfx, st, count, C)
@@ -471,6 +480,11 @@ class Engine:
             return out
         dmul = self.empty(y.Bn, C, dtype=F32) if mul is not None else None
         out.aux["dmul"] = dmul
+        src = None
+        if single_consumer and relu and not pool and ident is None and y2 is None and mul is None and out.root is out:
+            src = dict(y=y.t, ldy=y.ld, coff=y.coff, mean=mean, invstd=invstd, scale=scale, shift=shift, parts=None)
+            out.aux["bn_src"] = src
+
         def bwd():
             Gb = self.G[pfx + ".bias"]
             # [dbeta | dgamma] (and the paired downsample block) are contiguous in the arena
@@ -504,14 +518,15 @@ class Engine:
                        dy2_coff=0 if y2 is None else y2.coff, mul=mul, dmul=dmul, dident=did,
                        lddi=None if ident is None else ident.ld, di_coff=0 if ident is None else ident.coff,
                        dident_accum=bool(did_acc), between=between if (self.sync_bn and link is None) else None,
-                       link=link, local_sums=arena_block if link is not None else None)
+                       link=link, local_sums=arena_block if link is not None else None,
+                       pre_reduced=None if src is None else src["parts"])
 
         self.tape.append(bwd)
         return out
 
-    def conv_bn(self, x: Act, pfx_conv: str, pfx_bn: str, N: int, k=1, pad=0, relu=True, pool=False, out=None, **kw):
+    def conv_bn(self, x: Act, pfx_conv: str, pfx_bn: str, N: int, k=1, pad=0, relu=True, pool=False, out=None, single_consumer=False, **kw):
         y, st = self.gemm(x, pfx_conv + ".weight", N, k=k, pad=pad, stats=True, **kw)
-        return self.bn(y, st, pfx_bn, relu=relu, pool=pool, out=out)
+        return self.bn(y, st, pfx_bn, relu=relu, pool=pool, out=out, single_consumer=single_consumer)
 
     # ------------------------------------------------------------------------------------------
     # LayerNorm layer
@@ -607,10 +622,10 @@ class Engine:
             y1, st1 = self.gemm(x, p + ".conv1.weight", planes, stats=True, group=G, group_bwd=stride > 1)
             yd, std = self.gemm(xi, p + ".downsample.0.weight", planes * 4, stats=True, group=G, group_bwd=stride > 1)
             self.group_end(G)
-            a1 = self.bn(y1, st1, p + ".bn1")
+            a1 = self.bn(y1, st1, p + ".bn1", single_consumer=True)
         else:
-            a1 = self.conv_bn(x, p + ".conv1", p + ".bn1", planes)
-        a2 = self.conv_bn(a1, p + ".conv2", p + ".bn2", planes, k=3, pad=1, pool=stride > 1)
+            a1 = self.conv_bn(x, p + ".conv1", p + ".bn1", planes, single_consumer=True)
+        a2 = self.conv_bn(a1, p + ".conv2", p + ".bn2", planes, k=3, pad=1, pool=stride > 1, single_consumer=True)
         y3, st3 = self.gemm(a2, p + ".conv3.weight", planes * 4, stats=True)
         if has_ds:
             return self.bn(y3, st3, p + ".bn3", relu=True, y2=yd, st2=std, pfx2=p + ".downsample.1")
@@ -784,9 +799,11 @@ class Engine:
         # fusion 4
         cat4 = self.new_act(v4.Bn, v4.H, v4.W, 3 * fo[1])
         # the three 3x3 convolutions of fusion 4 (model/layers.py:300-302) read f5 / f4 / f3 and write three buffers; their input
-        # gradients go to three buffers as well: one grouped launch each way, on the tile the two larger ones would pick alone
+        # gradients go to three buffers as well: one grouped launch each way, see _group_variant
         G = self.group_begin()
-        gv = self._group_variant("f4_proj", "8w128x128" if all(c % 64 == 0 for c in (f5.C, f4.C, f3.C, fo[1])) else "64x128")
+        # (call r04b: forcing one tile on all three - 8w128x128 or 64x128 - is level with letting each keep its own: the two
+        # M 5408 problems share a launch, the M 1352 one runs alone)
+        gv = self._group_variant("f4_proj", "auto")
         y5p, s5p = self.gemm(f5, n + ".f4_proj5.0.weight", fo[1], k=3, pad=1, stats=True, group=G, variant=gv)
         y4p, s4p = self.gemm(f4, n + ".f4_proj4.0.weight", fo[1], k=3, pad=1, stats=True, group=G, variant=gv)
         y3p, s3p = self.gemm(f3, n + ".f4_proj3.0.weight", fo[1], k=3, pad=1, stats=True, group=G, variant=gv)

@@ -29,7 +29,9 @@ class ConvGemmParams(C.Structure):
                 ("T_L", I), ("T_Lpad", I), ("T_E", I),
                 ("drop_p", F), ("drop_thresh", U), ("drop_seed", U), ("drop_stream", U),
                 ("drop_seed_dev", P),
-                ("ws", P)]
+                ("ws", P),
+                ("bnr_y", P), ("bnr_mean", P), ("bnr_invstd", P), ("bnr_scale", P), ("bnr_shift", P),
+                ("bnr_ldy", I), ("bnr_coff", I), ("stat_ld", I), ("pad_", I)]
 
 
 GEMM_GROUP_MAX = 12
@@ -311,6 +313,8 @@ _SIGS = {
     "cris_p2p_ll_allreduce_sum": (I, [P, P, I, P]),
     "cris_bn_finalize_sync": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P]),
     "cris_bn_bwd_reduce_sync": (I, [P, P, P, P]),
+    "cris_bn_bwd_sum": (I, [P, I, P]),
+    "cris_bn_bwd_sum_sync": (I, [P, I, P, P, P]),
     "cris_jpeg_read_header": (I, [P, C.c_size_t, P]),
     "cris_jpeg_decode_coefficients": (I, [P, C.c_size_t, P, P]),
     "cris_jpeg_decode_coefficients_batch": (I, [I, P, P, P, P, I]),

@@ -150,11 +150,14 @@ def _launch_gemm(p, variant, flops, nbytes, tag):
 
 def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None, act=0, resid=None, ldr=None, r_coff=0,
               out=None, ldc=None, c_coff=0, outT=None, T_L=0, T_Lpad=0, T_E=0, T_sec_stride=0, stats=False,
-              drop: Drop = NO_DROP, variant: int = -1, queue: Optional[GemmQueue] = None):
+              drop: Drop = NO_DROP, variant: int = -1, queue: Optional[GemmQueue] = None, bnr: Optional[dict] = None):
     """out[M,N] = epi(A_im2col @ Wt^T).  A bf16 NHWC buffer (row stride lda), Wt bf16 [N][ldb].
     stats=True: also returns the BatchNorm statistics partials (Stats) of the output columns.
     variant: tile variant (index or name, see gemm_variants()); -1 = the library's choice for the problem size.
-    queue: defer the launch to the queue's flush (grouped with the other independent problems waiting there)."""
+    queue: defer the launch to the queue's flush (grouped with the other independent problems waiting there).
+    bnr: dict(y, ldy, coff, mean, invstd, scale, shift) - this GEMM's output is the gradient of relu(bn(y)): its epilogue also
+    writes the BatchNorm-backward partial sums; returns a BnrParts (table [parts][2N] for bn_bwd(pre_reduced=...)), or None when
+    the problem runs on a kernel without that epilogue (the GEMM is then launched plainly and the caller reduces as usual)."""
     p = hip.ConvGemmParams()
     p.A, p.Wt, p.bias = ptr(A), ptr(Wt), ptr(bias)
     p.lda = lda if lda is not None else A.shape[-1]
@@ -185,6 +188,19 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     rows = hip.load().cris_conv_gemm_variant_stat_rows(C.byref(p), variant)   # depends on the tile variant that will run
     if rows < 0:
         raise ValueError("GEMM tile variant %r cannot run this problem" % (variant,))
+    parts = None
+    if bnr is not None:
+        assert not stats
+        epi = C.c_int(0)
+        v = hip.load().cris_conv_gemm_plan(C.byref(p), variant, C.byref(epi))
+        nparts = (g.M + rows - 1) // rows
+        if gemm_variants()[v] not in ("128x64", "64x64", "64x128", "128x128", "8w128x128") or epi.value != 1 or nparts > BNR_MAX_PARTS:
+            bnr = None                           # no such epilogue on this kernel / too long a list: plain launch
+        else:
+            parts = BnrParts(torch.empty(nparts, 2 * N, dtype=torch.float32, device=A.device), nparts)
+            p.colsum, p.colsq, p.stat_ld = ptr(parts.t), parts.t.data_ptr() + 4 * N, 2 * N
+            p.bnr_y, p.bnr_ldy, p.bnr_coff = ptr(bnr["y"]), bnr["ldy"], bnr["coff"]
+            p.bnr_mean, p.bnr_invstd, p.bnr_scale, p.bnr_shift = ptr(bnr["mean"]), ptr(bnr["invstd"]), ptr(bnr["scale"]), ptr(bnr["shift"])
     if stats:
         st = Stats((g.M + rows - 1) // rows, N, rows, A.device)
         p.colsum, p.colsq = ptr(st[0]), ptr(st[1])
@@ -193,10 +209,23 @@ def conv_gemm(A, Wt, g: Geom, N: int, *, lda=None, a_coff=0, ldb=None, bias=None
     p.ws = ptr(ws)
     flops, nbytes, tag = 2.0 * g.M * N * g.K, 2.0 * (g.M * g.C + N * g.K + g.M * N), "M%d N%d K%d k%d" % (g.M, N, g.K, g.KH)
     if queue is not None:
+        assert bnr is None and parts is None, "a queued launch cannot feed a BatchNorm backward that runs before the flush"
         queue.add(p, variant, (A, Wt, bias, resid, out, outT, drop.dev, ws, st.t if st is not None else None), flops, nbytes, tag)
         return st
     _launch_gemm(p, variant, flops, nbytes, tag)
-    return st
+    return parts if bnr is not None else st
+
+
+BNR_MAX_PARTS = int(os.environ.get("CRIS_BNR_MAX_PARTS", "512"))     # longer partial lists (the 86528-pixel maps) keep the separate reduce launch
+BNR_FUSE = os.environ.get("CRIS_BNR_FUSE", "1") == "1"                 # 0: BatchNorm backward always reduces in its own launch (A/B)
+
+
+class BnrParts:
+    """BatchNorm-backward partial sums written by an input-gradient GEMM's epilogue: t [nparts][2C] = (sum g | sum g xhat)"""
+    __slots__ = ("t", "nparts")
+
+    def __init__(self, t, nparts):
+        self.t, self.nparts = t, nparts
 
 
 def gemm_variants():
@@ -512,7 +541,7 @@ def bn_apply(y, scale, shift, z, Bn, H, W, C_, *, ldy=None, y_coff=0, ldz=None, 
 def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, lddz=None, dz_coff=0, ldy=None, y_coff=0,
            lddy=None, dy_coff=0, relu=True, pool=False, z=None, ldz=None, z_coff=0, y2=None, ldy2=None, y2_coff=0, mean2=None,
            invstd2=None, scale2=None, dy2=None, lddy2=None, dy2_coff=0, mul=None, dmul=None, dident=None, lddi=None,
-           di_coff=0, dident_accum=False, between=None, link=None, local_sums=None):
+           di_coff=0, dident_accum=False, between=None, link=None, local_sums=None, pre_reduced: Optional[BnrParts] = None):
     """reduce + apply.  `between(sums)` (optional) runs between the two launches (SyncBN all-reduce by a collective); with
     `link` (hip.P2PLink) the summation launch itself adds this rank's sums into `local_sums` and exchanges them
     (cris_bn_bwd_reduce_sync): `sums` then receives the sums over all ranks."""
@@ -536,6 +565,17 @@ def bn_bwd(dz, y, scale, shift, mean, invstd, sums, dy, Bn, H, W, C_, count, *, 
     p.relu, p.pool = int(relu), int(pool)
     p.count = float(count)
     s = _stream()
+    if pre_reduced is not None:
+        # the partial rows came out of the epilogue of the GEMM that produced dz: only their summation (+ exchange) is left
+        p.part = ptr(pre_reduced.t)
+        if link is not None:
+            hip.call("cris_bn_bwd_sum_sync", C.byref(p), pre_reduced.nparts, ptr(local_sums), C.byref(link), s)
+        else:
+            hip.call("cris_bn_bwd_sum", C.byref(p), pre_reduced.nparts, s)
+            if between is not None:
+                between(sums)
+        hip.call("cris_bn_bwd_apply", C.byref(p), s)
+        return
     part = torch.empty(hip.load().cris_bn_bwd_ws_floats(C.byref(p)), dtype=torch.float32, device=dz.device)
     p.part = ptr(part)
     if link is not None:

@@ -65,6 +65,16 @@ typedef struct {
     uint32_t drop_seed, drop_stream;
     const uint32_t* drop_seed_dev; /* optional device word added to drop_seed (per-step seed of a replayed HIP graph) */
     float* ws;               /* workspace of cris_conv_gemm_ws_floats(p, variant) floats (the split-K skinny variant; else unused) */
+    /* BatchNorm-BACKWARD partials instead of the forward statistics (input-gradient GEMMs; tile variants only): when bnr_y is set,
+     * the output of this GEMM is dz, the gradient of z = relu(bn(y)) (model/clip.py:47-50 `relu(bn(conv(.)))` whose only consumer is
+     * the convolution this GEMM differentiates), and colsum / colsq receive per row block (sum g, sum g * xhat) with
+     * g = dz where scale*y + shift > 0 else 0, xhat = (y - mean) * invstd - what cris_bn_bwd_reduce would compute in a launch of
+     * its own.  stat_ld: row stride of the colsum / colsq tables in floats (0 = N), so that both can live in ONE [parts][2N]
+     * table (colsq = colsum + N) that cris_bn_bwd_sum adds up. */
+    const cris_bf16* bnr_y;
+    const float* bnr_mean; const float* bnr_invstd; const float* bnr_scale; const float* bnr_shift;
+    int bnr_ldy, bnr_coff;
+    int stat_ld, pad_;
 } cris_conv_gemm_params;
 int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
 /* rows per BatchNorm-statistics partial written for this problem (depends on the tile variant chosen; host only) */
@@ -226,6 +236,9 @@ typedef struct {
     float count;                                     /* rows entering the statistics (global count under SyncBN) */
 } cris_bn_bwd_params;
 int cris_bn_bwd_reduce(const cris_bn_bwd_params* p, void* stream);
+/* the second half of cris_bn_bwd_reduce alone: p->part already holds `nparts` partial rows [2C] (written by the epilogue of the
+ * input-gradient GEMM that produced dz: cris_conv_gemm_params.bnr_y); adds them up in row order into p->sums (+=) */
+int cris_bn_bwd_sum(const cris_bn_bwd_params* p, int nparts, void* stream);
 long cris_bn_bwd_ws_floats(const cris_bn_bwd_params* p);
 int cris_bn_bwd_apply(const cris_bn_bwd_params* p, void* stream);
 
@@ -514,6 +527,8 @@ int cris_bn_finalize_sync(const float* psum, const float* pm2, int nparts, int r
                           float eps, int C, float* scale, float* shift, float* mean, float* invstd, const cris_p2p_link* link,
                           void* stream);
 int cris_bn_bwd_reduce_sync(const cris_bn_bwd_params* p, float* local_sums, const cris_p2p_link* link, void* stream);
+/* nparts > 0: the partial rows are already in p->part (cris_bn_bwd_sum's case), only the summation + exchange launch runs */
+int cris_bn_bwd_sum_sync(const cris_bn_bwd_params* p, int nparts, float* local_sums, const cris_p2p_link* link, void* stream);
 
 /* ---- Data-parallel exchanges on library-owned RCCL communicators (csrc/comm.hip) ---------------------------------------
  * What the reference gets from `dist.init_process_group("nccl")` + `DistributedDataParallel` + `SyncBatchNorm`

@@ -125,8 +125,10 @@ def test_rccl_collectives_inside_the_captured_graph():
         out = r.stdout.decode()
         line = [x for x in out.splitlines() if x.startswith("mode ")]
         assert r.returncode == 0 and line, out[-2000:]
-        m = re.match(r"mode (\w+) -> launch (\w+) graph_error (.*?) \| .* losses (\[.*?\]) \.\.\. ([0-9.]+)", line[0])
+        m = re.match(r"mode (\w+) -> launch (\w+) graph_error (.*?) syncbn (.*?) \| .* losses (\[.*?\]) \.\.\. ([0-9.]+)", line[0])
         assert m, line[0]
         assert m.group(2) == mode and m.group(3) == "None", line[0]
-        got[mode] = (m.group(4), m.group(5))
+        # (with a world of one the mailboxes are in use as well: the BatchNorm kernels exchange with themselves inside their launches)
+        assert "inside the BatchNorm launches" in m.group(4), line[0]
+        got[mode] = (m.group(5), m.group(6))
     assert got["graph"] == got["cmdlist"] == got["eager"], got

@@ -405,6 +405,36 @@ def test_conv_gemm_group_matches_single_launches(variant, epi):
             assert s1.rows_per_part == s2.rows_per_part and torch.equal(s1.t[:, :s1.nparts], s2.t[:, :s2.nparts])
 
 
+@pytest.mark.parametrize("variant", ["64x64", "64x128", "128x128", "8w128x128", -1])
+@pytest.mark.parametrize("case", [dict(B=2, H=26, W=26, C=128, N=64, k=3), dict(B=3, H=13, W=11, C=64, N=256, k=1),
+                                  dict(B=8, H=52, W=52, C=128, N=128, k=3)])
+def test_conv_gemm_bn_backward_partials(variant, case):
+    """the input-gradient GEMM's epilogue also produces the BatchNorm-backward partial sums of the layer whose output gradient it
+    writes (cris_conv_gemm_params.bnr_y): summed over the row blocks they equal sum g and sum g * xhat of the STORED gradient
+    with g = dz where scale * y + shift > 0 - on interior and edge tiles (M 1352 / 429 / 21632) - and the output is unchanged"""
+    B, H, W, C_, N, k = case["B"], case["H"], case["W"], case["C"], case["N"], case["k"]
+    x = rnd(B, H, W, C_).to(BF).float()
+    w = (rnd(N, C_, k, k, seed=1) / math.sqrt(C_ * k * k)).to(BF).float()
+    g = Geom(B, H, W, C_, k, k, 1, k // 2)
+    y = rnd(g.M, N, seed=2).to(BF)
+    mean, invstd = rnd(N, seed=3) * 0.1, 1.0 + 0.2 * rnd(N, seed=4).abs()
+    scale, shift = 1.0 + 0.3 * rnd(N, seed=5), 0.2 * rnd(N, seed=6)
+    dev = lambda t: t.to(DEV).contiguous()
+    out = torch.empty(g.M, N, dtype=BF, device=DEV)
+    plain = torch.empty(g.M, N, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), bf(pack_F(w)), g, N, out=plain, variant=variant)
+    parts = ops.conv_gemm(bf(x), bf(pack_F(w)), g, N, out=out, variant=variant,
+                          bnr=dict(y=dev(y), ldy=N, coff=0, mean=dev(mean), invstd=dev(invstd), scale=dev(scale), shift=dev(shift)))
+    assert isinstance(parts, ops.BnrParts) and parts.t.shape == (parts.nparts, 2 * N)
+    assert torch.equal(out, plain)
+    dz, yf = out.float().cpu(), y.float()
+    gg = torch.where(yf * scale + shift > 0, dz, torch.zeros_like(dz))
+    got = parts.t.double().sum(0).cpu()
+    ref0, ref1 = gg.double().sum(0), (gg.double() * ((yf.double() - mean.double()) * invstd.double())).sum(0)
+    tol = 2e-4 * float(gg.abs().double().sum(0).max())
+    assert float((got[:N] - ref0).abs().max()) <= tol and float((got[N:] - ref1).abs().max()) <= 2 * tol, (got[:4], ref0[:4])
+
+
 def test_conv_gemm_group_chunks_and_mixed_keys():
     """more problems than CRIS_GEMM_GROUP_MAX, two epilogue kinds and a skinny problem in one queue: several launches, same results"""
     q = ops.GemmQueue()
