@@ -101,8 +101,8 @@ class InferEngine(Engine):
         return ph, None
 
     def bn(self, y: Act, st, pfx: str, *, relu=True, pool=False, ident: Optional[Act] = None, y2: Optional[Act] = None, st2=None,
-           pfx2: Optional[str] = None, mul=None, out: Optional[Act] = None, want_stats=False):
-        pd = y.aux.pop("pending", None) if not self.training else None
+           pfx2: Optional[str] = None, mul=None, out: Optional[Act] = None, want_stats=False, single_consumer=False):
+        pd = y.aux.pop("pending", None) if not self.training else None      # (single_consumer: a hint for the training backward only)
         if pd is None:
             return super().bn(y, st, pfx, relu=relu, pool=pool, ident=ident, y2=y2, st2=st2, pfx2=pfx2, mul=mul, out=out,
                               want_stats=want_stats)
