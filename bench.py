@@ -170,15 +170,30 @@ def module_path(args, rank, world, dev):
     nb = 4
     batches = [tuple(t.to(dev) for t in synth.make_batch(args.batch, args.size, word_len, rank, s)) for s in range(nb)]
 
+    phases = ("forward", "zero_grad", "backward", "scaler.step", "scaler.update", "metric", "item")
+    marks = []                                   # --phase-times: (host time, device event) at every phase boundary of every timed step
+
+    def mark():
+        if args.phase_times:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append((time.perf_counter(), ev))
+
     def step(i):
         image, text, target = batches[i % nb]
         target = target if target.dim() == 4 else target.unsqueeze(1)
+        mark()
         with torch.autocast("cuda"):                                                      # engine/engine.py:48
             pred, target, loss = model(image, text, target)
+        mark()
         optimizer.zero_grad()
+        mark()
         scaler.scale(loss).backward()
+        mark()
         scaler.step(optimizer)
+        mark()
         scaler.update()
+        mark()
         o = (torch.sigmoid(pred.flatten(1)) >= 0.35)                                       # utils/misc.py:114-129
         t = target.flatten(1).bool()
         ious = (o & t).sum(1) / ((o | t).sum(1) + 1e-6)
@@ -188,13 +203,17 @@ def module_path(args, rank, world, dev):
             dist.all_reduce(l)
             dist.all_reduce(iou)
             dist.all_reduce(pr5)
-        return l.item() / world, iou.item() / world, pr5.item() / world                   # the meters' .item() syncs (:67-69)
+        mark()
+        r = l.item() / world, iou.item() / world, pr5.item() / world                      # the meters' .item() syncs (:67-69)
+        mark()
+        return r
 
     model.train()
     first = None
     for i in range(max(args.warmup, 2)):
         r = step(i)
         first = first if first is not None else r[0]
+    del marks[:]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -209,9 +228,22 @@ def module_path(args, rank, world, dev):
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
+    phase_ms = None
+    if args.phase_times and marks:
+        # per phase: host time spent in it, and device time between the events recorded at its two ends (the device works
+        # through what the host queued; a phase whose device time exceeds its host time ran behind the host, and vice versa)
+        n = len(phases) + 1
+        host, devt = [0.0] * len(phases), [0.0] * len(phases)
+        for s0 in range(0, len(marks) - n + 1, n):
+            for k in range(len(phases)):
+                host[k] += 1e3 * (marks[s0 + k + 1][0] - marks[s0 + k][0])
+                devt[k] += marks[s0 + k][1].elapsed_time(marks[s0 + k + 1][1])
+        cnt = len(marks) // n
+        phase_ms = {ph: {"host_ms": host[k] / cnt, "device_ms": devt[k] / cnt} for k, ph in enumerate(phases)}
     if rank == 0:
         sps = world * args.batch * args.steps / dt
         print(json.dumps({
+            "phase_times": phase_ms,
             "metric": "train-step samples/sec, CRIS-R50 416x416 bs=64; loss parity vs ref", "value": sps, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1000.0 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -219,7 +251,7 @@ def module_path(args, rank, world, dev):
                                    "GradScaler, fp16 autocast outside / bf16 HIP engine inside, trainMetricGPU + .item() syncs%s), "
                                    "CRIS-R50 %dx%d, per-GPU bs=%d, %d-token text, batches resident in HBM"
                                    % ("; SyncBatchNorm + DistributedDataParallel" if world > 1 else "", args.size, args.size, args.batch, word_len),
-                       "path": "module", "optimizer": "cris.pytorch_amd.optim.Adam (fused update: %s)" % optimizer._usable() if args.optimizer == "cris" else "torch.optim.Adam",
+                       "path": "module", "replay": os.environ.get("CRIS_MODULE_REPLAY", "graph"), "optimizer": "cris.pytorch_amd.optim.Adam (fused update: %s)" % optimizer._usable() if args.optimizer == "cris" else "torch.optim.Adam",
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first,
                        "final_loss": r[0], "grad_scale": float(scaler.get_scale())},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12)}}))
@@ -254,6 +286,7 @@ def main():
     ap.add_argument("--optimizer", default="torch", choices=["torch", "cris"],
                     help="--path module: torch = torch.optim.Adam as train.py:105 builds it (the unchanged loop); cris = "
                          "cris.pytorch_amd.optim.Adam, the optional one-line replacement whose step() is the library's fused update")
+    ap.add_argument("--phase-times", action="store_true", help="--path module: host and device time of every phase of the loop body")
     ap.add_argument("--launch-check", action="store_true",
                     help="exercise only the multi-rank launch protocol (spawn, rendezvous, barrier, max-over-ranks, one JSON "
                          "line from rank 0) without touching a GPU - what tests/test_bench_launch.py runs on the CPU")

@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = ["api.hip", "gemm.hip", "gemm8.hip", "wgrad.hip", "norm.hip", "attention.hip", "elementwise.hip", "evalpost.hip", "inputpipe.hip", "p2p.hip", "comm.hip", "jpeg.hip", "png.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm8.hip", "wgrad.hip", "norm.hip", "attention.hip", "elementwise.hip", "smallf32.hip", "evalpost.hip", "inputpipe.hip", "p2p.hip", "comm.hip", "jpeg.hip", "png.hip"]
 LIB = os.path.join(HERE, "libcris_hip.so")
 STAMP = os.path.join(HERE, ".build_stamp")
 # -fno-slp-vectorize -fno-vectorize: keep packed-FP32 VALU instructions (v_pk_mul/add/fma_f32) out of the code object.
@@ -21,7 +21,7 @@ OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
 
 def _digest():
     h = hashlib.sha256()
-    for f in SOURCES + ["common.h", "gemm_common.h", "jpeg_core.h", os.path.join("..", "..", "..", "include", "cris_hip.h")]:
+    for f in SOURCES + ["common.h", "gemm_common.h", "p2p_ll.h", "jpeg_core.h", os.path.join("..", "..", "..", "include", "cris_hip.h")]:
         with open(os.path.join(HERE, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

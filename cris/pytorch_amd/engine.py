@@ -107,6 +107,10 @@ class Engine:
         # a model that evaluates during training (engine/engine.py:90-123 `validate`) would otherwise hold both twice
         self.inference_only = inference_only
         self.embed_live = None          # optional uint8 [vocabulary]: rows of the token embedding that ever had a gradient (trainer)
+        # the sentence vector and the (at most batch-size rows of) layers it runs through in fp32 (csrc/smallf32.hip; CRIS_STATE_FP32=0:
+        # bf16 GEMM launches as in rounds 1-3)
+        import os
+        self.state_f32 = os.environ.get("CRIS_STATE_FP32", "1") == "1"
         self.P, self.Bf = params, buffers
         self.comm = comm or Comm()
         self.sync_bn = sync_bn and (self.comm.world > 1 or debug.HOOKS.force_dist)
@@ -544,6 +548,8 @@ class Engine:
         ops.ln_fwd(x.t, gamma, beta, rows, C, mean, rstd, ldx=x.ld, y=None if y is None else y.t,
                    ypos=None if ypos is None else ypos.t, pos=pos, pos_rows=pos_rows, resid=None if resid is None else resid.t,
                    out_f32=None if outs is None else outs.t, in_relu=in_relu, in_drop=in_drop, out_drop=out_drop, eps=LN_EPS)
+        if y is not None:
+            y.aux["ln_stats"] = (mean, rstd)
         if self.training:
             def bwd():
                 if outs is not None:
@@ -737,23 +743,50 @@ class Engine:
             self._link_stream(x2, x1)
             x = x2
         xf, _, _ = self.ln(x, "backbone.ln_final", dx_stream=x)
-        rows = Act(self.empty(B, D), B, 1, 1, D)
         eot = torch.empty(B, dtype=torch.int32, device=self.dev)
-        ops.eot_gather(word, xf.t, D, rows.t, eot)
-        if self.training:
-            def bwd_eot():
-                gx, acc = xf.grad_target()
-                if not acc:
-                    ops.zero_(gx)
-                ops.eot_scatter_add(eot, rows.g, B, L, D, gx)
-            self.tape.append(bwd_eot)
-        state = self.gemm(rows, "backbone.text_projection", self.clip.embed_dim, w_transposed=True)
+        if self.state_f32 and B <= ops.SMALL_MAX_ROWS:
+            state = self._state_f32(word, x, xf, eot, B, L, D)
+        else:
+            rows = Act(self.empty(B, D), B, 1, 1, D)
+            ops.eot_gather(word, xf.t, D, rows.t, eot)
+            if self.training:
+                def bwd_eot():
+                    gx, acc = xf.grad_target()
+                    if not acc:
+                        ops.zero_(gx)
+                    ops.eot_scatter_add(eot, rows.g, B, L, D, gx)
+                self.tape.append(bwd_eot)
+            state = self.gemm(rows, "backbone.text_projection", self.clip.embed_dim, w_transposed=True)
         if self.training:
             def bwd_embed():
                 ops.embed_bwd(word, x0.g, self.G["backbone.token_embedding.weight"], self.G["backbone.positional_embedding"],
                               row_live=self.embed_live)
             self.tape.insert(self._text_tape_start, bwd_embed)
         return xf, state
+
+    def _state_f32(self, word, x: Act, xf: Act, eot, B, L, D) -> Act:
+        """state = LayerNorm(x)[eot] @ text_projection (model/clip.py:449-456) in fp32: the rows are normalised from the fp32
+        residual stream with the statistics ln_final saved (not gathered from its bf16 output), the [B, D] x [D, E] product runs
+        on the VALU from the fp32 parameter.  Returns an fp32 Act [B, E]; its consumers (neck.txt_proj, proj.txt) continue in fp32."""
+        E = self.clip.embed_dim
+        mean, rstd = xf.aux["ln_stats"]
+        Pn = "backbone.text_projection"
+        rows = torch.empty(B, D, dtype=F32, device=self.dev)
+        ops.eot_gather_ln_f32(word, x.t, mean, rstd, self.P["backbone.ln_final.weight"], self.P["backbone.ln_final.bias"], D, rows, eot)
+        state = Act(torch.empty(B, E, dtype=F32, device=self.dev), B, 1, 1, E)
+        ops.linear_f32_small(rows, self.P[Pn], state.t, w_is_kn=True)
+        if self.training:
+            def bwd():
+                ds = state.g                                                  # fp32 [B, E]: neck.txt_proj + proj.txt
+                ops.outer_sum_f32_small(rows, ds, self.G[Pn])                 # dP[d][e] = sum_b rows[b][d] ds[b][e]
+                drows = torch.empty(B, D, dtype=F32, device=self.dev)
+                ops.linear_f32_small(ds, self.P[Pn], drows)                   # drows[b][d] = sum_e ds[b][e] P[d][e]
+                gx, acc = xf.grad_target()
+                if not acc:
+                    ops.zero_(gx)
+                ops.eot_scatter_add_f32(eot, drows, B, L, D, gx)
+            self.tape.append(bwd)
+        return state
 
     def _link_stream(self, new: Act, old: Act):
         """x_new = x_old + f(..): the stream gradient passes through unchanged - share one fp32 buffer."""
@@ -774,17 +807,24 @@ class Engine:
         fo = self.head.fpn_out
         B = v5.Bn
         # text projection: Linear(no bias) + BN1d + ReLU on [B, C]
-        ys, sts = self.gemm(state, n + ".txt_proj.0.weight", fo[2], stats=True)
-        s = self.bn(ys, sts, n + ".txt_proj.1")
-        s32 = self.empty(B, fo[2], dtype=F32)
-        ops.cast_bf16_f32(s.t, s32)
+        f32_head = state.t.dtype == F32
+        if f32_head:
+            s, s32, txt_bwd = None, *self._txt_proj_f32(state, n + ".txt_proj", fo[2])
+        else:
+            ys, sts = self.gemm(state, n + ".txt_proj.0.weight", fo[2], stats=True)
+            s = self.bn(ys, sts, n + ".txt_proj.1")
+            s32 = self.empty(B, fo[2], dtype=F32)
+            ops.cast_bf16_f32(s.t, s32)
         y5, st5 = self.gemm(v5, n + ".f1_v_proj.0.weight", fo[2], stats=True)
         u = self.bn(y5, st5, n + ".f1_v_proj.1", mul=s32, want_stats=True)
         if self.training:
-            def bwd_s():
-                gs, acc = s.grad_target()
-                assert not acc
-                ops.cast_f32_bf16(u.aux["dmul"], gs)
+            if f32_head:
+                bwd_s = lambda: txt_bwd(u.aux["dmul"])
+            else:
+                def bwd_s():
+                    gs, acc = s.grad_target()
+                    assert not acc
+                    ops.cast_f32_bf16(u.aux["dmul"], gs)
             self.tape.insert(len(self.tape) - 1, bwd_s)          # runs after the bn(mul) backward that fills dmul
         f5 = self.bn(u, u.aux["stats"], n + ".norm_layer.0")
         # fusion 2: cat[f2_v_proj(v4), up2(f5)] -> f2_cat
@@ -816,10 +856,49 @@ class Engine:
         cc = self.new_act(v4.Bn, v4.H, v4.W, pad8(fo[1] + 2))
         self.conv_bn(cat4, n + ".aggr.0", n + ".aggr.1", fo[1], out=cc.slice(0, fo[1]))
         ops.fill_coords(cc.t, cc.ld, fo[1], cc.ld - fo[1], cc.Bn, cc.H, cc.W)
-        self._neck_taps = dict(f5=f5, f4=f4, f3=f3, aggr=cc.slice(0, fo[1]), s=s)
+        self._neck_taps = dict(f5=f5, f4=f4, f3=f3, aggr=cc.slice(0, fo[1]), s=s if s is not None else s32)
         fq = self.conv_bn(cc, n + ".coordconv.0.conv1.0", n + ".coordconv.0.conv1.1", fo[1], k=3, pad=1)
         fq = self.conv_bn(fq, n + ".coordconv.1.0", n + ".coordconv.1.1", fo[1], k=3, pad=1)
         return fq
+
+    def _txt_proj_f32(self, state: Act, p: str, C: int):
+        """s = relu(BatchNorm1d(Linear(state))) (model/layers.py:262-264,286) over the B rows of the fp32 sentence vector: fp32
+        kernels of csrc/smallf32.hip; the BatchNorm coefficients (and, with SyncBatchNorm, the exchange) come from the same
+        launch as for every other BatchNorm.  Returns (s fp32 [B, C], backward(ds))."""
+        B = state.Bn
+        W = self.P[p + ".0.weight"]                                           # [C, E]
+        pfx = p + ".1"
+        ys = torch.empty(B, C, dtype=F32, device=self.dev)
+        ops.linear_f32_small(state.t, W, ys)
+        st = ops.colstats_f32_small(ys, self.dev) if self.training else None
+        scale, shift, mean, invstd, gcount = self._bn_coeffs(pfx, st, float(B), C)
+        s32 = torch.empty(B, C, dtype=F32, device=self.dev)
+        ops.bn_relu_f32_small(ys, scale, shift, s32)
+
+        def bwd(ds):
+            Gb = self.G[pfx + ".bias"]
+            arena_block = self.grad_arena[Gb.storage_offset():Gb.storage_offset() + 2 * C]       # [dbeta | dgamma]
+            link = self.comm.next_link() if self.sync_bn else None
+            if link is not None:
+                sums = self.empty(2 * C, dtype=F32)
+            elif self.sync_bn:
+                sums = self.zeros(2 * C)
+            else:
+                sums = arena_block
+
+            def between(t):
+                ops.axpy_f32(arena_block, t, 1.0)
+                ops.torch_op(self.comm.allreduce_sum_op(t))
+
+            dys = torch.empty(B, C, dtype=F32, device=self.dev)
+            ops.bn_relu_bwd_f32_small(ds, ys, scale, shift, mean, invstd, sums, gcount, dys,
+                                      between=between if (self.sync_bn and link is None) else None, link=link,
+                                      local_sums=arena_block if link is not None else None)
+            ops.outer_sum_f32_small(dys, state.t, self.G[p + ".0.weight"])    # dW[c][e] = sum_b dys[b][c] state[b][e]
+            gst, acc = state.grad_target()
+            ops.linear_f32_small(dys, W, gst, w_is_kn=True, accumulate=acc)   # dstate[b][e] (+)= sum_c dys[b][c] W[c][e]
+
+        return s32, bwd
 
     def _upsample(self, x: Act, out: Act):
         ops.upsample2_fwd(x.t, x.Bn, x.H, x.W, x.C, out.t, ldx=x.ld, xcoff=x.coff, ldy=out.ld, ycoff=out.coff)
@@ -927,6 +1006,17 @@ class Engine:
     def _wb_layer(self, state: Act, wb: Act, nwb: int):
         """wb = Linear(state) in fp32 (per-sample 3x3 kernel + bias of the text-to-pixel conv)."""
         p = "proj.txt"
+        if state.t.dtype == F32:
+            W = self.P[p + ".weight"]                                         # [nwb, E]
+            ops.linear_f32_small(state.t, W, wb.t[:, :nwb], bias=self.P[p + ".bias"])
+            if self.training:
+                def bwd32():
+                    dwb = self._dwb[:, :nwb]                                  # fp32 [B, nwb] filled by dynconv_bwd
+                    ops.outer_sum_f32_small(dwb, state.t, self.G[p + ".weight"], rowsum=self.G[p + ".bias"])
+                    gst, acc = state.grad_target()
+                    ops.linear_f32_small(dwb, W, gst, w_is_kn=True, accumulate=acc)
+                self.tape.append(bwd32)
+            return
         g = Geom.linear(state.M, state.C)
         ops.conv_gemm(state.t, self.WF[p + ".weight"], g, nwb, lda=state.ld, a_coff=state.coff, bias=self.P[p + ".bias"],
                       out=wb.t, ldc=wb.ld)

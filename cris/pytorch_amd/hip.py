@@ -278,6 +278,14 @@ _SIGS = {
     "cris_embed_bwd": (I, [P, P, I, I, I, P, P, P, P]),
     "cris_eot_gather": (I, [P, P, I, I, I, P, P, P]),
     "cris_eot_scatter_add": (I, [P, P, I, I, I, P, P]),
+    "cris_eot_gather_ln_f32": (I, [P, P, P, P, P, P, I, I, I, P, P, P]),
+    "cris_eot_scatter_add_f32": (I, [P, P, I, I, I, P, P]),
+    "cris_linear_f32_small": (I, [P, I, P, I, I, P, I, I, I, P, I, I, P]),
+    "cris_outer_sum_f32_small": (I, [P, I, P, I, I, I, I, P, I, P, P]),
+    "cris_colstats_f32_small": (I, [P, I, I, I, P, P, P]),
+    "cris_bn_relu_f32_small": (I, [P, I, P, P, I, I, P, I, P]),
+    "cris_bn_relu_bwd_reduce_f32_small": (I, [P, I, P, I, P, P, P, P, I, I, P, P]),
+    "cris_bn_relu_bwd_apply_f32_small": (I, [P, I, P, I, P, P, P, P, P, F, I, I, P, I, P]),
     "cris_posresize_fwd": (I, [P, P, I, I, I, P, P]),
     "cris_posresize_bwd": (I, [P, P, I, I, I, P, P]),
     "cris_batch_rowsum": (I, [P, I, I, I, I, P, P]),

@@ -96,7 +96,12 @@ class _CrisStep(torch.autograd.Function):
                                "training forward; losses of several forwards cannot be back-propagated together)")
         gscale = gloss.detach().reshape(1).to(torch.float32).contiguous()        # GradScaler's factor arrives here
         st = ctx.graph
-        if st is not None:
+        if st is not None and st.get("bwd") is None:
+            # command-list mode, first step with this shape: the forward was recorded while it ran, now the backward is
+            st["gscale"].copy_(gscale, non_blocking=True)
+            module._record_backward(st)
+            grads = st["grads"]
+        elif st is not None:
             st["gscale"].copy_(gscale, non_blocking=True)
             st["bwd"].replay()
             grads = st["grads"]
@@ -270,6 +275,11 @@ class CRIS(nn.Module):
             if key not in self._graph_seen:
                 self._graph_seen.add(key)
                 return None                                                  # first step with these shapes: eager
+            if os.environ.get("CRIS_MODULE_REPLAY", "graph") == "cmdlist":
+                # host command lists instead of HIP graphs: this call RUNS the forward while recording it
+                st = self._record_forward(img, word, mask, seed)
+                self._graphs[key] = st
+                return st
             try:
                 st = self._capture_graphs(img, word, mask)
             except Exception as ex:              # noqa: BLE001 - fall back to the eager schedule, say why once
@@ -278,12 +288,59 @@ class CRIS(nn.Module):
                 eng.seed_dev = None
                 return None
             self._graphs[key] = st
+        if st.get("bwd") is None:
+            raise RuntimeError("CRIS (HIP path): a training forward of a shape whose first backward has not run yet (command-list mode "
+                               "records the backward pass with the first backward of a shape)")
         st["img"].copy_(img, non_blocking=True)
         st["word"].copy_(word, non_blocking=True)
         st["mask"].copy_(mask, non_blocking=True)
         st["seed"].fill_(((int(seed) & 0xFFFFFFFF) ^ 0x80000000) - 0x80000000)     # the uint32 seed's bit pattern in the int32 word
         st["fwd"].replay()
         return st
+
+    def _record_forward(self, img, word, mask, seed):
+        """CRIS_MODULE_REPLAY=cmdlist: the step's launches as host command lists (hip.CommandList) instead of two HIP graphs -
+        every library call of one executed forward (here) and backward (_record_backward, from the first backward of the
+        shape) is recorded with its arguments; all buffers come from a private memory pool that stays reserved.  A replay costs
+        ~3 us of host time per launch but the first kernel starts at once - under a loop that synchronises every step
+        (engine/engine.py:67-69) a graph launch's latency is paid twice per step and cannot be hidden by running ahead."""
+        from .. import hip
+        eng = self._engine
+        st = dict(img=img.clone(), word=word.clone(), mask=mask.clone(),
+                  seed=torch.zeros(1, dtype=torch.int32, device=img.device), gscale=torch.ones(1, dtype=torch.float32, device=img.device))
+        st["seed"].fill_(((int(seed) & 0xFFFFFFFF) ^ 0x80000000) - 0x80000000)
+        st["pool"] = torch.cuda.MemPool()
+        fwd = hip.CommandList()
+        eng.seed_dev = st["seed"]
+        eng.packs_current = False                                            # the re-pack belongs to every replay
+        try:
+            with torch.cuda.use_mem_pool(st["pool"]):
+                hip.RECORDER = fwd
+                try:
+                    pred, msk, loss = eng.forward(st["img"], st["word"], st["mask"], training=True, seed=0)
+                finally:
+                    hip.RECORDER = None
+        finally:
+            eng.seed_dev = None
+        st.update(fwd=fwd, bwd=None, pred=pred, msk=msk, loss=loss)
+        return st
+
+    def _record_backward(self, st):
+        from .. import hip
+        eng = self._engine
+        bwd = hip.CommandList()
+        eng.seed_dev = st["seed"]
+        try:
+            with torch.cuda.use_mem_pool(st["pool"]):
+                hip.RECORDER = bwd
+                try:
+                    eng.backward(gscale=st["gscale"])
+                    grads = self._export_grads()
+                finally:
+                    hip.RECORDER = None
+        finally:
+            eng.seed_dev = None
+        st.update(bwd=bwd, grads=grads)
 
     def _capture_graphs(self, img, word, mask):
         eng = self._engine

@@ -775,6 +775,69 @@ def eot_scatter_add(eot_index, drows, Bn, L, D, dx):
     hip.call("cris_eot_scatter_add", ptr(eot_index), ptr(drows), Bn, L, D, ptr(dx), _stream())
 
 
+# ---- the sentence-vector path in fp32 (csrc/smallf32.hip): at most SMALL_MAX_ROWS rows ------------------------------------------
+SMALL_MAX_ROWS = 16
+
+
+def eot_gather_ln_f32(tokens, x, mean, rstd, gamma, beta, D, out, eot_index):
+    Bn, L = tokens.shape
+    hip.call("cris_eot_gather_ln_f32", ptr(tokens), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), Bn, L, D, ptr(out), ptr(eot_index),
+             _stream())
+
+
+def eot_scatter_add_f32(eot_index, drows, Bn, L, D, dx):
+    hip.call("cris_eot_scatter_add_f32", ptr(eot_index), ptr(drows), Bn, L, D, ptr(dx), _stream())
+
+
+def linear_f32_small(A, W, out, *, w_is_kn=False, bias=None, accumulate=False):
+    """out[M][N] (+)= A[M][K] @ W^T (+ bias) with W [N][K], or A @ W with W [K][N] (w_is_kn); fp32 throughout, M <= 16"""
+    M, K = A.shape
+    N = W.shape[1] if w_is_kn else W.shape[0]
+    assert (W.shape[0] if w_is_kn else W.shape[1]) == K and out.shape == (M, N)
+    hip.call("cris_linear_f32_small", ptr(A), A.stride(0), ptr(W), W.stride(0), int(w_is_kn), ptr(bias), M, N, K, ptr(out), out.stride(0),
+             int(accumulate), _stream())
+
+
+def outer_sum_f32_small(X1, X2, G, rowsum=None):
+    """G[R][C] = sum_m X1[m][r] * X2[m][c]; rowsum[r] = sum_m X1[m][r]"""
+    M, R = X1.shape
+    Cc = X2.shape[1]
+    assert X2.shape[0] == M and G.shape == (R, Cc)
+    hip.call("cris_outer_sum_f32_small", ptr(X1), X1.stride(0), ptr(X2), X2.stride(0), M, R, Cc, ptr(G), G.stride(0), ptr(rowsum), _stream())
+
+
+def colstats_f32_small(y, device) -> "Stats":
+    M, C_ = y.shape
+    st = Stats(1, C_, M, device)
+    hip.call("cris_colstats_f32_small", ptr(y), y.stride(0), M, C_, ptr(st[0]), ptr(st[1]), _stream())
+    return st
+
+
+def bn_relu_f32_small(y, scale, shift, z):
+    M, C_ = y.shape
+    hip.call("cris_bn_relu_f32_small", ptr(y), y.stride(0), ptr(scale), ptr(shift), M, C_, ptr(z), z.stride(0), _stream())
+
+
+def bn_relu_bwd_f32_small(dz, y, scale, shift, mean, invstd, sums, count, dy, *, between=None, link=None, local_sums=None):
+    """backward of z = relu(bn(y)) over M <= 16 fp32 rows: one partial row -> cris_bn_bwd_sum(_sync) into `sums` (+= / exchanged,
+    exactly as ops.bn_bwd does with its partial table) -> dy"""
+    M, C_ = y.shape
+    part = torch.empty(1, 2 * C_, dtype=torch.float32, device=y.device)
+    s = _stream()
+    hip.call("cris_bn_relu_bwd_reduce_f32_small", ptr(dz), dz.stride(0), ptr(y), y.stride(0), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+             M, C_, ptr(part), s)
+    p = hip.BnBwdParams()
+    p.part, p.sums, p.C = ptr(part), ptr(sums), C_
+    if link is not None:
+        hip.call("cris_bn_bwd_sum_sync", C.byref(p), 1, ptr(local_sums), C.byref(link), s)
+    else:
+        hip.call("cris_bn_bwd_sum", C.byref(p), 1, s)
+        if between is not None:
+            between(sums)
+    hip.call("cris_bn_relu_bwd_apply_f32_small", ptr(dz), dz.stride(0), ptr(y), y.stride(0), ptr(scale), ptr(shift), ptr(mean), ptr(invstd),
+             ptr(sums), float(count), M, C_, ptr(dy), dy.stride(0), s)
+
+
 def posresize_fwd(R, pos, T, G, C_, posr):
     hip.call("cris_posresize_fwd", ptr(R), ptr(pos), T, G, C_, ptr(posr), _stream())
 

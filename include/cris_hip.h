@@ -476,6 +476,36 @@ int cris_adam_block_elems(void);
 /* dst (param layout, desc.p) <- src (GEMM layout, desc.g) for a table of tensors; block_start as for cris_adam_step */
 int cris_unpack_grads(const cris_adam_desc* dev_table, int n_desc, int total_blocks, void* stream);
 
+/* ---- The sentence-vector path in fp32 (csrc/smallf32.hip) ----------------------------------------------------------------
+ * At most CRIS_SMALL_MAX_ROWS (= the per-GPU batch) rows: LayerNorm of the end-of-text rows (model/clip.py:449-452), `@
+ * text_projection` (:456), neck.txt_proj = Linear + BatchNorm1d + ReLU (model/layers.py:262-264,286), proj.txt = Linear
+ * (model/layers.py:58,71).  The bf16 path's loss error is dominated by the rounding of exactly these values (one rounding of the
+ * sentence vector shifts every logit of a sample; profiles/parity_r04.md), and they are a few MFLOP: fp32 on the VALU, reading the
+ * fp32 parameters directly.  Matrices are row-major with a leading dimension in floats.
+ *   cris_eot_gather_ln_f32     out[b] = LayerNorm(x[b, argmax tokens[b]]) from the saved row statistics; eot_index out
+ *   cris_eot_scatter_add_f32   dx[b, eot_b] += d out[b]   (dx: the bf16 gradient of the LayerNorm output)
+ *   cris_linear_f32_small      out[M][N] (+)= A[M][K] W^T (+ bias), W = [N][K] (w_is_kn 0) or [K][N] (w_is_kn 1: x @ P, and the
+ *                              input gradient of a [N][K] layer: dA = dOut W)
+ *   cris_outer_sum_f32_small   G[R][C] = sum_m X1[m][r] X2[m][c] (weight gradient of either layout), rowsum[r] = sum_m X1[m][r] (bias)
+ *   cris_colstats_f32_small    one statistics part (sum, M2) per column for cris_bn_finalize(_sync)
+ *   cris_bn_relu_f32_small     z = relu(scale y + shift);  _bwd_reduce: ONE partial row [2C] for cris_bn_bwd_sum(_sync);
+ *                              _bwd_apply: dy from the summed (global) sums */
+#define CRIS_SMALL_MAX_ROWS 16
+int cris_eot_gather_ln_f32(const int64_t* tokens, const float* x, const float* mean, const float* rstd, const float* gamma,
+                           const float* beta, int Bn, int L, int D, float* out, int* eot_index, void* stream);
+int cris_eot_scatter_add_f32(const int* eot_index, const float* drows, int Bn, int L, int D, cris_bf16* dx, void* stream);
+int cris_linear_f32_small(const float* A, int lda, const float* W, int ldw, int w_is_kn, const float* bias, int M, int N, int K,
+                          float* out, int ldo, int accumulate, void* stream);
+int cris_outer_sum_f32_small(const float* X1, int ld1, const float* X2, int ld2, int M, int R, int C, float* G, int ldg, float* rowsum,
+                             void* stream);
+int cris_colstats_f32_small(const float* y, int ldy, int M, int C, float* psum, float* pm2, void* stream);
+int cris_bn_relu_f32_small(const float* y, int ldy, const float* scale, const float* shift, int M, int C, float* z, int ldz, void* stream);
+int cris_bn_relu_bwd_reduce_f32_small(const float* dz, int lddz, const float* y, int ldy, const float* scale, const float* shift,
+                                      const float* mean, const float* invstd, int M, int C, float* part, void* stream);
+int cris_bn_relu_bwd_apply_f32_small(const float* dz, int lddz, const float* y, int ldy, const float* scale, const float* shift,
+                                     const float* mean, const float* invstd, const float* sums, float count, int M, int C, float* dy,
+                                     int lddy, void* stream);
+
 /* ---- Low-latency cross-rank sum of small fp32 vectors (EXPERIMENTAL, CRIS_SYNCBN_P2P=1) -------------------------------
  * Replaces the per-layer all_gather / all_reduce of nn.SyncBatchNorm (train.py:97-98; 142 small collectives per CRIS-R50
  * step) by ONE kernel per exchange: every rank owns a fine-grained device mailbox that all peers map through HIP IPC; the

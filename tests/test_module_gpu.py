@@ -78,11 +78,13 @@ def _run_module(graph, steps=5, shapes=((4, 64),)):
         os.environ.pop("CRIS_MODULE_GRAPH", None)
 
 
-def test_module_graph_replay_equals_the_eager_schedule():
+@pytest.mark.parametrize("replay", ["graph", "cmdlist"])
+def test_module_graph_replay_equals_the_eager_schedule(replay, monkeypatch):
     """the drop-in module replays two captured HIP graphs per step (forward + loss, backward + gradient export) from its
     autograd node; the dropout seed and GradScaler's factor live in device memory.  Same kernels in the same order: losses,
     logits and the parameters after five torch-Adam steps are bit-identical to the eager schedule - with one input shape
     (steps 0 eager, 1 capture, 2.. replay) and with two alternating shapes (two graph pairs over separate pools)."""
+    monkeypatch.setenv("CRIS_MODULE_REPLAY", replay)          # cmdlist: host command lists instead of HIP graphs (same contract)
     for shapes in (((4, 64),), ((4, 64), (2, 96))):
         steps = 5 if len(shapes) == 1 else 8
         lg, sg, mg = _run_module(True, steps, shapes)

@@ -143,7 +143,7 @@ def main(spec="tiny", B=4, S=64, blocks=("layer2.0", "layer2.1")):
     e._text_tape_start = len(e.tape)
     xf, state = e._encode_text(c.word.to(DEV))
     xf.root._g = gw.reshape(-1, gw.shape[-1]).to(DEV).to(BF).contiguous()
-    state.root._g = gs.to(DEV).to(BF).contiguous()
+    state.root._g = gs.to(DEV).to(state.t.dtype).contiguous()             # (fp32 when the sentence vector stays in fp32)
     c.finish("text", [("word", xf.t.float().view(wref.shape), wref), ("state", state.t.float(), sref)], "backbone.t")
     print("      token_embedding cos %.5f pos cos %.5f text_projection cos %.5f ln_final.w cos %.5f" % tuple(
         cos(e.grad_param_layout(k), c.leaf[k].grad) for k in ("backbone.token_embedding.weight", "backbone.positional_embedding",
@@ -156,7 +156,8 @@ def main(spec="tiny", B=4, S=64, blocks=("layer2.0", "layer2.1")):
     gout = rand_like(ref, 5)
     ref.backward(gout)
     acts = [to_act(x.detach()) for x in ins[:3]]
-    st = Act(ins[3].detach().to(DEV).to(BF).contiguous(), B, 1, 1, ins[3].shape[1])
+    sdt = torch.float32 if (e.state_f32 and B <= 16) else BF
+    st = Act(ins[3].detach().to(DEV).to(sdt).contiguous(), B, 1, 1, ins[3].shape[1])
     z = e._fpn(acts[0], acts[1], acts[2], st)
     set_grad(z, gout)
     c.finish("fpn", [("out", nhwc_to_nchw(z), ref)], "neck")
@@ -191,7 +192,7 @@ def main(spec="tiny", B=4, S=64, blocks=("layer2.0", "layer2.1")):
     lref = O.bce_with_logits_mean(pref, m)
     lref.backward()
     fa = to_act(fql.detach())
-    st = Act(sl.detach().to(DEV).to(BF).contiguous(), B, 1, 1, sl.shape[1])
+    st = Act(sl.detach().to(DEV).to(sdt).contiguous(), B, 1, 1, sl.shape[1])
     pred, x, wb = e._projector(fa, st)
     OH, OW = pred.shape[-2:]
     from cris.pytorch_amd import ops

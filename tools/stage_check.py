@@ -51,7 +51,7 @@ def main(spec="tiny", B=4, S=64):
     x2, x3 = ot["layer2"], ot["layer3"]
     v3, v4, v5 = to_act(x2, dev), to_act(x3, dev), to_act(ot["attnpool"], dev)
     st = ot["state"]
-    state = Act(st.to(dev).to(BF).contiguous(), B, 1, 1, st.shape[1])
+    state = Act(st.to(dev).to(torch.float32 if (eng.state_f32 and B <= 16) else BF).contiguous(), B, 1, 1, st.shape[1])
     fq = eng._fpn(v3, v4, v5, state)
     nt = eng._neck_taps
     for k in ("f5", "f4", "f3", "aggr"):
