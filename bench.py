@@ -214,6 +214,17 @@ def module_path(args, rank, world, dev):
         r = step(i)
         first = first if first is not None else r[0]
     del marks[:]
+    if args.pyprof:
+        # where the HOST time of the loop body goes (the device idles while the host prepares a launch after a step's syncs)
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(10):
+            step(i)
+        pr.disable()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(35)
+        del marks[:]
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -286,6 +297,7 @@ def main():
     ap.add_argument("--optimizer", default="torch", choices=["torch", "cris"],
                     help="--path module: torch = torch.optim.Adam as train.py:105 builds it (the unchanged loop); cris = "
                          "cris.pytorch_amd.optim.Adam, the optional one-line replacement whose step() is the library's fused update")
+    ap.add_argument("--pyprof", action="store_true", help="--path module: cProfile of ten loop bodies (stderr) before the timed region")
     ap.add_argument("--phase-times", action="store_true", help="--path module: host and device time of every phase of the loop body")
     ap.add_argument("--launch-check", action="store_true",
                     help="exercise only the multi-rank launch protocol (spawn, rendezvous, barrier, max-over-ranks, one JSON "

@@ -33,7 +33,9 @@ def test_folded_forward_matches_unfolded_and_oracle(spec, batch, size, word_len)
     b = plain(img.to(DEV), word.to(DEV)).clone()
     torch.cuda.synchronize()
     e = folded.engine
-    assert len(e._fold) == len(e.bn_prefixes) - 2             # every BatchNorm but neck.f1_v_proj.1 / neck.norm_layer.0
+    # every BatchNorm but neck.f1_v_proj.1 / neck.norm_layer.0 (a per-sample multiplication sits between them) and the BatchNorm1d
+    # of neck.txt_proj, which runs in fp32 on the sentence vector's rows (csrc/smallf32.hip) when that path is on
+    assert len(e._fold) == len(e.bn_prefixes) - (3 if (e.state_f32 and batch <= 16) else 2)
     assert len(plain.engine._fold) == 0
     with torch.no_grad():
         ref = O.cris_forward(sd, clip, head, img, word, training=False)
