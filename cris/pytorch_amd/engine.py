@@ -107,10 +107,11 @@ class Engine:
         # a model that evaluates during training (engine/engine.py:90-123 `validate`) would otherwise hold both twice
         self.inference_only = inference_only
         self.embed_live = None          # optional uint8 [vocabulary]: rows of the token embedding that ever had a gradient (trainer)
-        # the sentence vector and the (at most batch-size rows of) layers it runs through in fp32 (csrc/smallf32.hip; CRIS_STATE_FP32=0:
-        # bf16 GEMM launches as in rounds 1-3)
+        # CRIS_STATE_FP32=1: the sentence vector and the (at most batch-size rows of) layers it runs through in fp32
+        # (csrc/smallf32.hip).  Measured (calls r04d / r04f, profiles/parity_r04.md): logits 15 % closer to the fp32 oracle and better
+        # gradient cosines over the 100 teacher-forced states, no change of their mean loss error, +0.19 ms per step - off by default
         import os
-        self.state_f32 = os.environ.get("CRIS_STATE_FP32", "1") == "1"
+        self.state_f32 = os.environ.get("CRIS_STATE_FP32", "0") == "1"
         self.P, self.Bf = params, buffers
         self.comm = comm or Comm()
         self.sync_bn = sync_bn and (self.comm.world > 1 or debug.HOOKS.force_dist)
@@ -1046,10 +1047,6 @@ class Engine:
         self._zero_slab_begin()
         if training:
             self.comm.begin_step()
-            if debug.HOOKS.zero_all:
-                ops.zero_(self.grad_arena)
-            else:
-                ops.zero_ranges(self.zero_ranges)
         if not self.packs_current:
             self.repack_weights()
         # token ids index the embedding table and the key-padding mask as int64 (torch.nn.Embedding would raise on anything
@@ -1121,6 +1118,12 @@ class Engine:
         overlap with the rest of backward."""
         self._gscale = gscale
         Act._engine = self                              # (another engine may have run a forward in between)
+        # the accumulated parts of the gradient arena (BatchNorm sums, embedding rows) are cleared HERE, not in forward: a forward
+        # never touches the arena, so gradients a caller still holds from the previous step survive it (drop-in module)
+        if debug.HOOKS.zero_all:
+            ops.zero_(self.grad_arena)
+        else:
+            ops.zero_ranges(self.zero_ranges)
         marks = dict(self._stage_marks)                 # tape index at which a stage's closures START
         (t0, t1), (v0, v1) = self._ranges["text"], self._ranges["visual"]
         head_start = max(t1, v1)                        # neck / decoder / projector closures: main stream

@@ -95,6 +95,8 @@ class _CrisStep(torch.autograd.Function):
                                "overwritten - the engine keeps the activations of one step (call backward before the next "
                                "training forward; losses of several forwards cannot be back-propagated together)")
         gscale = gloss.detach().reshape(1).to(torch.float32).contiguous()        # GradScaler's factor arrives here
+        if ctx.direct:
+            module._release_engine_grads()       # before the backward pass overwrites the engine's gradient buffers
         st = ctx.graph
         if st is not None and st.get("bwd") is None:
             # command-list mode, first step with this shape: the forward was recorded while it ran, now the backward is
@@ -224,7 +226,7 @@ class CRIS(nn.Module):
     def _assign_grads(self, grads):
         """gradient semantics of autograd's accumulation on `.grad`: None -> the new gradient (the engine's own buffer, no copy);
         an existing tensor -> += (gradient accumulation over several backward passes).  `.grad` is never the engine's buffer
-        here: _release_engine_grads() has replaced such a reference by a copy before the forward overwrote the buffer."""
+        here: _release_engine_grads() has replaced such a reference by a copy before this backward pass overwrote the buffer."""
         for p_, g in zip(self._step_params, grads):
             if p_.grad is None:
                 p_.grad = g
@@ -232,11 +234,13 @@ class CRIS(nn.Module):
                 p_.grad.add_(g)
 
     def _release_engine_grads(self):
-        """Direct-gradient mode hands the engine's persistent buffers out as `.grad`.  A training forward clears and re-uses
-        them, so whatever they still mean to the caller must be saved first: a parameter whose `.grad` is still the engine's
-        buffer - zero_grad(set_to_none=False) leaves it in place (zeroed), and so does a loop that accumulates gradients over
-        several micro-batches without any zero_grad - gets a copy instead; the coming backward then adds to the copy like
-        autograd's AccumulateGrad would.  The default loop (zero_grad() sets `.grad` to None) never copies."""
+        """Direct-gradient mode hands the engine's persistent buffers out as `.grad`.  A BACKWARD pass clears and re-uses them (a
+        forward never touches the gradient arena), so whatever they still mean to the caller is saved first, at the start of
+        backward: a parameter whose `.grad` is still the engine's buffer - zero_grad(set_to_none=False) leaves it in place
+        (zeroed), and so does a loop that accumulates gradients over several micro-batches without any zero_grad - gets a copy
+        instead; this backward then adds to the copy like autograd's AccumulateGrad would.  The reference's loop (forward,
+        `optimizer.zero_grad()` - which sets `.grad` to None -, backward: engine/engine.py:48-55) never copies.  (Round 4, call
+        r04f: doing this at the start of FORWARD copied all 449 gradients in every step of that loop - 2.5 ms.)"""
         bufs = self._step_grads
         for p_, g in zip(self._step_params, bufs):
             if p_.grad is g:
@@ -380,7 +384,6 @@ class CRIS(nn.Module):
                 self._anchor = torch.zeros(1, device=img.device, requires_grad=True)
                 self._step_cache_key = self._engine_key
             if self._direct_grads():
-                self._release_engine_grads()
                 pred, msk, loss = _CrisStep.apply(self, img, word, mask, seed, self._anchor)
             else:
                 pred, msk, loss = _CrisStep.apply(self, img, word, mask, seed, *self._step_params)

@@ -195,6 +195,18 @@ def test_stage_isolated_parity():
     assert not bad, bad
 
 
+def test_sentence_vector_in_fp32_option():
+    """CRIS_STATE_FP32=1 (read when an Engine is built, hence the subprocess): the end-of-text rows through ln_final, text_projection,
+    neck.txt_proj (Linear + BatchNorm1d + ReLU) and proj.txt in fp32 on the VALU (csrc/smallf32.hip) - the whole-step parity checks,
+    the stage-isolated check and the eval forward must hold with it on"""
+    import subprocess
+    env = dict(os.environ, CRIS_STATE_FP32="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider", "-k",
+                        "tiny_step or tiny_ragged or stage_isolated or eval_forward or deterministic"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+
+
 def test_eval_forward_matches_oracle():
     clip, head = arch.specs_by_name("tiny")
     sd = arch.synthetic_state_dict(clip, head, 0)
