@@ -295,12 +295,36 @@ class CRIS(nn.Module):
         if st.get("bwd") is None:
             raise RuntimeError("CRIS (HIP path): a training forward of a shape whose first backward has not run yet (command-list mode "
                                "records the backward pass with the first backward of a shape)")
+        if not getattr(self, "_replay_repacks", True) and not eng.packs_current:
+            eng.repack_weights()                                             # (weights changed outside the bound optimizer)
+            eng.packs_current = True
         st["img"].copy_(img, non_blocking=True)
         st["word"].copy_(word, non_blocking=True)
         st["mask"].copy_(mask, non_blocking=True)
         st["seed"].fill_(((int(seed) & 0xFFFFFFFF) ^ 0x80000000) - 0x80000000)     # the uint32 seed's bit pattern in the int32 word
         st["fwd"].replay()
         return st
+
+    def _prepare_packs_for_capture(self):
+        """Whether a replayed forward re-packs the bf16 operand copies of the weights.  Under a torch optimizer it must (the
+        optimizer changed the fp32 parameters behind the engine's back): the re-pack is part of every replay.  With
+        cris.pytorch_amd.optim.Adam bound (gradient-view mode) the update itself rewrites the copies, so the replay carries no
+        re-pack; a change from elsewhere (load_state_dict) clears `packs_current` and is repaired eagerly before the next replay."""
+        eng = self._engine
+        if self._grad_views_active:
+            if not eng.packs_current:
+                eng.repack_weights()
+                eng.packs_current = True
+            self._replay_repacks = False
+        else:
+            eng.packs_current = False
+            self._replay_repacks = True
+
+    def load_state_dict(self, *args, **kwargs):
+        r = super().load_state_dict(*args, **kwargs)
+        if self._engine is not None:
+            self._engine.packs_current = False          # the bf16 operand copies no longer match the parameters
+        return r
 
     def _record_forward(self, img, word, mask, seed):
         """CRIS_MODULE_REPLAY=cmdlist: the step's launches as host command lists (hip.CommandList) instead of two HIP graphs -
@@ -316,7 +340,7 @@ class CRIS(nn.Module):
         st["pool"] = torch.cuda.MemPool()
         fwd = hip.CommandList()
         eng.seed_dev = st["seed"]
-        eng.packs_current = False                                            # the re-pack belongs to every replay
+        self._prepare_packs_for_capture()
         try:
             with torch.cuda.use_mem_pool(st["pool"]):
                 hip.RECORDER = fwd
@@ -355,7 +379,7 @@ class CRIS(nn.Module):
         fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         eng.seed_dev = st["seed"]
         try:
-            eng.packs_current = False                                        # the re-pack belongs to every replay
+            self._prepare_packs_for_capture()
             with torch.cuda.graph(fwd, pool=pool):
                 pred, msk, loss = eng.forward(st["img"], st["word"], st["mask"], training=True, seed=0)
             with torch.cuda.graph(bwd, pool=pool):

@@ -34,4 +34,15 @@ x r50_480_L22 --size 480
 x r50_416_b16 --batch 16
 x r50_416_b32 --batch 32
 cat $L.extra.log
+# 6. the drop-in module under the reference's loop body (torch Adam = unchanged loop; cris = the optional one-line optimizer)
+B2="python bench.py --path module --steps 100 --warmup 10 --no-cpu-baseline --phase-times"
+mp() { tag=$1; shift; timeout 300 env "$@" 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('module/$tag', round(d['ms_per_step'],3), 'ms/step', round(d['value'],1), 'samples/s', d['config'].get('optimizer'), d['config'].get('replay'))
+for k,v in (d.get('phase_times') or {}).items(): print('   %-14s host %.2f ms  device %.2f ms' % (k, v['host_ms'], v['device_ms']))" >> $L.module.log 2>&1; }
+: > $L.module.log
+mp torch_graph X=1 $B2
+mp cris_graph X=1 $B2 --optimizer cris
+mp cris_cmdlist CRIS_MODULE_REPLAY=cmdlist $B2 --optimizer cris
+cat $L.module.log
+timeout 300 python -m pytest tests/test_module_gpu.py -m gpu -q -x -p no:cacheprovider 2>&1 | tail -3
 rocm-smi --showclocks --showpower --showtemp 2>/dev/null | grep -v "^=\|^$" | head -12 > $L.smi_end.log
