@@ -12,7 +12,24 @@ from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu_long
 
+from cris.pytorch_amd import selfcheck  # noqa: E402
 from test_engine_gpu import _trajectory, assert_teacher_forced, teacher_forced  # noqa: E402
+
+
+# (single steps of configs[3] / [4] against the CPU oracle, logits + every gradient: 30 s each of CPU oracle time - the default
+# `-m gpu` suite keeps configs[1] and the reduced-size R101 / 22-token cases, these two run here beside their teacher-forced runs)
+def test_config3_r101_416_batch8_step_matches_oracle():
+    """BASELINE.json configs[3]: CRIS-R101, 416x416, batch 8."""
+    rep = selfcheck.run("r101", batch=8, size=416, dropout=0.0, seed=3)
+    print(rep)
+    selfcheck.assert_parity(rep, "r101_full")
+
+
+def test_config4_r50_480_22_tokens_step_matches_oracle():
+    """BASELINE.json configs[4]: CRIS-R50, 480x480 (120/60/30/15 maps, 900-token decoder attention), 22-token text, batch 8."""
+    rep = selfcheck.run("r50", batch=8, size=480, dropout=0.0, seed=3, word_len=22)
+    print(rep)
+    selfcheck.assert_parity(rep, "r50_full")
 
 
 # Fixed bounds on |loss_hip - loss_fp32_oracle| per phase of the 100-step curve: (first step, last step + 1, max, mean).  Measured
@@ -63,14 +80,21 @@ def test_teacher_forced_r50_full_size_100_steps():
     rows, dl = teacher_forced("r50", 416, 17, 100, "r50")
     fx = json.load(open(os.path.join(GOLDEN, "traj_r50_b8_s416_d0.1_lr0.0001.json")))["loss"]
     assert abs(rows[0]["loss_fp32"] - fx[0]) < 1e-4                  # the GPU teacher starts where the pinned CPU oracle starts
-    assert_teacher_forced(rows, dl, mean_bound=TF_R50_MEAN, cos_min=0.80)         # measured: worst tensor 0.870
+    assert_teacher_forced(rows, dl, mean_bound=TF_R50_MEAN, cos_min=0.80)         # measured: worst tensor 0.835 - 0.882
+    settled = dl[40:]
+    print("teacher-forced r50: mean |dloss| %.3e over the 100 states (north star: 1e-3), %.3e over states 40-99" % (sum(dl) / len(dl), sum(settled) / len(settled)))
+    assert sum(settled) / len(settled) <= TF_R50_SETTLED_MEAN, sum(settled) / len(settled)
     assert rows[-1]["loss_fp32"] < 0.5 * rows[0]["loss_fp32"]          # the teacher's trajectory is a training run
 
 
-# mean |dloss| bounds of the teacher-forced runs (fixed; measured in round 4, profiles/parity_r04.md: R50 9.6e-4 over 100 states,
-# R101 2.7e-3 and 480 / 22 tokens 4.2e-3 over their first 20 states - the violent ones: the 100-state R50 mean is 2.2e-3 over
-# its first 40 states and 1.5e-4 over the last 60)
-TF_R50_MEAN, TF_R101_MEAN, TF_480_MEAN = 1.0e-3, 4.0e-3, 6.0e-3
+# mean |dloss| bounds of the teacher-forced runs (fixed; measured in round 4, profiles/parity_r04.md).  R50, 100 states, five runs on
+# five boxes: 9.60e-4, 6.77e-4, 6.36e-4, 6.80e-4, 9.46e-4 - every one below the north star's 1e-3, but the figure moves by +-25 % with
+# the TEACHER: stock PyTorch's trajectory through the untrained head's first 40 steps is not reproducible from run to run (different
+# boxes pick different MIOpen / hipBLASLt kernels; even one box differs in the 4th digit at step 3), and four of those states carry half
+# of the sum.  The asserted bound on the 100-state mean therefore leaves room for that spread (1.2e-3), and the part of the statement
+# that IS reproducible is asserted tightly: states 40-99 (the settled phase) averaged 1.17e-4 ... 1.50e-4 in all five runs.
+# R101 / 480x480 + 22 tokens, first 20 states (all in the violent phase): 2.6 - 2.8e-3 / 3.3 - 4.2e-3.
+TF_R50_MEAN, TF_R50_SETTLED_MEAN, TF_R101_MEAN, TF_480_MEAN = 1.2e-3, 3.0e-4, 4.0e-3, 6.0e-3
 
 
 def test_teacher_forced_r101_20_states():
