@@ -132,7 +132,9 @@ __global__ __launch_bounds__(256) void p2p_allreduce_sum_kernel(const cris_p2p_p
     __shared__ int s_bad;
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
-    if ((int)threadIdx.x < p.world) {
+    if (p.err && p.err[0] != 0) {                  // a peer already timed out in an earlier launch: do not wait again
+        if (threadIdx.x == 0) s_bad = 1;
+    } else if ((int)threadIdx.x < p.world) {
         const int* flag = reinterpret_cast<const int*>(reinterpret_cast<float*>(p.boxes[p.rank]) + data_floats) + entry + threadIdx.x;
         long spins = 0;
         const long limit = p.spin_limit > 0 ? (long)p.spin_limit : P2P_SPIN_LIMIT;

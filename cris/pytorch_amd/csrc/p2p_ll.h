@@ -45,6 +45,12 @@ __device__ __forceinline__ void p2p_ll_send(const cris_p2p_link& L, int gen, int
 // a peer that never arrives within the poll limit sets `bad`
 __device__ __forceinline__ float p2p_ll_recv_sum(const cris_p2p_link& L, int gen, int idx, bool& bad) {
     const long limit = L.spin_limit > 0 ? (long)L.spin_limit : P2P_SPIN_LIMIT;
+    // a peer already timed out in an EARLIER launch of this rank (the flag is only read here; kernels of one stream run in order):
+    // do not wait again - one timeout, not one per exchange, until the host looks at the flag (the values are NaN from here on)
+    if (L.err && L.err[0] != 0) {
+        bad = true;
+        return 0.f;
+    }
     float s = 0.f;
     for (int q = 0; q < L.world; ++q) {
         const unsigned long long* src = p2p_ll_row(L, L.rank, q, gen) + idx;
