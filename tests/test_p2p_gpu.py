@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-pytestmark = [pytest.mark.gpu]
+gpu = pytest.mark.gpu
 
 
 def _free_port():
@@ -57,6 +57,7 @@ def _prim_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@gpu
 def test_peer_mailbox_allreduce_two_ranks_one_gpu():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -108,7 +109,9 @@ def _train_worker(rank, world, port, p2p, launch, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("launch", ["eager", "cmdlist"])
+# (two processes time-slice the one GPU of the test box - every exchange costs a scheduling quantum, 50 - 80 s per variant: the
+# command-list variant runs with the long parity runs, `-m "gpu or gpu_long"`)
+@pytest.mark.parametrize("launch", [pytest.param("eager", marks=gpu), pytest.param("cmdlist", marks=pytest.mark.gpu_long)])
 def test_trainer_with_peer_mailboxes_equals_torch_distributed_exchange(launch):
     """two ranks, four optimizer steps: the SyncBN exchange through torch.distributed, through the mailbox kernel, and INSIDE the
     BatchNorm launches (the default) - bit-identical losses, and bit-identical parameters and running statistics at the end (two
