@@ -237,7 +237,7 @@ def test_loss_trajectory_tiny_100_steps():
 # Teacher-forced bounds, fixed numbers (profiles/parity_r04.md): at EVERY state of the fp32 oracle's own trajectory
 # |loss_hip - loss_fp32| <= TF_LOSS, logits relative L2 <= TF_LOGITS, median parameter-gradient cosine >= TF_COS_MED, worst
 # parameter's cosine >= TF_COS_MIN; and the MEAN |dloss| over the states <= the bound given per configuration.
-TF_LOSS, TF_LOGITS, TF_COS_MED, TF_COS_MIN = 3.0e-2, 8.0e-2, 0.99, 0.75
+TF_LOSS, TF_LOGITS, TF_COS_MED, TF_COS_MIN = 3.0e-2, 8.0e-2, 0.985, 0.75      # (median cosine at the worst state of six 100-state runs: 0.9903 ... 0.9970)
 
 
 def teacher_forced(spec, size, word_len, steps, tag, every=1, dropout=0.1, lr=1e-4, batch=8):

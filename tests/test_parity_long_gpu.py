@@ -87,12 +87,12 @@ def test_teacher_forced_r50_full_size_100_steps():
     assert rows[-1]["loss_fp32"] < 0.5 * rows[0]["loss_fp32"]          # the teacher's trajectory is a training run
 
 
-# mean |dloss| bounds of the teacher-forced runs (fixed; measured in round 4, profiles/parity_r04.md).  R50, 100 states, five runs on
-# five boxes: 9.60e-4, 6.77e-4, 6.36e-4, 6.80e-4, 9.46e-4 - every one below the north star's 1e-3, but the figure moves by +-25 % with
+# mean |dloss| bounds of the teacher-forced runs (fixed; measured in round 4, profiles/parity_r04.md).  R50, 100 states, six runs on
+# five boxes: 9.60e-4, 6.77e-4, 6.36e-4, 6.80e-4, 9.46e-4, 8.48e-4 - every one below the north star's 1e-3, but the figure moves by +-25 % with
 # the TEACHER: stock PyTorch's trajectory through the untrained head's first 40 steps is not reproducible from run to run (different
 # boxes pick different MIOpen / hipBLASLt kernels; even one box differs in the 4th digit at step 3), and four of those states carry half
 # of the sum.  The asserted bound on the 100-state mean therefore leaves room for that spread (1.2e-3), and the part of the statement
-# that IS reproducible is asserted tightly: states 40-99 (the settled phase) averaged 1.17e-4 ... 1.50e-4 in all five runs.
+# that IS reproducible is asserted tightly: states 40-99 (the settled phase) averaged 1.17e-4 ... 1.57e-4 in all six runs.
 # R101 / 480x480 + 22 tokens, first 20 states (all in the violent phase): 2.6 - 2.8e-3 / 3.3 - 4.2e-3.
 TF_R50_MEAN, TF_R50_SETTLED_MEAN, TF_R101_MEAN, TF_480_MEAN = 1.2e-3, 3.0e-4, 4.0e-3, 6.0e-3
 
