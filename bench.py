@@ -407,7 +407,6 @@ def main():
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first_loss, "final_loss": loss_v,
                        "launch": tr.launch, "graph_captured": tr._graph is not None, "graph_error": tr.graph_error,
                        "syncbn_exchange": tr.syncbn_exchange, "comm": type(comm).__name__ if comm is not None else None,
-                       "optimizer_update": "per arena stage, underneath backward" if tr._staged else "one pass after backward",
                        "syncbn_peer_timeout": (bool(int(comm.p2p.err.item())) if getattr(comm, "p2p", None) is not None else None),
                        "gpu_state_start": smi0, "gpu_state_end": smi1},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12),

@@ -207,12 +207,6 @@ class TorchDistComm:
         with torch.cuda.stream(self.side):
             self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.grad_group, async_op=True))
 
-    def stream_wait_last(self, stream):
-        """make `stream` wait for the most recently issued allreduce_async (the staged optimizer update of the native trainer:
-        a stage's update follows that stage's gradient exchange, not the whole backward pass)"""
-        with torch.cuda.stream(stream):
-            self._pending[-1].wait()
-
     def wait_all(self):
         for w in self._pending:
             w.wait()

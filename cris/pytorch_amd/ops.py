@@ -922,37 +922,29 @@ class _AdamDeviceTable:
 
 
 class AdamTable:
-    """Device tables of {p, g, m, v, n, lr [, bf16 packs]}: torch.optim.Adam.step() over every tensor in two launches per
-    segment (one segment unless the caller splits the tensors) - the 3x3 convolution weights whose bf16 operand copies are
-    refreshed by the update (9-tap tiles: 37 KB of LDS per block) and everything else (1-tap packed weights, plain tensors)."""
+    """Device tables of {p, g, m, v, n, lr [, bf16 packs]}: torch.optim.Adam.step() over every tensor in two launches - the
+    3x3 convolution weights whose bf16 operand copies are refreshed by the update (9-tap tiles: 74 KB of LDS per block) and
+    everything else (1-tap packed weights and plain tensors)."""
 
-    def __init__(self, params, grads, lrs, layouts=None, packs=None, row_live=None, segments=None):
+    def __init__(self, params, grads, lrs, layouts=None, packs=None, row_live=None):
         """layouts[i]: None (gradient in the parameter layout) or (N, Cin, taps, Cpad) (GEMM layout, see cris_conv_wgrad).
         packs[i]: None or (dstF, dstD, N, Cin, taps, Cpad, Npad, transposed) - the bf16 GEMM-operand copies of tensor i
         (PackTable layouts) that the update rewrites from the new values.
         row_live: {i: uint8 tensor [rows of tensor i]} - rows whose byte is 0 have never had a gradient and are skipped
-        (bit-identical to the dense update while weight_decay == 0; cris_adam_desc.row_live).
-        segments: optional list of index lists, a disjoint cover of the tensors: every segment gets device tables of its own,
-        so that `step_segment(k)` can update one of them as soon as ITS gradients are final (the native trainer: one segment
-        per arena stage, updated underneath the rest of the backward pass); `step()` updates all of them."""
+        (bit-identical to the dense update while weight_decay == 0; cris_adam_desc.row_live)."""
         lib = hip.load()
         self.m = [torch.zeros_like(p) for p in params]
         self.v = [torch.zeros_like(p) for p in params]
         self.params, self.grads, self.lrs = list(params), list(grads), list(lrs)
         self.packs = list(packs) if packs is not None else [None] * len(self.params)
         self.device = self.params[0].device
-        segments = [list(range(len(self.params)))] if segments is None else [list(s) for s in segments]
-        assert sorted(i for s in segments for i in s) == list(range(len(self.params))), "segments must cover every tensor once"
-        self.n_segments = len(segments)
-        groups = {}
-        for k, seg in enumerate(segments):
-            groups[(k, 9)], groups[(k, 1)] = [], []
-            for i in seg:
-                pk = self.packs[i]
-                groups[(k, 9 if (pk is not None and pk[4] == 9) else 1)].append(i)
+        groups = {9: [], 1: []}
+        for i in range(len(self.params)):
+            pk = self.packs[i]
+            groups[9 if (pk is not None and pk[4] == 9) else 1].append(i)
         self.index = groups
         self.tables = {}
-        for (k, taps), idx in groups.items():
+        for taps, idx in groups.items():
             arr = (hip.AdamDesc * max(len(idx), 1))()
             start = 0
             for j, i in enumerate(idx):
@@ -974,15 +966,15 @@ class AdamTable:
                     d.row_live, d.row_len = ptr(row_live[i]), p.shape[1]
                 d.block_start = start
                 start += lib.cris_adam_blocks(C.byref(d))
-            self.tables[(k, taps)] = _AdamDeviceTable(arr, len(idx), start, self.device)
+            self.tables[taps] = _AdamDeviceTable(arr, len(idx), start, self.device)
         self.row_live = dict(row_live) if row_live else {}
         self.keep = [pk[:2] for pk in self.packs if pk is not None]
         self.step_count = 0
 
     def set_lrs(self, lrs):
         self.lrs = list(lrs)
-        for key, idx in self.index.items():
-            t = self.tables[key]
+        for taps, idx in self.index.items():
+            t = self.tables[taps]
             for j, i in enumerate(idx):
                 t.arr[j].lr = self.lrs[i]
             t.upload(self.device)
@@ -995,21 +987,11 @@ class AdamTable:
         """step_dev: optional int32 device tensor holding the 1-based step count (graph replay); else a host counter.
         loss_scale_dev / skip_dev: GradScaler's scale and found_inf (device fp32 scalars): gradients are divided by the scale
         inside the update, a non-zero found_inf skips it (cris_adam_step_amp)"""
-        self.begin_step()
-        for k in range(self.n_segments):
-            self.step_segment(k, beta1, beta2, eps, weight_decay, grad_scale, step_dev, loss_scale_dev, skip_dev)
-
-    def begin_step(self):
-        """count one optimizer step (the host-side bias corrections of a caller without a device step counter)"""
         self.step_count += 1
-
-    def step_segment(self, k, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0, step_dev=None, loss_scale_dev=None,
-                     skip_dev=None):
-        """the update of segment k alone, on the current stream (begin_step() once per step before the first segment)"""
         bc1 = 1.0 - beta1 ** self.step_count
         bc2 = 1.0 - beta2 ** self.step_count
         for taps in (9, 1):
-            t = self.tables[(k, taps)]
+            t = self.tables[taps]
             if t.n:
                 hip.call("cris_adam_step_amp", ptr(t.dev), t.n, t.total_blocks, beta1, beta2, eps, weight_decay, bc1, bc2,
                          grad_scale, ptr(step_dev), ptr(loss_scale_dev), ptr(skip_dev), taps, _stream())

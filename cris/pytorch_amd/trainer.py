@@ -131,26 +131,8 @@ class NativeTrainer:
         e, names = self.engine, self.names
         lr_of = dict(zip(names, lrs))
         live = {names.index("backbone.token_embedding.weight"): e.embed_live} if e.embed_live is not None else None
-        # Staged update (CRIS_ADAM_STAGED=1): one table segment per arena stage, updated on a stream of its own
-        # as soon as backward has finished the stage (and, with several ranks, its gradients have been exchanged) - the update
-        # is pure HBM streaming (30 bytes per parameter), the rest of backward is latency-chained mid-size kernels, so the two
-        # overlap instead of the update running alone behind the last gradient.  A stage's parameters and bf16 operand copies
-        # are read for the last time in a step by the stage's own backward closures (the closure that produces a tensor's
-        # gradient is the one that reads it), so rewriting them then is safe; the arithmetic is elementwise, so the result is
-        # bit-identical to the single pass at the end.
-        self._staged = (os.environ.get("CRIS_ADAM_STAGED", "0") == "1" and torch.device(self.device).type == "cuda"
-                        and (self.comm.world == 1 or hasattr(self.comm, "stream_wait_last")))
-        segments = None
-        self._segment_of = {}
-        if self._staged:
-            stages = sorted({e.stage_of(n) for n in names})
-            self._segment_of = {st: k for k, st in enumerate(stages)}
-            segments = [[i for i, n in enumerate(names) if e.stage_of(n) == st] for st in stages]
-            if getattr(self, "_upd", None) is None:
-                self._upd = torch.cuda.Stream(device=self.device)
         self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [lr_of[n] for n in names],
-                                  layouts=[e.gemm_layout(n) for n in names], packs=[e.pack_info.get(n) for n in names], row_live=live,
-                                  segments=segments)
+                                  layouts=[e.gemm_layout(n) for n in names], packs=[e.pack_info.get(n) for n in names], row_live=live)
 
     @property
     def step_idx(self):
@@ -185,42 +167,16 @@ class NativeTrainer:
                 ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
         else:
             ops.train_metric(pred, msk, pred.shape[0], pred.shape[2] * pred.shape[3], self.metric)
-        exchange = self.comm.world > 1 or debug.HOOKS.force_dist
-        # (not under bench.py's per-launch timer: an update running beside a timed kernel would be charged to that kernel)
-        if self._staged and ops.KERNEL_TIMER is None and (not exchange or hasattr(self.comm, "stream_wait_last")):
-            upd, done = self._upd, set()
-            self.adam.begin_step()
-
+        if self.comm.world > 1 or debug.HOOKS.force_dist:
             def on_stage(st):
-                # (called on the stream that finished the stage: the launch stream, or the text encoder's for stage 4)
-                if exchange:
-                    lo, hi = e.stage_ranges[st]
-                    ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))
-                    ops.torch_op(lambda: self.comm.stream_wait_last(upd))            # the update waits for the exchanged gradients
-                else:
-                    ops.torch_op(lambda: upd.wait_stream(torch.cuda.current_stream()))
-                if st not in self._segment_of:          # (a stage without parameters)
-                    return
-                with torch.cuda.stream(upd):
-                    self.adam.step_segment(self._segment_of[st], weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world,
-                                           step_dev=self.step_dev)
-                done.add(st)
+                lo, hi = e.stage_ranges[st]
+                ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))
             e.backward(on_stage_done=on_stage)
-            assert done == set(self._segment_of), (sorted(done), sorted(self._segment_of))   # every segment was updated
-            if exchange:
-                ops.torch_op(self.comm.wait_all)
-            ops.torch_op(lambda: torch.cuda.current_stream().wait_stream(upd))
+            ops.torch_op(self.comm.wait_all)
         else:
-            if exchange:
-                def on_stage(st):
-                    lo, hi = e.stage_ranges[st]
-                    ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))
-                e.backward(on_stage_done=on_stage)
-                ops.torch_op(self.comm.wait_all)
-            else:
-                e.backward()
-            # one Adam pass over every tensor; it also rewrites the bf16 operand copies of the GEMM weights from the new values
-            self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
+            e.backward()
+        # one Adam pass over every tensor; it also rewrites the bf16 operand copies of the GEMM weights from the new values
+        self.adam.step(weight_decay=self.weight_decay, grad_scale=1.0 / self.comm.world, step_dev=self.step_dev)
         e.packs_current = self.adam.refreshes_packs
         return loss, pred, msk
 

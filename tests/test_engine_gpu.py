@@ -129,42 +129,6 @@ def test_training_step_is_deterministic():
         assert all(torch.equal(params[k], outs[0][2][k]) for k in params)
 
 
-def _run_trainer(spec, batch, size, steps, mode):
-    clip, head = arch.specs_by_name(spec)
-    dev = torch.device("cuda:0")
-    tr = NativeTrainer(clip, head, arch.synthetic_state_dict(clip, head, 0), dev, launch=mode)
-    losses = []
-    for t in range(steps):
-        img, word, mask = synth.make_batch(batch, size, head.word_len, 0, t)
-        loss, _ = tr.train_step(img.to(dev), word.to(dev), mask.to(dev))
-        losses.append(float(loss))
-    torch.cuda.synchronize()
-    state = [v.clone() for v in tr.engine.P.values()] + [v.clone() for v in tr.engine.Bf.values()]
-    state += [t.clone() for t in tr.adam.m] + [t.clone() for t in tr.adam.v] + [t.clone() for pair in tr.adam.keep for t in pair if t is not None]
-    return tr, losses, state
-
-
-@pytest.mark.parametrize("spec,batch,size,steps,mode", [("tiny", 4, 64, 5, "eager"), ("tiny", 4, 64, 5, "graph"), ("tiny", 4, 64, 5, "cmdlist"),
-                                                        ("r50", 8, 416, 4, "graph")])
-def test_staged_optimizer_update_is_bit_identical(monkeypatch, spec, batch, size, steps, mode):
-    """The native trainer updates every arena stage's parameters on a stream of its own as soon as backward has finished the
-    stage (trainer._build_adam); CRIS_ADAM_STAGED=0 runs the one pass behind the last gradient instead.  Same losses, and
-    bit-identical parameters, BatchNorm buffers, Adam moments and bf16 operand copies after several steps - in every launch
-    mode, and at the full configs[1] size, where the update really overlaps the rest of backward."""
-    res = {}
-    for staged in ("0", "1"):
-        monkeypatch.setenv("CRIS_ADAM_STAGED", staged)
-        tr, losses, state = _run_trainer(spec, batch, size, steps, mode)
-        assert tr._staged == (staged == "1") and tr.launch == mode and tr.graph_error is None
-        assert tr.adam.n_segments == (len({tr.engine.stage_of(n) for n in tr.names}) if staged == "1" else 1)
-        res[staged] = (losses, state)
-        del tr
-        torch.cuda.empty_cache()
-    assert res["0"][0] == res["1"][0], (res["0"][0], res["1"][0])
-    assert len(res["0"][1]) == len(res["1"][1])
-    assert all(torch.equal(a, b) for a, b in zip(res["0"][1], res["1"][1]))
-
-
 def test_two_streams_do_not_disturb_each_other():
     """The text encoder runs on a second stream underneath the convolutions.  (1) tools/concurrency_probe.py: its backward
     pattern repeated from fixed inputs stays bit-identical under every kind of load on the other stream (it did not while

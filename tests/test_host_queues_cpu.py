@@ -100,35 +100,3 @@ def test_optional_adam_is_torch_adam_without_an_engine_backed_module():
             opt.step()
         res.append(w.detach().clone())
     assert torch.equal(res[0], res[1])
-
-
-def test_adam_table_segments_cover_every_tensor_once(recorder):
-    """ops.AdamTable(segments=...): one pair of device tables per segment (3x3 packed weights / everything else), block numbering
-    restarted per table, `step()` = begin_step + every segment, `step_segment(k)` = the launches of segment k alone - the
-    native trainer's per-stage update underneath backward (trainer._build_adam)."""
-    ps = [torch.zeros(10000), torch.zeros(70, 3), torch.zeros(9000), torch.zeros(5)]
-    gs = [torch.zeros_like(p) for p in ps]
-    one = ops.AdamTable(ps, gs, [1e-3] * 4)
-    assert one.n_segments == 1 and one.tables[(0, 1)].n == 4 and one.tables[(0, 9)].n == 0
-    be = hip.load().cris_adam_block_elems()
-    blocks = [(p.numel() + be - 1) // be for p in ps]
-    assert one.tables[(0, 1)].total_blocks == sum(blocks)
-    seg = ops.AdamTable(ps, gs, [1e-3, 2e-3, 3e-3, 4e-3], segments=[[2, 0], [1, 3]])
-    t0, t1 = seg.tables[(0, 1)], seg.tables[(1, 1)]
-    assert (t0.n, t1.n) == (2, 2)
-    assert [t0.arr[j].block_start for j in range(2)] == [0, blocks[2]] and t0.total_blocks == blocks[2] + blocks[0]
-    assert [t1.arr[j].block_start for j in range(2)] == [0, blocks[1]] and t1.total_blocks == blocks[1] + blocks[3]
-    assert [t0.arr[j].p for j in range(2)] == [ps[2].data_ptr(), ps[0].data_ptr()]
-    assert [round(t1.arr[j].lr, 6) for j in range(2)] == [2e-3, 4e-3]
-    seg.set_lrs([5e-3] * 4)
-    assert all(round(t.arr[j].lr, 6) == 5e-3 for t in (t0, t1) for j in range(2))
-    with pytest.raises(AssertionError):
-        ops.AdamTable(ps, gs, [1e-3] * 4, segments=[[0, 1], [1, 2, 3]])
-    del recorder[:]
-    seg.step()
-    assert [c[0] for c in recorder] == ["cris_adam_step_amp"] * 2 and seg.step_count == 1
-    assert [c[1][1:3] for c in recorder] == [(2, t0.total_blocks), (2, t1.total_blocks)]
-    del recorder[:]
-    seg.begin_step()
-    seg.step_segment(1)
-    assert len(recorder) == 1 and recorder[0][1][2] == t1.total_blocks and seg.step_count == 2

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the code this exercises was REMOVED after calls L / M measured it slower: profiles/r04/call_l_m_staged_adam_rejected.patch holds it)
 # Round 4, call L (the last 7 GPU-minutes): the per-stage optimizer update (CRIS_ADAM_STAGED) - bit-identity test, step time A/B,
 # the multi-rank code paths with it on.  Every piece under its own timeout; most important first.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out; L=gpurun_out/r04l
