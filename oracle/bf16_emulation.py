@@ -66,16 +66,18 @@ def staged():
 
 
 @contextlib.contextmanager
-def bf16_storage(kinds=None, where=None):
+def bf16_storage(kinds=None, where=None, skip=None):
     """kinds: the storage points to round (None: all of KINDS); where: optional predicate, evaluated at every storage point -
-    rounding happens only while it is true (e.g. `lambda: STAGE[0] == "decoder"` under staged())"""
+    rounding happens only while it is true (e.g. `lambda: STAGE[0] == "decoder"` under staged()); skip: optional predicate of
+    the point's kind - a point it accepts is left in fp32 (e.g. `lambda kind: STAGE[0] == "text" and kind == "linear_w"`:
+    everything rounded except the text encoder's weights - what promoting one group of points would buy)"""
     kinds = set(KINDS if kinds is None else kinds)
     assert kinds <= set(KINDS), kinds - set(KINDS)
     saved = dict(conv2d=O.F.conv2d, linear=O.F.linear, relu=O.F.relu, interpolate=O.F.interpolate, avg_pool2d=O.F.avg_pool2d,
                  layer_norm=O.layer_norm, mha_core=O.mha_core)
 
     def rk(x, kind):
-        if kind in kinds and (where is None or where()):
+        if kind in kinds and (where is None or where()) and not (skip is not None and skip(kind)):
             return r(x)
         return x
 

@@ -33,14 +33,14 @@ KIND_GROUPS = {
 }
 
 
-def emul_loss(ot, batch, seed, kinds=None, stage=None, extra_where=None):
+def emul_loss(ot, batch, seed, kinds=None, stage=None, extra_where=None, skip=None):
     img, word, mask = (t.to(ot.device) for t in batch)
     where = None
     if stage is not None:
         where = (lambda: E.STAGE[0] == stage)
     if extra_where is not None:
         where = extra_where
-    with torch.no_grad(), E.staged(), E.bf16_storage(kinds=kinds, where=where):
+    with torch.no_grad(), E.staged(), E.bf16_storage(kinds=kinds, where=where, skip=skip):
         _, _, loss = O.cris_forward(ot.leaf, ot.clip, ot.head, img, word, mask, training=True,
                                     drop_seed=seed if ot.head.dropout > 0 else None, bn_updates={})
     return float(loss)
@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--no-hip", action="store_true")
     ap.add_argument("--device", default="cuda:0")
     ap.add_argument("--detail", default=None, help="a stage name: only that stage, one kind of storage point at a time")
+    ap.add_argument("--without", default=None, help="stage names joined by '+': the floor with every storage point on EXCEPT that stage's "
+                                                    "(all of them / its weights / its activations) - what promoting the stage to fp32 would buy")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device(args.device)
@@ -73,6 +75,17 @@ def main():
     if args.detail:
         configs = [("all", None, None), ("stage:" + args.detail, None, args.detail)]
         configs += [("%s/%s" % (args.detail, k), (k,), args.detail) for k in E.KINDS]
+    skips = {}
+    if args.without:
+        ws = tuple(args.without.split("+"))
+        assert all(w in E.STAGES for w in ws), (ws, E.STAGES)
+        configs = [("all", None, None)]
+        for w in ws:
+            skips["all but " + w] = (lambda kind, w=w: E.STAGE[0] == w)
+            skips["all but %s weights" % w] = (lambda kind, w=w: E.STAGE[0] == w and kind in ("linear_w", "conv_w"))
+            skips["all but %s activations" % w] = (lambda kind, w=w: E.STAGE[0] == w and kind not in ("linear_w", "conv_w"))
+        if len(ws) > 1:
+            skips["all but " + " + ".join(ws)] = (lambda kind: E.STAGE[0] in ws)
     rows = []
     for t in range(args.steps):
         batch = synth.make_batch(args.batch, args.size, head.word_len, 0, t)
@@ -92,6 +105,8 @@ def main():
             row["fp32"] = float(l32)
             for name, kinds, stage in configs:
                 row[name] = emul_loss(ot, batch, seed, kinds=kinds, stage=stage)
+            for name, skip in skips.items():
+                row[name] = emul_loss(ot, batch, seed, skip=skip)
             rows.append(row)
             print("BUDGET step %3d fp32 %.5f " % (t, row["fp32"]) + " ".join(
                 "%s %.1e" % (k, abs(v - row["fp32"])) for k, v in row.items() if k not in ("step", "fp32")), flush=True)
