@@ -1,6 +1,10 @@
 """TEST INFRASTRUCTURE ONLY - the oracle as a trainer: forward (oracle/cris_oracle.py) + autograd + torch.optim.Adam on any
-device, in one of three precision policies:
+device, in one of four precision policies:
 
+  "fp64"   every parameter, buffer and activation in float64 (the oracle is dtype-generic).  The teacher of the teacher-forced
+           parity tests since round 5: at the 1e-3 scale of the north star its trajectory does not depend on which MIOpen /
+           hipBLASLt kernel a box picks or on the summation order of atomics (an fp32 teacher's trajectory through the untrained
+           head's first 40 steps moved the 100-state mean |dloss| by +-25 % from box to box, profiles/parity_r04.md);
   "fp32"   plain fp32 (on the CPU this is the pinned ground truth; on the GPU it is checked equal to it,
            tests/test_oracle_device.py);
   "fp16"   the REFERENCE's own policy: torch.autocast(float16) around forward + loss, GradScaler around backward and the
@@ -27,11 +31,13 @@ def seed_of_step(t):
 
 class OracleTrainer:
     def __init__(self, clip, head, sd, device, mode="fp32", lr=1e-4):
-        assert mode in ("fp32", "fp16", "bf16")
+        assert mode in ("fp64", "fp32", "fp16", "bf16")
         self.clip, self.head, self.device, self.mode = clip, head, torch.device(device), mode
         self.leaf = {}
         for k, v in sd.items():
             t = v.detach().to(self.device).clone()
+            if mode == "fp64" and t.is_floating_point():
+                t = t.double()
             if t.is_floating_point() and not k.endswith(("running_mean", "running_var")):
                 t.requires_grad_(True)
             self.leaf[k] = t
@@ -48,7 +54,7 @@ class OracleTrainer:
             torch.use_deterministic_algorithms(True, warn_only=True)
 
     def _ctx(self):
-        if self.mode == "fp32":
+        if self.mode in ("fp32", "fp64"):
             return contextlib.nullcontext()
         return torch.autocast(self.device.type, dtype=torch.float16 if self.mode == "fp16" else torch.bfloat16)
 
@@ -57,7 +63,7 @@ class OracleTrainer:
         img, word, mask = (t.to(self.device) for t in batch)
         self.opt.zero_grad(set_to_none=True)
         bnu = {}
-        O.NATIVE_NORMS = self.mode != "fp32"
+        O.NATIVE_NORMS = self.mode not in ("fp32", "fp64")
         try:
             with self._ctx():
                 pred, m, loss = O.cris_forward(self.leaf, self.clip, self.head, img, word, mask, training=True,
