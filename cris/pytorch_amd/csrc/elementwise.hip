@@ -378,14 +378,18 @@ extern "C" int cris_cast_f32_bf16_drop(const float* x, cris_bf16* y, long n, flo
     CRIS_LAUNCH_CHECK();
     return 0;
 }
-__global__ void step_advance_kernel(int* step, uint32_t* seed) {
+__global__ void step_advance_kernel(int* step, uint32_t* seed, int* exchange_gen) {
     const int s = step[0];                       // steps completed so far
     seed[0] = (uint32_t)s * 7919u + 17u;        // dropout seed of the step that starts now (0-based rule)
     step[0] = s + 1;                             // 1-based count read by cris_adam_step
+    // generation of this step's peer-mailbox exchanges (p2p_ll.h): a counter of its own that NOTHING ever rewinds - the optimizer
+    // step can be (load_optimizer_state_dict of an earlier checkpoint on a live trainer), and a rewound generation would accept
+    // the words still lying in the mailboxes from the first time it was used
+    if (exchange_gen) exchange_gen[0] += 1;
 }
-extern "C" int cris_step_advance(int32_t* step, uint32_t* seed, void* stream) {
+extern "C" int cris_step_advance(int32_t* step, uint32_t* seed, int32_t* exchange_gen, void* stream) {
     CRIS_CHECK_ARG(step && seed, "bad args");
-    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, seed);
+    hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step, seed, exchange_gen);
     CRIS_LAUNCH_CHECK();
     return 0;
 }

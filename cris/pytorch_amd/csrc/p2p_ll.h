@@ -7,6 +7,9 @@
 // the values it owns by itself (RCCL's LL protocol, applied per channel).  Layout of the LL region (behind the flag-protocol
 // region of p2p.hip, 256-byte aligned), in words:
 //   ll [2 parities][slots][world][max_floats]          word (parity, slot, src, i) of rank r's mailbox = value i sent by rank src
+// The generation is a device counter of its own (cris_step_advance's exchange_gen) that advances once per step and is never
+// rewound - the optimizer step count is, when a checkpoint is loaded into a live trainer, and a generation used twice would
+// accept the words of its first use without waiting.
 // Reuse: a word is rewritten two generations (steps) later at the earliest; a rank can only reach step t+2's exchange `slot`
 // after every rank has taken part in step t+1's - i.e. after every rank's step-t kernel of that slot has completed (kernels of
 // one stream run in order) - so nobody still reads generation t when generation t+2 is written.

@@ -131,7 +131,7 @@ class TorchDistComm:
         self.p2p, self._gen_dev, self._slot, self._fused = None, None, 0, False
 
     def enable_p2p(self, slots, max_floats, gen_dev):
-        """Route the SyncBN exchanges through peer mailboxes; `gen_dev` = the trainer's device step counter.  Collective: every
+        """Route the SyncBN exchanges through peer mailboxes; `gen_dev` = the trainer's device counter of exchange generations (advances with every step, never rewound - unlike the optimizer step).  Collective: every
         rank runs the SAME sequence of host all-gathers whatever fails locally (a rank whose allocation or mapping fails
         reports it in the next all-gather instead of leaving the sequence).  Returns None when the mailboxes are in use, else
         the reason they are not (allocation / IPC mapping / self-test failed on some rank: every rank then keeps the RCCL
@@ -166,6 +166,20 @@ class TorchDistComm:
         # CRIS_SYNCBN_FUSED=0: the exchange stays a kernel of its own between the BatchNorm launches (round 3's form)
         self._fused = os.environ.get("CRIS_SYNCBN_FUSED", "1") == "1"
         return None
+
+    def check_peer_timeout(self):
+        """COLLECTIVE (host all-gather; every rank must call it, e.g. at a logging interval or an epoch boundary - it costs one
+        device synchronisation): raises RuntimeError on EVERY rank when a mailbox exchange of ANY rank gave up waiting for a peer
+        (csrc/p2p_ll.h: the poll limit; the statistics of that rank are NaN from there on).  A rank that lost a peer therefore
+        never trains on alone, and no rank hangs: the exchange kernels themselves are bounded by the poll limit."""
+        if self.p2p is None:
+            return
+        torch.cuda.synchronize()
+        flags = self.all_gather_object(int(self.p2p.err.item()))
+        bad = [q for q, f in enumerate(flags) if f]
+        if bad:
+            raise RuntimeError("SyncBN peer-mailbox exchange: rank(s) %s gave up waiting for a peer (poll limit reached) - the statistics "
+                               "of this run are invalid from that step on" % bad)
 
     def next_link(self):
         if self.p2p is None or not self._fused:

@@ -270,7 +270,7 @@ _SIGS = {
     "cris_cast_f32_bf16": (I, [P, P, L, P]),
     "cris_cast_bf16_f32": (I, [P, P, L, I, P]),
     "cris_cast_f32_bf16_drop": (I, [P, P, L, F, U, U, U, P, P]),
-    "cris_step_advance": (I, [P, P, P]),
+    "cris_step_advance": (I, [P, P, P, P]),
     "cris_axpy_f32": (I, [P, P, F, L, P]),
     "cris_quickgelu_fwd": (I, [P, P, L, P]),
     "cris_quickgelu_bwd": (I, [P, P, P, L, P]),

@@ -118,6 +118,22 @@ class _CrisStep(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
+# Bumped whenever ANY nn.Module registers a parameter or a sub-module (torch's global registration hooks; assignments through
+# __setattr__ go through them too): CRIS._fast_key re-walks its parameter list when this moved.  Round-4 advisor finding: the
+# fast key looked at the first and last parameter only, so a replaced MIDDLE parameter kept training the old tensor.
+_REGISTRATION_EPOCH = [0]
+
+
+def _bump_registration_epoch(*_a, **_k):
+    _REGISTRATION_EPOCH[0] += 1
+    return None
+
+
+nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
+nn.modules.module.register_module_module_registration_hook(_bump_registration_epoch)
+_data_ptr = torch.Tensor.data_ptr
+
+
 class CRIS(nn.Module):
     _instances = weakref.WeakSet()          # live modules (cris.pytorch_amd.optim.Adam looks its parameters' owner up here)
 
@@ -163,10 +179,15 @@ class CRIS(nn.Module):
         submodules cost ~1.5 ms of host time per step - time in which the GPU idles under the reference's loop): the device, the
         storage of the first and last parameter (a move re-allocates all of them; in-place loads keep them), the kind of the
         BatchNorm modules (convert_sync_batchnorm replaces them all), whether a process group exists, the gradient mode"""
-        if getattr(self, "_plist", None) is None:
+        if getattr(self, "_plist", None) is None or self._plist_epoch != _REGISTRATION_EPOCH[0]:
+            # (a Parameter or sub-module registered ANYWHERE since the list was made - weight surgery, a re-initialised head -
+            # makes the cached list suspect: walk the tree again, once)
             self._plist = list(self.parameters())
+            self._plist_epoch = _REGISTRATION_EPOCH[0]
         pl = self._plist
-        return (str(device), pl[0].data_ptr(), pl[-1].data_ptr(), len(pl), type(self.backbone.visual.bn1),
+        # every parameter's storage address (`p.data = other` re-points one tensor without registering anything): ~40 us of
+        # host time for the 449 tensors, against ~1.5 ms for the tree walk
+        return (str(device), sum(map(_data_ptr, pl)), pl[0].data_ptr(), pl[-1].data_ptr(), len(pl), type(self.backbone.visual.bn1),
                 dist.is_available() and dist.is_initialized(), bool(self._grad_views))
 
     def _ensure_engine(self, device):
@@ -178,7 +199,10 @@ class CRIS(nn.Module):
         buffers = {n: b for n, b in self.named_buffers() if n.endswith(("running_mean", "running_var"))}
         sync = (any(isinstance(m, nn.SyncBatchNorm) for m in self.modules()) and dist.is_available()
                 and dist.is_initialized() and dist.get_world_size() > 1)
-        views = bool(self._grad_views) and not sync and not (dist.is_available() and dist.is_initialized())
+        # gradient-view mode (cris.pytorch_amd.optim.Adam bound): also under a process group / DistributedDataParallel - there
+        # `.grad` is DDP's averaged gradient in its own tensor, which the optimizer copies into the arena views before its
+        # fused update (optim.Adam.step)
+        views = bool(self._grad_views)
         key = (str(device), sync, views, tuple(p.data_ptr() for p in params.values()), tuple(b.data_ptr() for b in buffers.values()))
         if self._engine is not None and key == self._engine_key:
             return self._engine

@@ -739,8 +739,8 @@ def cast_f32_bf16_drop(x, y, drop: Drop):
              ptr(drop.dev), _stream())
 
 
-def step_advance(step, seed):
-    hip.call("cris_step_advance", ptr(step), ptr(seed), _stream())
+def step_advance(step, seed, exchange_gen=None):
+    hip.call("cris_step_advance", ptr(step), ptr(seed), ptr(exchange_gen), _stream())
 
 
 def axpy_f32(dst, src, alpha=1.0):

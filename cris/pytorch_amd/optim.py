@@ -1,6 +1,7 @@
 """Optional optimizer for the drop-in module: `cris.pytorch_amd.optim.Adam` is a `torch.optim.Adam` whose `step()` runs the
-library's fused update (`cris_adam_step_amp`) when every parameter it holds belongs to ONE engine-backed
-`cris.pytorch_amd.model.CRIS` in a single process - the one-line change at the reference's train.py:105
+library's fused update (`cris_adam_step_amp`) when it holds the parameters of ONE engine-backed
+`cris.pytorch_amd.model.CRIS` (bare, or wrapped in DistributedDataParallel as train.py:100-102 does) - the one-line change at the
+reference's train.py:105
 
     optimizer = cris.pytorch_amd.optim.Adam(param_list, lr=args.base_lr, weight_decay=args.weight_decay)
 
@@ -13,12 +14,20 @@ Everything else of the loop stays as it is (engine/engine.py:48-57: `scaler.scal
     re-pack of the weights in the next forward, no per-parameter Python in `step()`;
   * GradScaler hands its scale and found_inf over as device scalars (`_step_supports_amp_scaling`): the gradients are unscaled
     inside the update and a step with a non-finite gradient is skipped on the device, without a host synchronisation.
-With parameters of anything else (or under DistributedDataParallel, whose averaged gradients live in its own buckets) the
-class IS torch.optim.Adam: `step()` falls through to the parent, and `_step_supports_amp_scaling` reads False.
+When does the fused update run?  The optimizer must hold EVERY gradient parameter of one engine-backed CRIS module (the
+reference's two groups do), with one set of betas / eps / weight_decay over its groups and without amsgrad / maximize /
+capturable / differentiable.  Anything else - parameters of another model, a subset, per-group weight decay - and the class IS
+torch.optim.Adam: `step()` falls through to the parent (and tells the module that its bf16 operand copies are stale), and
+`_step_supports_amp_scaling` reads False.
+The update reads the gradient ARENA, so `step()` first makes the arena hold what `.grad` holds: a parameter whose `.grad` is
+still the arena view (the reference's loop: zero_grad -> backward -> step) costs nothing; a `.grad` that is its own tensor - a
+sum over several micro-batches (gradient accumulation), `zero_grad(set_to_none=False)`, and under DistributedDataParallel the
+averaged gradient DDP wrote (the reference's train.py:100-102 wraps the model in DDP even on one GPU) - is copied into its view
+first (all tensors: 0.6 GB read + written, ~0.2 ms, against ~4 ms for torch's unscale + foreach Adam).  A parameter whose
+`.grad` is None makes the step fall back to torch's (which skips such parameters).
 `state_dict()` / `load_state_dict()` keep torch.optim.Adam's format (exp_avg / exp_avg_sq / step per parameter), so the
 reference's checkpoints (train.py:159-174,192-207) move both ways."""
 import torch
-import torch.distributed as dist
 
 from . import hip, ops
 
@@ -33,27 +42,66 @@ class Adam(torch.optim.Adam):
 
     # ------------------------------------------------------------------------------------------------
     def _bind(self):
-        """find the CRIS module that owns all of this optimizer's parameters; tell it to expose gradients as arena views"""
+        """find the CRIS module whose gradient parameters are exactly this optimizer's; only if the hyperparameters allow the
+        fused update is it told to expose gradients as arena views (in that mode the module's replayed forward carries no
+        re-pack of the bf16 operand copies - the update rewrites them; round-4 advisor finding: switching the mode on for an
+        optimizer that then falls back to torch's step left the copies stale)"""
         from .model.segmenter import CRIS
         mine = {id(p) for g in self.param_groups for p in g["params"]}
-        for m in list(CRIS._instances):
-            own = {id(p) for p in m.parameters()}
-            if mine and mine <= own:
-                self._cris = m
-                m._grad_views = True          # (an engine built before this is rebuilt by the next forward: the flag is part of its key)
-                return
         self._cris = None
+        for m in list(CRIS._instances):
+            need = {id(p) for n, p in m.named_parameters() if n != "backbone.logit_scale"}     # (never receives a gradient)
+            own = {id(p) for p in m.parameters()}
+            if mine and need <= mine <= own:
+                self._cris = m
+                if self._hyper_ok():
+                    m._grad_views = True      # (an engine built before this is rebuilt by the next forward: the flag is part of its key)
+                return
+
+    def _hyper_ok(self):
+        g = self.param_groups[0]
+        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
+            return False
+        return all(gr["betas"] == g["betas"] and gr["eps"] == g["eps"] and gr["weight_decay"] == g["weight_decay"]
+                   and not (gr.get("amsgrad") or gr.get("maximize")) for gr in self.param_groups)
 
     def _usable(self):
         m = self._cris
         if m is None or m._engine is None or not getattr(m, "_grad_views_active", False):
             return False
-        if dist.is_available() and dist.is_initialized():
-            return False                                  # DDP averages into its own buckets: the arena holds local gradients
-        g = self.param_groups[0]
-        if g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable"):
-            return False
-        return all(gr["betas"] == g["betas"] and gr["eps"] == g["eps"] and gr["weight_decay"] == g["weight_decay"] for gr in self.param_groups)
+        return self._hyper_ok()
+
+    def _torch_step(self, closure):
+        """torch.optim.Adam's own step; the parameters then changed behind the engine's back"""
+        if self._tab is not None:
+            self._sync_state_steps()                      # torch's bias corrections read state["step"]: the fused steps so far
+        r = super().step(closure)
+        if self._tab is not None:
+            self._step_dev.add_(1)                        # (exp_avg / exp_avg_sq ARE the table's tensors: updated in place)
+        m = self._cris
+        if m is not None and m._engine is not None:
+            m._engine.packs_current = False               # the module re-packs before its next replay (segmenter._graph_step)
+        return r
+
+    def _grads_into_arena(self):
+        """Make the arena hold what `.grad` holds (see the module docstring).  False: some `.grad` is None - not a fused step."""
+        m = self._cris
+        src, dst = [], []
+        for p, v in zip(m._step_params, m._step_grads):
+            g = p.grad
+            if g is v:
+                continue
+            if g is None:
+                return False
+            src.append(g)
+            dst.append(v)
+        if src:
+            try:
+                torch._foreach_copy_(dst, src)
+            except Exception:                             # noqa: BLE001 - (strided destinations on an older torch)
+                for d, s_ in zip(dst, src):
+                    d.copy_(s_)
+        return True
 
     @property
     def _step_supports_amp_scaling(self):
@@ -101,11 +149,13 @@ class Adam(torch.optim.Adam):
     @torch.no_grad()
     def step(self, closure=None):
         if not self._usable():
-            return super().step(closure)
+            return self._torch_step(closure)
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if getattr(self._cris, "_step_cache_key", None) != self._cris._engine_key or not self._grads_into_arena():
+            return self._torch_step(None)                 # (no training forward on this engine yet / a `.grad` is None)
         tab = self._table()
         lrs = [float(g["lr"]) for g in self.param_groups for p in g["params"] if p in self.state]
         if lrs != self._tab_lrs:                          # a scheduler moved the learning rates (train.py:108-110, once per epoch)

@@ -91,6 +91,9 @@ class NativeTrainer:
         # per-step device state: steps done (int32) and the dropout seed of the running step
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=device)
         self.seed_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        # generation of the peer-mailbox exchanges: advances with every step and is NEVER rewritten (the optimizer step is, by
+        # load_optimizer_state_dict: a rewound generation would accept the stale words of its first use, csrc/p2p_ll.h)
+        self.xgen_dev = torch.zeros(1, dtype=torch.int32, device=device)
         # SyncBN statistics: 142 exchanges of a few KB per step, all on the critical path.  Default: peer-mapped mailboxes, one
         # kernel per exchange (dist.PeerMailboxes) - when allocation, IPC mapping and a self-test with known data succeed on
         # EVERY rank; otherwise (and with CRIS_SYNCBN_P2P=0, or a communicator without mailboxes) the RCCL collectives.
@@ -98,7 +101,7 @@ class NativeTrainer:
         if (e.sync_bn and os.environ.get("CRIS_SYNCBN_P2P", "1") == "1"          # (world 1 + CRIS_FORCE_DIST: the exchange with itself)
                 and torch.device(device).type == "cuda" and hasattr(self.comm, "enable_p2p")):
             cmax = max(e.P[pfx + ".weight"].numel() for pfx in e.bn_prefixes)
-            why = self.comm.enable_p2p(slots=2 * len(e.bn_prefixes) + 8, max_floats=4 * cmax, gen_dev=self.step_dev)
+            why = self.comm.enable_p2p(slots=2 * len(e.bn_prefixes) + 8, max_floats=4 * cmax, gen_dev=self.xgen_dev)
             if why is None:
                 fused = getattr(self.comm, "_fused", False)
                 self.syncbn_exchange = "p2p mailboxes, exchanged inside the BatchNorm launches" if fused else "p2p mailboxes, one exchange kernel per BatchNorm"
@@ -134,6 +137,12 @@ class NativeTrainer:
         self.adam = ops.AdamTable([e.P[n] for n in names], [e.G[n] for n in names], [lr_of[n] for n in names],
                                   layouts=[e.gemm_layout(n) for n in names], packs=[e.pack_info.get(n) for n in names], row_live=live)
 
+    def check_peer_timeout(self):
+        """collective: raise on every rank if any rank's SyncBN mailbox exchange timed out (dist.TorchDistComm.check_peer_timeout)"""
+        chk = getattr(self.comm, "check_peer_timeout", None)
+        if chk is not None:
+            chk()
+
     @property
     def step_idx(self):
         return int(self.step_dev.item())
@@ -152,10 +161,10 @@ class NativeTrainer:
     def _step_body(self, img, word, mask, host_seed: Optional[int]):
         e = self.engine
         if host_seed is None:
-            ops.step_advance(self.step_dev, self.seed_dev)
+            ops.step_advance(self.step_dev, self.seed_dev, self.xgen_dev)
             e.seed_dev, seed = self.seed_dev, 0
         else:                                    # explicit seed (tests): host value, the device counter still advances
-            ops.step_advance(self.step_dev, self.seed_dev)
+            ops.step_advance(self.step_dev, self.seed_dev, self.xgen_dev)
             e.seed_dev, seed = None, host_seed
         pred, msk, loss = e.forward(img, word, mask, training=True, seed=seed)
         # the train metric (utils/misc.py:114-129) only needs the logits: it runs on the text-encoder stream underneath the

@@ -356,8 +356,9 @@ int cris_cast_bf16_f32(const cris_bf16* x, float* y, long n, int accum, void* st
 /* y = bf16(dropout(x)) over a flat fp32 tensor (gradient of nn.Dropout on the residual branches, model/layers.py:217-219) */
 int cris_cast_f32_bf16_drop(const float* x, cris_bf16* y, long n, float drop_p, uint32_t drop_thresh, uint32_t seed,
                             uint32_t stream_id, const uint32_t* seed_dev, void* stream);
-/* device-side per-step state of a replayed HIP graph: seed[0] = step[0] * 7919 + 17 ; step[0] += 1 */
-int cris_step_advance(int32_t* step, uint32_t* seed, void* stream);
+/* device-side per-step state of a replayed HIP graph: seed[0] = step[0] * 7919 + 17 ; step[0] += 1 ; exchange_gen[0] += 1
+ * (exchange_gen may be NULL: the generation counter of the peer-mailbox exchanges, never rewound - see csrc/p2p_ll.h) */
+int cris_step_advance(int32_t* step, uint32_t* seed, int32_t* exchange_gen, void* stream);
 int cris_axpy_f32(float* dst, const float* src, float alpha, long n, void* stream);
 /* QuickGELU x*sigmoid(1.702x) on a stored bf16 pre-activation (model/clip.py:234-236) */
 int cris_quickgelu_fwd(const cris_bf16* x, cris_bf16* y, long n, void* stream);

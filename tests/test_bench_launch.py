@@ -66,3 +66,20 @@ def test_two_ranks_on_one_gpu_end_to_end():
     d = lines[0]
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["final_loss"] == d["config"]["final_loss"]          # not NaN
+
+
+@pytest.mark.gpu
+def test_eight_ranks_on_one_gpu_launch_protocol():
+    """The first real 8-GPU SCALE run must not die in set-up: the N = 8 form of the driver's command on the one GPU of the test box
+    (gloo carries the host collectives, the eight ranks share the device; tiny model, batch 1, 64x64 - the launch protocol, the
+    mailbox set-up with world 8, SyncBN exchanges and the gradient exchange over eight ranks, not the benchmark configuration)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--backend", "gloo", "--spec", "tiny", "--size", "64", "--batch", "1",
+                        "--steps", "2", "--warmup", "0", "--no-cpu-baseline", "--no-kernel-timer"], env=_env(), stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=1200, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["final_loss"] == d["config"]["final_loss"]          # not NaN
+    assert d["config"]["syncbn_peer_timeout"] in (False, None)

@@ -208,6 +208,140 @@ def test_optional_fused_adam_matches_torch_adam_under_the_reference_loop():
     assert worst < 2e-3, worst                                        # five steps of lr 1e-4: the two runs took the same steps
 
 
+def _accumulate_params(opt_cls, zero_style, steps=3):
+    """two micro-batches per optimizer step under `opt_cls`; returns the parameters after `steps` optimizer steps"""
+    dev = torch.device("cuda:0")
+    model, groups = build_segmenter(NS(**TINY))
+    clip, head = arch.specs_by_name("tiny")
+    model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+    model = model.to(dev).train()
+    opt = opt_cls(groups, lr=1e-4, weight_decay=0.0)
+    for step in range(steps):
+        if zero_style == "none":
+            opt.zero_grad(set_to_none=True)
+        elif zero_style == "zeros":
+            opt.zero_grad(set_to_none=False)
+        for micro in range(2):
+            img, word, mask = _batch(2 * step + micro, dev)
+            _, _, loss = model(img, word, mask)
+            (0.5 * loss).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    return {n: p.detach().clone() for n, p in model.named_parameters()}, model, opt
+
+
+@pytest.mark.parametrize("zero_style", ["none", "zeros", "never"])
+def test_fused_adam_applies_the_accumulated_gradient(zero_style):
+    """the fused update reads the gradient ARENA, which after a second backward without zero_grad (or with
+    zero_grad(set_to_none=False)) holds the LAST micro-batch only while `.grad` holds the sum.  optim.Adam.step() copies such
+    `.grad`s into their arena views first: the parameters after three optimizer steps of two micro-batches each equal
+    torch.optim.Adam's, for every zero_grad style."""
+    from cris.pytorch_amd import optim
+    pa, ma, oa = _accumulate_params(optim.Adam, zero_style)
+    pb, _, _ = _accumulate_params(torch.optim.Adam, zero_style)
+    assert oa._usable() and ma._grad_views_active and oa._tab is not None        # the fused path ran
+    worst = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
+    # three steps of lr 1e-4: a step taken with only the last micro-batch's gradient moves many weights by up to 2e-4 the other
+    # way (Adam's first steps are sign-like); equal gradients leave the optimizers' fp32 rounding (measured ~1e-6 ... 2e-5)
+    assert worst < 1e-4, worst
+
+
+def test_fused_adam_fallback_keeps_the_operand_copies_current():
+    """(a) an optimizer whose hyperparameters rule the fused update out from the start (per-group weight
+    decay) must not switch the module to gradient-view mode; (b) one that becomes ineligible later falls back to torch's step
+    and marks the bf16 operand copies stale, so the next replayed forward re-packs them.  Checked on the copies themselves."""
+    from cris.pytorch_amd import optim
+    dev = torch.device("cuda:0")
+
+    def fresh():
+        model, groups = build_segmenter(NS(**TINY))
+        clip, head = arch.specs_by_name("tiny")
+        model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+        return model.to(dev).train(), groups
+
+    def steps(model, opt, n, first=0):
+        for step in range(first, first + n):
+            img, word, mask = _batch(step, dev)
+            _, _, loss = model(img, word, mask)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+
+    def copies_current(model):
+        e, w = model._engine, "neck.f2_cat.0.weight"                 # a 1x1 convolution: forward copy = bf16 of [N][Cin]
+        p = dict(model.named_parameters())[w].detach()
+        N, Cin = p.shape[0], p.shape[1]
+        return torch.equal(e.WF[w].view(N, -1)[:, :Cin].float(), p.view(N, Cin).bfloat16().float())
+
+    # (a) never eligible
+    model, groups = fresh()
+    groups[1]["weight_decay"] = 0.01
+    opt = optim.Adam(groups, lr=1e-4, weight_decay=0.0)
+    assert not model._grad_views
+    steps(model, opt, 4)                                             # steps 2 .. 3 are replays
+    assert not opt._usable() and not model._grad_views_active
+    _ = model(*_batch(9, dev))                                       # a forward after the last update: re-packs in its replay
+    assert copies_current(model)
+    # (b) eligible, then not
+    model, groups = fresh()
+    opt = optim.Adam(groups, lr=1e-4, weight_decay=0.0)
+    steps(model, opt, 3)
+    assert opt._usable() and model._engine.packs_current and copies_current(model)
+    opt.param_groups[1]["weight_decay"] = 0.01
+    steps(model, opt, 2, first=3)
+    assert not opt._usable() and not model._engine.packs_current      # torch's step ran: the copies are marked stale ...
+    _ = model(*_batch(9, dev))
+    assert copies_current(model)                                     # ... and the next forward repaired them
+    opt.param_groups[1]["weight_decay"] = 0.0
+    steps(model, opt, 2, first=5)                                    # eligible again: fused steps continue from torch's state
+    assert opt._usable() and copies_current(model)
+    assert int(opt._step_dev.item()) == 7
+
+
+def test_fused_adam_under_distributed_data_parallel_like_train_py():
+    """the reference's train.py ALWAYS initialises a process group and wraps the model in
+    DistributedDataParallel (train.py:80-102), also on one GPU.  The fused update runs there too: `.grad` is then DDP's
+    (averaged) gradient in a tensor of its own, which step() copies into the arena views.  One rank, gloo."""
+    import os
+    import tempfile
+    import torch.distributed as dist
+    from cris.pytorch_amd import optim
+    assert not dist.is_initialized()
+    dev = torch.device("cuda:0")
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        dist.init_process_group("gloo", init_method="file://" + os.path.join(td, "pg"), rank=0, world_size=1)
+        try:
+            for name, cls in (("cris", optim.Adam), ("torch", torch.optim.Adam)):
+                model, groups = build_segmenter(NS(**TINY))
+                clip, head = arch.specs_by_name("tiny")
+                model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+                model = torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)                                   # train.py:97-98
+                ddp = torch.nn.parallel.DistributedDataParallel(model.to(dev), device_ids=[0], find_unused_parameters=True)
+                opt = cls(groups, lr=1e-4, weight_decay=0.0)
+                sc = torch.amp.GradScaler("cuda")
+                ddp.train()
+                losses = []
+                for step in range(5):
+                    img, word, mask = _batch(step, dev)
+                    with torch.autocast("cuda"):
+                        _, _, loss = ddp(img, word, mask)
+                    opt.zero_grad()
+                    sc.scale(loss).backward()
+                    sc.step(opt)
+                    sc.update()
+                    losses.append(float(loss))
+                res[name] = (losses, {n: p.detach().clone() for n, p in model.named_parameters()}, opt, model)
+        finally:
+            dist.destroy_process_group()
+    la, pa, oa, ma = res["cris"]
+    lb, pb, _, _ = res["torch"]
+    assert oa._usable() and oa._tab is not None and ma._grad_views_active and int(oa._step_dev.item()) == 5
+    for a, b in zip(la, lb):
+        assert abs(a - b) < 1e-2, (la, lb)
+    assert max(float((pa[k] - pb[k]).abs().max()) for k in pa) < 2e-3
+
+
 def test_optional_fused_adam_skips_the_step_on_found_inf():
     """GradScaler's contract for `_step_supports_amp_scaling` optimizers: found_inf != 0 -> nothing changes, the step count
     does not advance; the gradients are divided by grad_scale inside the update"""

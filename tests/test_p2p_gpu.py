@@ -1,7 +1,10 @@
 """The peer-mailbox SyncBN exchange
-(csrc/p2p.hip, dist.PeerMailboxes) with two ranks sharing the one GPU of the test box - the mailboxes travel through HIP
-IPC exactly as between two GPUs.  (1) the primitive: sums over ranks, slot / generation reuse, device generation counter;
-(2) the whole trainer with CRIS_SYNCBN_P2P=1 equals the run that exchanges through torch.distributed."""
+(csrc/p2p.hip, dist.PeerMailboxes) with 2, 4 and 8 ranks sharing the one GPU of the test box - the mailboxes travel through HIP
+IPC exactly as between GPUs, and slot layout, rank-order summation and the generation-reuse argument all depend on `world`
+(csrc/p2p_ll.h).  (1) the primitive: sums over ranks in rank order, slot / generation reuse over six generations, device
+generation counter; a peer that never arrives: bounded wait, error flag, RuntimeError on EVERY rank; (2) the whole trainer with
+CRIS_SYNCBN_P2P=1 equals the run that exchanges through torch.distributed (world 2: all three exchange forms; world 4: the default
+form; world 8 under marker gpu_long - eight processes time-slicing one GPU take minutes)."""
 import dataclasses
 import os
 import socket
@@ -57,22 +60,83 @@ def _prim_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-@gpu
-def test_peer_mailbox_allreduce_two_ranks_one_gpu():
+def _spawn(target, world, *args, timeout=600):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_prim_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + args + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        res = sorted(q.get(timeout=timeout) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(120)
+            if p.is_alive():
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    return res
+
+
+@gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_peer_mailbox_allreduce_ranks_share_one_gpu(world):
+    """both protocols, four slots of 1 / 64 / 999 / 1000 floats, six generations (both parities, every slot reused three times),
+    host and device generation counters: every rank holds the sum taken in RANK ORDER, bit for bit"""
+    res = _spawn(_prim_worker, world)
     assert all(ok for _, ok in res), res
 
 
-def _train_worker(rank, world, port, p2p, launch, q):
+def _timeout_worker(rank, world, port, q):
+    """generation 7 of slot 0: the LAST rank does not take part.  Every other rank's exchange must give up at its poll limit (not
+    hang), set its error flag and poison its result; the collective check then raises on every rank, the absent one included."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cris.pytorch_amd.dist import TorchDistComm
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        comm = TorchDistComm(dev)
+        gen = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert comm.enable_p2p(slots=2, max_floats=64, gen_dev=gen) is None
+        box = comm.p2p
+        t = torch.full((64,), float(rank + 1), device=dev)
+        box.ll_allreduce_sum(t, 0, gen_host=5)                                # a complete exchange first (default poll limit: seconds)
+        torch.cuda.synchronize()
+        good = bool((t == float(world * (world + 1) // 2)).all()) and int(box.err.item()) == 0
+        comm.check_peer_timeout()                                            # nothing to report yet
+        dist.barrier()
+        t2 = torch.full((64,), 1.0, device=dev)
+        if rank != world - 1:
+            box.ll_allreduce_sum(t2, 0, gen_host=7, spin_limit=1 << 14)      # bounded wait for a peer that never comes
+            box.ll_allreduce_sum(t2, 1, gen_host=7, spin_limit=1 << 14)      # a later exchange does not wait again
+        torch.cuda.synchronize()
+        flagged = int(box.err.item()) != 0
+        poisoned = bool(torch.isnan(t2).all()) if rank != world - 1 else None
+        raised = False
+        try:
+            comm.check_peer_timeout()
+        except RuntimeError as ex:
+            raised = "gave up waiting" in str(ex)
+        dist.barrier()
+        box.close()
+        q.put((rank, good, flagged, poisoned, raised))
+    finally:
+        dist.destroy_process_group()
+
+
+@gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_peer_that_never_arrives_raises_on_every_rank(world):
+    res = _spawn(_timeout_worker, world)
+    for rank, good, flagged, poisoned, raised in res:
+        assert good and raised, res
+        if rank != world - 1:
+            assert flagged and poisoned, res
+
+
+def _train_worker(rank, world, port, p2p, launch, steps, q):
     """p2p: False = exchange through torch.distributed; "kernel" = mailboxes, the exchange a kernel of its own between the
     BatchNorm launches (CRIS_SYNCBN_FUSED=0); True = mailboxes, the exchange inside the BatchNorm launches (the default)"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -92,7 +156,7 @@ def _train_worker(rank, world, port, p2p, launch, q):
                            launch=launch)
         assert (tr.comm.p2p is not None) == bool(p2p)
         losses = []
-        for step in range(4):
+        for step in range(steps):
             img, word, mask = (t.to(dev) for t in synth.make_batch(4, 64, 9, rank, step))
             loss, _ = tr.train_step(img, word, mask)
             losses.append(float(loss))
@@ -109,30 +173,28 @@ def _train_worker(rank, world, port, p2p, launch, q):
         dist.destroy_process_group()
 
 
-# (two processes time-slice the one GPU of the test box - every exchange costs a scheduling quantum, 50 - 80 s per variant: the
-# command-list variant runs with the long parity runs, `-m "gpu or gpu_long"`)
-@pytest.mark.parametrize("launch", [pytest.param("eager", marks=gpu), pytest.param("cmdlist", marks=pytest.mark.gpu_long)])
-def test_trainer_with_peer_mailboxes_equals_torch_distributed_exchange(launch):
-    """two ranks, four optimizer steps: the SyncBN exchange through torch.distributed, through the mailbox kernel, and INSIDE the
-    BatchNorm launches (the default) - bit-identical losses, and bit-identical parameters and running statistics at the end (two
-    ranks: a + b in either order; the pack / unpack arithmetic is the same code in all three forms)"""
-    ctx = mp.get_context("spawn")
+# (the processes time-slice the one GPU of the test box - every exchange costs a scheduling quantum, 50 - 80 s per two-rank variant:
+# the command-list variant and the eight-rank run go with the long parity runs, `-m "gpu or gpu_long"`)
+@pytest.mark.parametrize("launch,world,steps", [pytest.param("eager", 2, 6, marks=gpu), pytest.param("eager", 4, 6, marks=gpu),
+                                                pytest.param("eager", 8, 6, marks=pytest.mark.gpu_long),
+                                                pytest.param("cmdlist", 2, 4, marks=pytest.mark.gpu_long)])
+def test_trainer_with_peer_mailboxes_equals_torch_distributed_exchange(launch, world, steps):
+    """`world` ranks, `steps` optimizer steps (six: every mailbox word is reused three times per parity): the SyncBN exchange through
+    torch.distributed, through the mailbox kernel, and INSIDE the BatchNorm launches (the default).  Two ranks: bit-identical
+    losses, parameters and running statistics in all three forms (a + b in either order).  More ranks: the mailbox forms add in
+    rank order on every rank and must agree with each other bit for bit and across ranks; torch.distributed's (gloo) reduction
+    order is its own, so against it the losses agree to fp32 rounding of a sum of `world` terms."""
     out = {}
-    modes = (False, "kernel", True) if launch == "eager" else (False, True)        # (the stand-alone exchange kernel: eager only)
+    modes = (False, "kernel", True) if (launch == "eager" and world == 2) else (False, True)   # (the stand-alone exchange kernel: eager, two ranks)
     for p2p in modes:
-        q = ctx.Queue()
-        port = _free_port()
-        procs = [ctx.Process(target=_train_worker, args=(r, 2, port, p2p, launch, q)) for r in range(2)]
-        for p in procs:
-            p.start()
-        res = sorted(q.get(timeout=600) for _ in procs)
-        for p in procs:
-            p.join(120)
-            assert p.exitcode == 0
-        out[p2p] = res
+        out[p2p] = _spawn(_train_worker, world, p2p, launch, steps, timeout=1200)
     for mode in modes[1:]:
         for (_, la, _, ha), (_, lb, err, hb) in zip(out[False], out[mode]):
             assert err == 0
-            assert la == lb, (mode, la, lb)
-            assert ha == hb, "parameters / running statistics differ from the torch.distributed run (%r)" % (mode,)
-    assert out[True][0][3] == out[True][1][3]                  # and both ranks hold the same model
+            if world == 2:
+                assert la == lb, (mode, la, lb)
+                assert ha == hb, "parameters / running statistics differ from the torch.distributed run (%r)" % (mode,)
+            else:
+                assert all(abs(a - b) <= 2e-4 * max(1.0, abs(a)) for a, b in zip(la, lb)), (mode, la, lb)
+    hashes = {r[3] for r in out[True]}
+    assert len(hashes) == 1, "the ranks hold different models"    # rank-order sums: every rank computed the same statistics
