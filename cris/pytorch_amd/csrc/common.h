@@ -41,6 +41,26 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// Cache policy of the large activation / gradient stores (GEMM epilogues, BatchNorm / LayerNorm apply kernels).  0 (default): plain
+// stores - dirty lines stay in the XCD's L2 until the end-of-kernel write-back.  1: agent-scope write-through (sc1): the data
+// leaves the L2 while the kernel still runs.  2: non-temporal.  A/B switch (-DCRIS_STORE_POLICY=..., tools/build_variants.sh);
+// results are identical.
+#ifndef CRIS_STORE_POLICY
+#define CRIS_STORE_POLICY 0
+#endif
+#define CRIS_STORE_AUX (CRIS_STORE_POLICY == 1 ? 16 : CRIS_STORE_POLICY == 2 ? 2 : 0)      // buffer-store aux: bit 4 = sc1, bit 1 = nt
+__device__ __forceinline__ void cris_st16(void* p, const uint4& v) {
+#if CRIS_STORE_POLICY == 1
+    const u32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(w) : "memory");
+#elif CRIS_STORE_POLICY == 2
+    const u32x4 w = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(w) : "memory");
+#else
+    *reinterpret_cast<uint4*>(p) = v;
+#endif
+}
+
 // Counter-based dropout decision (restated in oracle/dropout_hash.py - keep the two in sync).
 __device__ __forceinline__ uint32_t cris_fmix32(uint32_t v) {
     v ^= v >> 16; v *= 0x85EBCA6Bu; v ^= v >> 13; v *= 0xC2B2AE35u; v ^= v >> 16;

@@ -25,6 +25,22 @@
 #endif
 #define SKINNY_MAX_M 144      // M <= this and a 1x1 geometry -> skinny kernel (no LDS staging, K split over the waves)
 
+// Phase stamps of the 4-wave tile (tools/probe/gemm4_probe.hip compiles this file with -DG4_PROBE; the library never does): the
+// shader clock (s_memtime) of wave 0 of every block at  0 entry, 1 prologue DMAs issued, 2 first K-step landed (first barrier
+// passed), 3 K loop done, 4 epilogue stores issued, 5 stores acknowledged - kept in SGPRs and written once at the end, so the
+// counted vmcnt waits of the loop see no extra memory operation.  G4_ABL: pieces compiled out (results wrong by construction):
+// 1 no MFMAs, 2 no DMA refills inside the loop, 4 no epilogue.
+#ifdef G4_PROBE
+__device__ unsigned long long* g4_stamps;       // [blocks][8]
+#define G4_T(k) t_stamp[k] = __builtin_amdgcn_s_memtime()
+#ifndef G4_ABL
+#define G4_ABL 0
+#endif
+#else
+#define G4_T(k)
+#define G4_ABL 0
+#endif
+
 
 // ------------------------------------------------------------------------------------------------
 // forward / dgrad (4-wave tiles; lds_off and gemm_epilogue live in gemm_common.h)
@@ -61,6 +77,10 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
     constexpr int A_BYTES = BM * 128;
     constexpr int STAGE_BYTES = (BM + BN) * 128;
 
+#ifdef G4_PROBE
+    unsigned long long t_stamp[6];
+#endif
+    G4_T(0);
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = (t >> 6) & 3;             // role inside the group of four (DMA rows, wave tile)
@@ -215,12 +235,16 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
         // prologue: STAGES-1 K-steps in flight (steps beyond nk read zeros: keeps the vmcnt arithmetic uniform)
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s) issue_stage(s);
+        G4_T(1);
         int buf = 0;
         const int nkg = (nk + KS - 1) / KS;              // K-steps per group (a group's steps beyond nk read zeros)
         for (int kt = 0; kt < nkg; ++kt) {
             CRIS_VMCNT((STAGES - 2) * (NA + NB));       // this wave's share of K-step kt has landed ...
             __builtin_amdgcn_s_barrier();               // ... and everyone's; everyone is also done reading step kt-1
-            {
+#ifdef G4_PROBE
+            if (kt == 0) G4_T(2);
+#endif
+            if (!(G4_ABL & 2) || kt == 0) {
                 int nb = buf + STAGES - 1;
                 if (nb >= STAGES) nb -= STAGES;
                 issue_stage(nb);                        // refill the buffer of step kt-1 with step kt+STAGES-1
@@ -244,7 +268,9 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j) {
-                        if constexpr (MT == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        if (G4_ABL & 1) {               // (probe ablation: keep the fragment reads alive without the MFMA)
+                            acc[i][j][0] += (float)af[i][0] + (float)bfr[j][0];
+                        } else if constexpr (MT == 32) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                         else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
                     }
             }
@@ -253,6 +279,7 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
         }
     }
     CRIS_VMCNT(0);                                  // drain the (out-of-range) tail DMAs before the block retires
+    G4_T(3);
 
     if constexpr (KS > 1) {
         // group 1's partial sums -> LDS (over the drained rings) -> group 0: acc(even K-steps) + acc(odd K-steps)
@@ -276,7 +303,24 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
 #pragma unroll
                 for (int r = 0; r < NR; ++r) acc[i][j][r] += xch[(i * FN + j) * NR + r];
     }
-    gemm_epilogue<EPI, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
+    if (!(G4_ABL & 4)) gemm_epilogue<EPI, MT, FM, FN>(p, acc, m0 + wm * WTM, n0 + wn * WTN, tile_m * WAVES_M + wm, lane);
+#ifdef G4_PROBE
+    if (G4_ABL & 4) {                               // keep the accumulators alive
+        float sink = 0.f;
+        for (int i = 0; i < FM; ++i)
+            for (int j = 0; j < FN; ++j) sink += acc[i][j][0] + acc[i][j][7];
+        if (sink == 123.456f) p.colsum[0] = sink;
+    }
+    G4_T(4);
+    CRIS_VMCNT(0);
+    G4_T(5);
+    if (t == 0 && g4_stamps) {
+        unsigned long long* d = g4_stamps + (size_t)blockIdx.x * 8;
+        for (int k = 0; k < 6; ++k) d[k] = t_stamp[k];
+        d[6] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+        d[7] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+    }
+#endif
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int STAGES, int EPI, int MT_ = 32, int KS = 1>

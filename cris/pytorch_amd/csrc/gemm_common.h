@@ -104,7 +104,7 @@ __device__ __forceinline__ void gemm_epilogue_fast32(const cris_conv_gemm_params
                 acc[i][j][e] = x;
                 s1 += x;
                 const bf16_t xb = f2bf_hw(x);
-                __builtin_amdgcn_raw_buffer_store_b16((short)xb, rsO, vo[e & 3], so, 0);
+                __builtin_amdgcn_raw_buffer_store_b16((short)xb, rsO, vo[e & 3], so, CRIS_STORE_AUX);
                 if (bnr) {                          // as bn_bwd_reduce_fast_kernel (MASK 2) on the STORED gradient
                     const float g = (yv[e] * b_sc + b_sh) > 0.f ? bf2f(xb) : 0.f;
                     b0 += g;
@@ -207,8 +207,8 @@ __device__ __forceinline__ void gemm_epilogue_fast32_gen(const cris_conv_gemm_pa
                 if (act == 3) x = fmaxf(x, 0.f);
                 acc[i][j][e] = x;
                 s1 += x;
-                if constexpr (OUT_F32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, vo[e & 3], so, 0);
-                else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf_hw(x), rsO, vo[e & 3], so, 0);
+                if constexpr (OUT_F32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, vo[e & 3], so, CRIS_STORE_AUX);
+                else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf_hw(x), rsO, vo[e & 3], so, CRIS_STORE_AUX);
             }
             if (has_T) {
 #pragma unroll
@@ -341,8 +341,8 @@ __device__ __forceinline__ void gemm_epilogue(const cris_conv_gemm_params& p, AC
                 vals[ig][r] = x;
                 if (has_out) {
                     const unsigned off = valid ? ((unsigned)m * (unsigned)p.ldc + (unsigned)(p.c_coff + col)) * out_es : CRIS_OOB;
-                    if (out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, 0);
-                    else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(x), rsO, off, 0, 0);
+                    if (out_f32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x), rsO, off, 0, CRIS_STORE_AUX);
+                    else __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(x), rsO, off, 0, CRIS_STORE_AUX);
                 }
             }
             if (!LEAN && p.outT && cvalid && rowb < p.M) {

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const cris_bn_apply_param
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] *= 0.25f;
         }
-        *reinterpret_cast<uint4*>(p.z + (size_t)mo * p.ldz + p.z_coff + c0) = pack8(o);
+        cris_st16(p.z + (size_t)mo * p.ldz + p.z_coff + c0, pack8(o));
     }
 }
 
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void bn_apply_fast_kernel(const cris_bn_apply_
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = fmaxf(o[j], 0.f);
             }
-            *reinterpret_cast<uint4*>(zb + (size_t)mu * p.ldz) = pack8(o);
+            cris_st16(zb + (size_t)mu * p.ldz, pack8(o));
         }
     }
 }
@@ -988,14 +988,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_par
         load8f(p.scale + c0, sc);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = sc[j] * (g[j] - s0[j] * invc - xh[j] * s1[j] * invc);
-        *reinterpret_cast<uint4*>(p.dy + (size_t)m * p.lddy + p.dy_coff + c0) = pack8(o);
+        cris_st16(p.dy + (size_t)m * p.lddy + p.dy_coff + c0, pack8(o));
         if (p.y2 && p.dy2) {
             float s3[8], sc2[8];
             load8f(p.sums + 3 * p.C + c0, s3);
             load8f(p.scale2 + c0, sc2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = sc2[j] * (g[j] - s0[j] * invc - xh2[j] * s3[j] * invc);
-            *reinterpret_cast<uint4*>(p.dy2 + (size_t)m * p.lddy2 + p.dy2_coff + c0) = pack8(o);
+            cris_st16(p.dy2 + (size_t)m * p.lddy2 + p.dy2_coff + c0, pack8(o));
         }
         if (p.dident) {
             bf16_t* dst = p.dident + (size_t)m * p.lddi + p.di_coff + c0;
@@ -1005,7 +1005,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_par
 #pragma unroll
                 for (int j = 0; j < 8; ++j) g[j] += old[j];
             }
-            *reinterpret_cast<uint4*>(dst) = pack8(g);
+            cris_st16(dst, pack8(g));
         }
     }
 }
@@ -1073,7 +1073,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const cris_bn_bw
                 const float xh = (y[j] - mean[j]) * inv[j];
                 o[j] = sc[j] * (g[j] - a0[j] - xh * s1[j] * invc);
             }
-            *reinterpret_cast<uint4*>(dyb + (size_t)mu * p.lddy) = pack8(o);
+            cris_st16(dyb + (size_t)mu * p.lddy, pack8(o));
             if (want2) {
                 float y2[8];
                 unpack8(ry2[u], y2);
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const cris_bn_bw
                     const float xh2 = (y2[j] - mean2[j]) * inv2[j];
                     o[j] = sc2[j] * (g[j] - a0[j] - xh2 * s3[j] * invc);
                 }
-                *reinterpret_cast<uint4*>(dy2b + (size_t)mu * p.lddy2) = pack8(o);
+                cris_st16(dy2b + (size_t)mu * p.lddy2, pack8(o));
             }
             if (dib) {
                 if (di_acc) {
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_fast_kernel(const cris_bn_bw
 #pragma unroll
                     for (int j = 0; j < 8; ++j) g[j] += old[j];
                 }
-                *reinterpret_cast<uint4*>(dib + (size_t)mu * p.lddi) = pack8(g);
+                cris_st16(dib + (size_t)mu * p.lddi, pack8(g));
             }
         }
     }
@@ -1204,13 +1204,13 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const cris_ln_fwd_params p)
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = (v[i][j] - mean) * rstd * ga[j] + be[j];
             const size_t oo = (size_t)row * p.C + c0;
-            if (p.y) *reinterpret_cast<uint4*>(p.y + oo) = pack8(o);
+            if (p.y) cris_st16(p.y + oo, pack8(o));
             if (p.ypos) {
                 float pe[8], t[8];
                 load8f(p.pos + (size_t)(row % p.pos_rows) * p.C + c0, pe);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) t[j] = o[j] + pe[j];
-                *reinterpret_cast<uint4*>(p.ypos + oo) = pack8(t);
+                cris_st16(p.ypos + oo, pack8(t));
             }
             if (p.out_f32) {
                 float r[8];
@@ -1338,7 +1338,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const cris_ln_bwd_params p)
                 *reinterpret_cast<float4*>(d) = make_float4(o[0], o[1], o[2], o[3]);
                 *reinterpret_cast<float4*>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
             } else {
-                *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(p.dx) + xo) = pack8(o);
+                cris_st16(reinterpret_cast<bf16_t*>(p.dx) + xo, pack8(o));
             }
         }
     }

@@ -11,6 +11,11 @@ import torch  # noqa: F401  (must precede CDLL)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcris_hip.so")
+# A/B builds only (tools/build_variants.sh: the same sources compiled with extra -D switches into csrc/variants/libcris_hip_<tag>.so,
+# cross-compiled in the container so that one GPU call can compare several builds): CRIS_LIB_VARIANT=<tag> loads that file instead.
+# The product, the tests and the driver's bench never set it.
+if os.environ.get("CRIS_LIB_VARIANT"):
+    LIB_PATH = os.path.join(_HERE, "csrc", "variants", "libcris_hip_%s.so" % os.environ["CRIS_LIB_VARIANT"])
 
 P, I, L, F, U = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_uint32
 
