@@ -179,7 +179,19 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
     if ddp_one_rank and world == 1 and not dist.is_initialized():
         import tempfile
         pg_dir = tempfile.mkdtemp(prefix="cris_bench_pg_")
-        dist.init_process_group("nccl", init_method="file://" + os.path.join(pg_dir, "pg"), rank=0, world_size=1, device_id=dev)
+        # (RCCL prints its version banner to fd 1 when the communicator comes up: point fd 1 at stderr meanwhile - the bench's
+        # stdout carries ONE JSON line)
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", init_method="file://" + os.path.join(pg_dir, "pg"), rank=0, world_size=1, device_id=dev)
+            t_ = torch.zeros(1, device=dev)
+            dist.all_reduce(t_)                        # the communicator is created lazily: force it while fd 1 is redirected
+            torch.cuda.synchronize()
+        finally:
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
         own_pg = True
     from torch import nn
     from cris.pytorch_amd import arch, synth

@@ -29,7 +29,7 @@
 // shader clock (s_memtime) of wave 0 of every block at  0 entry, 1 prologue DMAs issued, 2 first K-step landed (first barrier
 // passed), 3 K loop done, 4 epilogue stores issued, 5 stores acknowledged - kept in SGPRs and written once at the end, so the
 // counted vmcnt waits of the loop see no extra memory operation.  G4_ABL: pieces compiled out (results wrong by construction):
-// 1 no MFMAs, 2 no DMA refills inside the loop, 4 no epilogue.
+// 1 no MFMAs, 2 no DMA refills inside the loop, 4 no epilogue, 8 nothing at all (the launch floor of this grid / LDS size).
 #ifdef G4_PROBE
 __device__ unsigned long long* g4_stamps;       // [blocks][8]
 #define G4_T(k) t_stamp[k] = __builtin_amdgcn_s_memtime()
@@ -81,6 +81,10 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
     unsigned long long t_stamp[6];
 #endif
     G4_T(0);
+    if (G4_ABL & 8) {                               // (probe: the launch alone - same grid, LDS size and kernel arguments, no work)
+        if (p.M < 0) p.colsum[0] = 0.f;
+        return;
+    }
     const int t = threadIdx.x;
     const int lane = t & 63;
     const int wave = (t >> 6) & 3;             // role inside the group of four (DMA rows, wave tile)
@@ -98,10 +102,10 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
     const int tiles_m = (p.M + BM - 1) / BM;
     int tile_m, tile_n;
     if ((long)p.N * p.K > (1L << 20)) {
-        tile_n = bid / tiles_m;
+        tile_n = cris_fast_div(bid, tiles_m, __builtin_amdgcn_rcpf((float)tiles_m));
         tile_m = bid - tile_n * tiles_m;
     } else {
-        tile_m = bid / tiles_n;
+        tile_m = cris_fast_div(bid, tiles_n, __builtin_amdgcn_rcpf((float)tiles_n));
         tile_n = bid - tile_m * tiles_n;
     }
     const int m0 = tile_m * BM;
@@ -111,20 +115,26 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
     const int rsub = lane >> 3;
     const int kc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);       // == (lane&7) ^ ((row>>1)&7) for every j
     const int OHW = p.OH * p.OW;
+    // 1x1 / stride 1 / no padding (every linear layer, conv1 / conv3 / downsample of a Bottleneck: most launches of the step): the
+    // pixel of output row m IS m - no (image, row, column) decomposition; otherwise two reciprocal divisions per DMA row
+    const bool lin = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0 && p.OH == p.H && p.OW == p.W;     // wave-uniform
+    const float r_ohw = __builtin_amdgcn_rcpf((float)OHW), r_ow = __builtin_amdgcn_rcpf((float)p.OW);
     int a_pix[NA], a_ih[NA], a_iw[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int m = m0 + (wave + 4 * i) * 8 + rsub;
-        if (m < p.M) {
-            const int b = m / OHW;
+        if (m >= p.M) {
+            a_pix[i] = 0; a_ih[i] = -(1 << 28); a_iw[i] = 0;       // never in range -> zeros
+        } else if (lin) {
+            a_pix[i] = m; a_ih[i] = 0; a_iw[i] = 0;                // (pixel index = a_pix + ih * W + iw with ih = iw = 0)
+        } else {
+            const int b = cris_fast_div(m, OHW, r_ohw);
             const int r = m - b * OHW;
-            const int oh = r / p.OW;
+            const int oh = cris_fast_div(r, p.OW, r_ow);
             const int ow = r - oh * p.OW;
             a_pix[i] = b * p.H * p.W;
             a_ih[i] = oh * p.stride - p.pad;
             a_iw[i] = ow * p.stride - p.pad;
-        } else {
-            a_pix[i] = 0; a_ih[i] = -(1 << 28); a_iw[i] = 0;       // never in range -> zeros
         }
     }
     unsigned b_off[NB];                        // byte offset of this lane's weight rows (rows >= N are out of range -> 0)
@@ -134,12 +144,16 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
         const_cast<bf16_t*>(p.A), 0, (int)((size_t)p.Bn * p.H * p.W * p.lda * 2), CRIS_BUF_FLAGS);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(p.Wt), 0, (int)((size_t)p.N * p.ldb * 2), CRIS_BUF_FLAGS);
-    // running (tap, c) of this lane's chunk
+    // running (tap, c) of this lane's chunk (the general K-step issue only: C not a multiple of 64)
+    const bool fastk = (p.C & 63) == 0;             // wave-uniform
     int kcur = kc * 8 + grp * BK;
-    int c_cur = kcur % p.C;
-    int tap = kcur / p.C;
-    int kh = tap / p.KW;
-    int kw = tap - kh * p.KW;
+    int c_cur = 0, kh = 0, kw = 0;
+    if (!fastk) {
+        const int tap = kcur / p.C;
+        c_cur = kcur - tap * p.C;
+        kh = tap / p.KW;
+        kw = tap - kh * p.KW;
+    }
 
     // general K-step issue: the 8-channel chunk of a lane may sit in any tap (C not a multiple of 64)
     auto issue_gen = [&](int buf) {
@@ -226,11 +240,136 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
     const int fr = lane & (MT - 1), fh = lane / MT;             // fragment row, 16-B chunk inside a k-slice
     constexpr int KSL = MT == 32 ? 4 : 2;                       // k-slices per 64-wide step (16 or 32 deep)
     constexpr int CPS = 8 / KSL;                                // 16-B chunks per slice
-    const bool fastk = (p.C & 63) == 0;             // wave-uniform
     auto issue_stage = [&](int b_) {
         if (fastk) issue_fast(b_);
         else issue_gen(b_);
     };
+#ifdef G4_AFUSE
+    // PROBE ONLY (round 5, the go / no-go of "BatchNorm apply + ReLU on the consumer's operand path"): the A operand goes
+    // global -> registers -> relu(y * scale[c] + shift[c]) -> ds_write instead of LDS-DMA; zero padding is a select AFTER the
+    // transform.  A loads run three K-steps ahead into two register sets, B stays on the DMA ring two steps ahead; the LDS image
+    // is the DMA's (lane-linear, swizzle on the source side), so the fragment reads and the epilogue are unchanged.  The
+    // coefficients (p.bnr_scale / p.bnr_shift, [C] floats each) sit in LDS behind the ring.  Needs C % 64 == 0, STAGES == 3.
+    if constexpr (STAGES == 3 && KS == 1 && MT == 32) {
+        float* coef = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);          // [2][C]
+        for (int c = t; c < p.C; c += 256) { coef[c] = p.bnr_scale[c]; coef[p.C + c] = p.bnr_shift[c]; }
+        int fa_kh = 0, fa_kw = 0, fa_c = 0, fa_k = 0, fb_k = 0;
+        bool fa_newtap = true;
+        u32x4 areg[2][NA];
+        int achan[2];
+        unsigned avalid[2];                            // bit i: row i of the set is inside the image and the step inside K
+        auto load_A = [&](auto SETC) {
+            constexpr int SET = decltype(SETC)::value;
+            if (fa_newtap) {
+                fa_newtap = false;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int ih = a_ih[i] + fa_kh, iw = a_iw[i] + fa_kw;
+                    const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                    a_base[i] = ok ? ((unsigned)(a_pix[i] + ih * p.W + iw) * (unsigned)p.lda + (unsigned)p.a_coff) * 2u + lane_k : CRIS_OOB;
+                }
+            }
+            const bool kin = fa_k < p.K;
+            const unsigned ca = (unsigned)fa_c * 2u;
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const bool ok = kin && a_base[i] < CRIS_OOB;
+                m |= ok ? (1u << i) : 0u;
+                areg[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_base[i] + ca : CRIS_OOB, 0, 0);
+            }
+            avalid[SET] = m;
+            achan[SET] = fa_c + kc * 8;
+            fa_k += BK;
+            fa_c += BK;
+            if (fa_c >= p.C) {
+                fa_c = 0;
+                fa_newtap = true;
+                if (++fa_kw == p.KW) { fa_kw = 0; ++fa_kh; }
+            }
+        };
+        auto store_A = [&](auto SETC, int buf) {
+            constexpr int SET = decltype(SETC)::value;
+            unsigned char* sa = ring + buf * STAGE_BYTES + wave * 1024 + lane * 16;
+            const int c0 = achan[SET];
+            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(coef + c0), sc1 = *reinterpret_cast<const f32x4*>(coef + c0 + 4);
+            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(coef + p.C + c0), sh1 = *reinterpret_cast<const f32x4*>(coef + p.C + c0 + 4);
+            const float sc[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
+            const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const u32x4 v = areg[SET][i];
+                const float f[8] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1]), bflo(v[2]), bfhi(v[2]), bflo(v[3]), bfhi(v[3])};
+                const bool ok = (avalid[SET] >> i) & 1u;
+                u32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = ok ? fmaxf(f[2 * e] * sc[2 * e] + sh[2 * e], 0.f) : 0.f;
+                    const float x1 = ok ? fmaxf(f[2 * e + 1] * sc[2 * e + 1] + sh[2 * e + 1], 0.f) : 0.f;
+                    o[e] = (uint32_t)f2bf_hw(x0) | ((uint32_t)f2bf_hw(x1) << 16);
+                }
+                *reinterpret_cast<u32x4*>(sa + i * 4096) = o;
+            }
+        };
+        auto issue_B = [&](int buf) {
+            unsigned char* sb = ring + buf * STAGE_BYTES + wave * 1024 + A_BYTES;
+            const unsigned kvm = fb_k < p.K ? 0u : CRIS_OOB;
+            const unsigned kb = (unsigned)fb_k * 2u + lane_k;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const unsigned off = (b_off[i] + kb) | kvm;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + i * 4096), 16, off, 0, 0, 0);
+            }
+            fb_k += BK;
+        };
+        using S0 = std::integral_constant<int, 0>;
+        using S1 = std::integral_constant<int, 1>;
+        // prologue: A(0) through set 1 into buffer 0, then A(1) -> set 0, B(0), A(2) -> set 1, B(1)
+        __syncthreads();                               // coefficients visible
+        load_A(S1{});
+        CRIS_VMCNT(0);
+        store_A(S1{}, 0);
+        load_A(S0{});
+        issue_B(0);
+        load_A(S1{});
+        issue_B(1);
+        G4_T(1);
+        int buf = 0;
+        auto step = [&](auto SETC, int kt) {
+            CRIS_VMCNT(NA + NB);                        // A(kt+1) in registers, B(kt) in LDS
+            __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): this wave's ds_writes of A(kt) are done
+            __builtin_amdgcn_s_barrier();
+#ifdef G4_PROBE
+            if (kt == 0) G4_T(2);
+#endif
+            int b1 = buf + 1; if (b1 >= STAGES) b1 -= STAGES;
+            int b2 = buf + 2; if (b2 >= STAGES) b2 -= STAGES;
+            store_A(SETC, b1);                          // A(kt+1) -> its buffer (last read two steps ago)
+            load_A(SETC);                               // A(kt+3) -> the set just drained
+            issue_B(b2);                                // B(kt+2) -> the buffer of step kt-1
+            const unsigned char* sa = ring + buf * STAGE_BYTES;
+            const unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < KSL; ++ks) {
+                bf16x8 af[FM], bfr[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * WTM + i * MT + fr, ks * CPS + fh));
+#pragma unroll
+                for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * WTN + j * MT + fr, ks * CPS + fh));
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (++buf == STAGES) buf = 0;
+        };
+        for (int kt = 0; kt < nk; kt += 2) {
+            step(S0{}, kt);
+            if (kt + 1 < nk) step(S1{}, kt + 1);
+        }
+    } else
+#endif
     {
         // prologue: STAGES-1 K-steps in flight (steps beyond nk read zeros: keeps the vmcnt arithmetic uniform)
 #pragma unroll
@@ -772,8 +911,13 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     if (conv_gemm_check(p) != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     // <= 72 KB per block: two blocks (8 waves) share a CU's 160 KB LDS and hide each other's barriers / epilogues
-    constexpr int LDS_128x64 = ST_128x64 * (128 + 64) * 128, LDS_64x128 = ST_64x128 * (64 + 128) * 128;
-    constexpr int LDS_128x128 = ST_128x128 * (128 + 128) * 128, LDS_64x64 = ST_64x64 * (64 + 64) * 128;
+#ifdef G4_AFUSE
+    constexpr int XL = 16384;                       // (probe build: the BatchNorm coefficient table behind the ring)
+#else
+    constexpr int XL = 0;
+#endif
+    constexpr int LDS_128x64 = ST_128x64 * (128 + 64) * 128 + XL, LDS_64x128 = ST_64x128 * (64 + 128) * 128 + XL;
+    constexpr int LDS_128x128 = ST_128x128 * (128 + 128) * 128, LDS_64x64 = ST_64x64 * (64 + 64) * 128 + XL;
     typedef void (*kern_t)(const cris_conv_gemm_params);
     // [variant][epilogue: 0 general, 1 lean, 2 lean + bias / ReLU]
     static const kern_t k_128x64[4] = {conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 0>, conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 1>,

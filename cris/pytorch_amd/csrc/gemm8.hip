@@ -90,10 +90,10 @@ __device__ __forceinline__ void conv_gemm8_tile(const cris_conv_gemm_params& p, 
 #endif
     const bool m_fastest = G8_ORDER == 2 || (G8_ORDER == 0 && (S1 || (!S4 && (long)p.N * p.K > (1L << 20))));
     if (m_fastest) {
-        tile_n = bid / tiles_m;
+        tile_n = cris_fast_div(bid, tiles_m, __builtin_amdgcn_rcpf((float)tiles_m));
         tile_m = bid - tile_n * tiles_m;
     } else {
-        tile_m = bid / tiles_n;
+        tile_m = cris_fast_div(bid, tiles_n, __builtin_amdgcn_rcpf((float)tiles_n));
         tile_n = bid - tile_m * tiles_n;
     }
     const int m0 = tile_m * BM;
@@ -111,9 +111,9 @@ __device__ __forceinline__ void conv_gemm8_tile(const cris_conv_gemm_params& p, 
     for (int i = 0; i < PA * 2; ++i) {
         const int m = m0 + (i & 1) * WTM + (i >> 1) * 64 + wave * 8 + rsub;          // i = a*2 + g
         if (m < p.M) {
-            const int b = m / OHW;
+            const int b = cris_fast_div(m, OHW, __builtin_amdgcn_rcpf((float)OHW));
             const int r = m - b * OHW;
-            const int oh = r / p.OW;
+            const int oh = cris_fast_div(r, p.OW, __builtin_amdgcn_rcpf((float)p.OW));
             const int ow = r - oh * p.OW;
             a_pix[i] = b * p.H * p.W;
             a_ih[i] = oh * p.stride - p.pad;

@@ -240,10 +240,18 @@ def test_fused_adam_applies_the_accumulated_gradient(zero_style):
     pa, ma, oa = _accumulate_params(optim.Adam, zero_style)
     pb, _, _ = _accumulate_params(torch.optim.Adam, zero_style)
     assert oa._usable() and ma._grad_views_active and oa._tab is not None        # the fused path ran
-    worst = max(float((pa[k] - pb[k]).abs().max()) for k in pa)
-    # three steps of lr 1e-4: a step taken with only the last micro-batch's gradient moves many weights by up to 2e-4 the other
-    # way (Adam's first steps are sign-like); equal gradients leave the optimizers' fp32 rounding (measured ~1e-6 ... 2e-5)
-    assert worst < 1e-4, worst
+    # after the step the arena views hold exactly what `.grad` holds (the mechanism) ...
+    for p_, v in zip(ma._step_params, ma._step_grads):
+        assert p_.grad is v or torch.equal(p_.grad, v)
+    # ... and the parameters took torch.optim.Adam's steps (the outcome).  Adam's first steps are sign-like (+-lr whatever the
+    # gradient's size), so a step taken with only the LAST micro-batch's gradient moves a large share of the elements the other
+    # way (by up to 2 lr per step); with equal gradients only elements whose gradient is rounding noise can differ (analytically
+    # zero gradients: their sign is decided by the optimizers' own fp32 rounding) - the worst element may differ by 3 lr, but
+    # the SHARE of elements off by more than lr / 2 stays tiny
+    diff = torch.cat([(pa[k] - pb[k]).abs().flatten() for k in pa])
+    share = float((diff > 5e-5).float().mean())
+    print("accumulation %s: worst %.2e, share of elements off by > 5e-5: %.4f" % (zero_style, float(diff.max()), share))
+    assert share < 0.02, share
 
 
 def test_fused_adam_fallback_keeps_the_operand_copies_current():

@@ -52,6 +52,25 @@ int main(int argc, char** argv) {
     hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
     hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
     p.A = (const cris_bf16*)dA; p.Wt = (const cris_bf16*)dW; p.out = dO; p.colsum = cs; p.colsq = cq;
+    // BatchNorm coefficients for the -DG4_AFUSE build (A -> relu(A * scale + shift) on the operand path); with G4_AFUSE_REF the
+    // plain kernel runs on the host-transformed operand instead: the two outputs are compared through their checksums
+    std::vector<float> hsc(C), hsh(C);
+    for (int c = 0; c < C; ++c) { hsc[c] = 0.5f + 0.001f * (c % 97); hsh[c] = 0.1f - 0.002f * (c % 53); }
+    float *dsc, *dsh;
+    hipMalloc((void**)&dsc, C * 4); hipMalloc((void**)&dsh, C * 4);
+    hipMemcpy(dsc, hsc.data(), C * 4, hipMemcpyHostToDevice); hipMemcpy(dsh, hsh.data(), C * 4, hipMemcpyHostToDevice);
+    p.bnr_scale = dsc; p.bnr_shift = dsh;
+#ifdef G4_AFUSE_REF
+    {
+        auto bf2f_host = [](unsigned short v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; };
+        for (size_t i = 0; i < na; ++i) {
+            const int c = (int)(i % C);
+            const float x = fmaf(bf2f_host(ha[i]), hsc[c], hsh[c]);
+            ha[i] = f2bf_host(x > 0.f ? x : 0.f);
+        }
+        hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
+    }
+#endif
     static const int bm[V_COUNT] = {0, 0, 0, 128, 64, 64, 128, 256, 256, 128, 128, 64}, bn[V_COUNT] = {0, 0, 0, 64, 64, 128, 128, 256, 128, 256, 128, 64};
     const int blocks = cris_cdiv(p.M, bm[variant]) * cris_cdiv(p.N, bn[variant]);
     unsigned long long* dst = nullptr;
@@ -80,6 +99,13 @@ int main(int argc, char** argv) {
     const double flop = 2.0 * p.M * N * p.K;
     printf("G4 %s abl=%d M%d N%d K%d k%d blocks %d : best %.2f us median %.2f us  (%.0f TFLOP/s at best)\n", argv[1], (int)G4_ABL, p.M, N, p.K, k, blocks,
            ts[0], ts[2], flop / ts[0] / 1e6);
+    {   // checksum of the output (the AFUSE and AFUSE_REF builds must agree)
+        std::vector<unsigned short> ho(no);
+        hipMemcpy(ho.data(), dO, no * 2, hipMemcpyDeviceToHost);
+        double sum = 0, asum = 0;
+        for (size_t i = 0; i < no; ++i) { unsigned u = (unsigned)ho[i] << 16; float f; memcpy(&f, &u, 4); sum += f; asum += f < 0 ? -f : f; }
+        printf("  output checksum: sum %.6e  abs-sum %.6e\n", sum, asum);
+    }
     // ---- phase stamps of ONE launch in the middle of a back-to-back run (its neighbours keep the chip in the steady state)
     for (int i = 0; i < 4; ++i) cris_conv_gemm_variant(&p, variant, st);
     hipMemcpyToSymbolAsync(HIP_SYMBOL(g4_stamps), &dst, sizeof(dst), 0, hipMemcpyHostToDevice, st);
