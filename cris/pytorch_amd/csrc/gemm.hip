@@ -244,132 +244,6 @@ __device__ __forceinline__ void conv_gemm_tile(const cris_conv_gemm_params& p, i
         if (fastk) issue_fast(b_);
         else issue_gen(b_);
     };
-#ifdef G4_AFUSE
-    // PROBE ONLY (round 5, the go / no-go of "BatchNorm apply + ReLU on the consumer's operand path"): the A operand goes
-    // global -> registers -> relu(y * scale[c] + shift[c]) -> ds_write instead of LDS-DMA; zero padding is a select AFTER the
-    // transform.  A loads run three K-steps ahead into two register sets, B stays on the DMA ring two steps ahead; the LDS image
-    // is the DMA's (lane-linear, swizzle on the source side), so the fragment reads and the epilogue are unchanged.  The
-    // coefficients (p.bnr_scale / p.bnr_shift, [C] floats each) sit in LDS behind the ring.  Needs C % 64 == 0, STAGES == 3.
-    if constexpr (STAGES == 3 && KS == 1 && MT == 32) {
-        float* coef = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);          // [2][C]
-        for (int c = t; c < p.C; c += 256) { coef[c] = p.bnr_scale[c]; coef[p.C + c] = p.bnr_shift[c]; }
-        int fa_kh = 0, fa_kw = 0, fa_c = 0, fa_k = 0, fb_k = 0;
-        bool fa_newtap = true;
-        u32x4 areg[2][NA];
-        int achan[2];
-        unsigned avalid[2];                            // bit i: row i of the set is inside the image and the step inside K
-        auto load_A = [&](auto SETC) {
-            constexpr int SET = decltype(SETC)::value;
-            if (fa_newtap) {
-                fa_newtap = false;
-#pragma unroll
-                for (int i = 0; i < NA; ++i) {
-                    const int ih = a_ih[i] + fa_kh, iw = a_iw[i] + fa_kw;
-                    const bool ok = (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                    a_base[i] = ok ? ((unsigned)(a_pix[i] + ih * p.W + iw) * (unsigned)p.lda + (unsigned)p.a_coff) * 2u + lane_k : CRIS_OOB;
-                }
-            }
-            const bool kin = fa_k < p.K;
-            const unsigned ca = (unsigned)fa_c * 2u;
-            unsigned m = 0;
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const bool ok = kin && a_base[i] < CRIS_OOB;
-                m |= ok ? (1u << i) : 0u;
-                areg[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_base[i] + ca : CRIS_OOB, 0, 0);
-            }
-            avalid[SET] = m;
-            achan[SET] = fa_c + kc * 8;
-            fa_k += BK;
-            fa_c += BK;
-            if (fa_c >= p.C) {
-                fa_c = 0;
-                fa_newtap = true;
-                if (++fa_kw == p.KW) { fa_kw = 0; ++fa_kh; }
-            }
-        };
-        auto store_A = [&](auto SETC, int buf) {
-            constexpr int SET = decltype(SETC)::value;
-            unsigned char* sa = ring + buf * STAGE_BYTES + wave * 1024 + lane * 16;
-            const int c0 = achan[SET];
-            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(coef + c0), sc1 = *reinterpret_cast<const f32x4*>(coef + c0 + 4);
-            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(coef + p.C + c0), sh1 = *reinterpret_cast<const f32x4*>(coef + p.C + c0 + 4);
-            const float sc[8] = {sc0[0], sc0[1], sc0[2], sc0[3], sc1[0], sc1[1], sc1[2], sc1[3]};
-            const float sh[8] = {sh0[0], sh0[1], sh0[2], sh0[3], sh1[0], sh1[1], sh1[2], sh1[3]};
-#pragma unroll
-            for (int i = 0; i < NA; ++i) {
-                const u32x4 v = areg[SET][i];
-                const float f[8] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1]), bflo(v[2]), bfhi(v[2]), bflo(v[3]), bfhi(v[3])};
-                const bool ok = (avalid[SET] >> i) & 1u;
-                u32x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = ok ? fmaxf(f[2 * e] * sc[2 * e] + sh[2 * e], 0.f) : 0.f;
-                    const float x1 = ok ? fmaxf(f[2 * e + 1] * sc[2 * e + 1] + sh[2 * e + 1], 0.f) : 0.f;
-                    o[e] = (uint32_t)f2bf_hw(x0) | ((uint32_t)f2bf_hw(x1) << 16);
-                }
-                *reinterpret_cast<u32x4*>(sa + i * 4096) = o;
-            }
-        };
-        auto issue_B = [&](int buf) {
-            unsigned char* sb = ring + buf * STAGE_BYTES + wave * 1024 + A_BYTES;
-            const unsigned kvm = fb_k < p.K ? 0u : CRIS_OOB;
-            const unsigned kb = (unsigned)fb_k * 2u + lane_k;
-#pragma unroll
-            for (int i = 0; i < NB; ++i) {
-                const unsigned off = (b_off[i] + kb) | kvm;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(sb + i * 4096), 16, off, 0, 0, 0);
-            }
-            fb_k += BK;
-        };
-        using S0 = std::integral_constant<int, 0>;
-        using S1 = std::integral_constant<int, 1>;
-        // prologue: A(0) through set 1 into buffer 0, then A(1) -> set 0, B(0), A(2) -> set 1, B(1)
-        __syncthreads();                               // coefficients visible
-        load_A(S1{});
-        CRIS_VMCNT(0);
-        store_A(S1{}, 0);
-        load_A(S0{});
-        issue_B(0);
-        load_A(S1{});
-        issue_B(1);
-        G4_T(1);
-        int buf = 0;
-        auto step = [&](auto SETC, int kt) {
-            CRIS_VMCNT(NA + NB);                        // A(kt+1) in registers, B(kt) in LDS
-            __builtin_amdgcn_s_waitcnt(0xC07F);         // lgkmcnt(0): this wave's ds_writes of A(kt) are done
-            __builtin_amdgcn_s_barrier();
-#ifdef G4_PROBE
-            if (kt == 0) G4_T(2);
-#endif
-            int b1 = buf + 1; if (b1 >= STAGES) b1 -= STAGES;
-            int b2 = buf + 2; if (b2 >= STAGES) b2 -= STAGES;
-            store_A(SETC, b1);                          // A(kt+1) -> its buffer (last read two steps ago)
-            load_A(SETC);                               // A(kt+3) -> the set just drained
-            issue_B(b2);                                // B(kt+2) -> the buffer of step kt-1
-            const unsigned char* sa = ring + buf * STAGE_BYTES;
-            const unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-            for (int ks = 0; ks < KSL; ++ks) {
-                bf16x8 af[FM], bfr[FN];
-#pragma unroll
-                for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sa + lds_off(wm * WTM + i * MT + fr, ks * CPS + fh));
-#pragma unroll
-                for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + lds_off(wn * WTN + j * MT + fr, ks * CPS + fh));
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            if (++buf == STAGES) buf = 0;
-        };
-        for (int kt = 0; kt < nk; kt += 2) {
-            step(S0{}, kt);
-            if (kt + 1 < nk) step(S1{}, kt + 1);
-        }
-    } else
-#endif
     {
         // prologue: STAGES-1 K-steps in flight (steps beyond nk read zeros: keeps the vmcnt arithmetic uniform)
 #pragma unroll
@@ -911,13 +785,8 @@ extern "C" int cris_conv_gemm_variant(const cris_conv_gemm_params* pp, int varia
     if (conv_gemm_check(p) != 0) return -1;
     hipStream_t s = (hipStream_t)stream;
     // <= 72 KB per block: two blocks (8 waves) share a CU's 160 KB LDS and hide each other's barriers / epilogues
-#ifdef G4_AFUSE
-    constexpr int XL = 16384;                       // (probe build: the BatchNorm coefficient table behind the ring)
-#else
-    constexpr int XL = 0;
-#endif
-    constexpr int LDS_128x64 = ST_128x64 * (128 + 64) * 128 + XL, LDS_64x128 = ST_64x128 * (64 + 128) * 128 + XL;
-    constexpr int LDS_128x128 = ST_128x128 * (128 + 128) * 128, LDS_64x64 = ST_64x64 * (64 + 64) * 128 + XL;
+    constexpr int LDS_128x64 = ST_128x64 * (128 + 64) * 128, LDS_64x128 = ST_64x128 * (64 + 128) * 128;
+    constexpr int LDS_128x128 = ST_128x128 * (128 + 128) * 128, LDS_64x64 = ST_64x64 * (64 + 64) * 128;
     typedef void (*kern_t)(const cris_conv_gemm_params);
     // [variant][epilogue: 0 general, 1 lean, 2 lean + bias / ReLU]
     static const kern_t k_128x64[4] = {conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 0>, conv_gemm_kernel<128, 64, 4, 1, ST_128x64, 1>,

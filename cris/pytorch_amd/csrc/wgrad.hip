@@ -26,11 +26,6 @@
 #define WG_MS 32          // pixel rows per pipeline step
 #define WG_STAGES 3       // ring depth: 3 x 2 x 32 x 256 B = 48 KB LDS -> 3 blocks per CU
 #define WG_LDS (WG_STAGES * 2 * WG_MS * 256)
-// "deep" form for the memory-bound problems (a long pixel range per block, small N x K: stem, layer1 / layer2 1x1 convolutions):
-// the same tile with a five-deep ring - four steps (64 KB) in flight per block, two blocks (160 KB) per CU - instead of two steps
-// of three blocks: those launches moved their operands at 1.1 - 2.3 TB/s (profiles/r04_gemm_shapes.tsv) with ~40 KB in flight per CU
-#define WG_DEEP_STAGES 5
-#define WG_DEEP_LDS (WG_DEEP_STAGES * 2 * WG_MS * 256)
 #ifndef WG_RUN
 #define WG_RUN 8          // consecutive tiles handed to one XCD (they share the dY tile)
 #endif
@@ -566,14 +561,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const cris_wgrad_params
     wgrad_tile<WG_MS, WG_STAGES>(p, bx, by, bz, smem);
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_deep_kernel(const cris_wgrad_params p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tk = (p.K + WG_T - 1) / WG_T, tn = (p.N + WG_T - 1) / WG_T;
-    const int lb = wg_logical_block(blockIdx.x, gridDim.x);
-    const int bx = lb % tk, by = (lb / tk) % tn, bz = lb / (tk * tn);
-    wgrad_tile<WG_MS, WG_DEEP_STAGES>(p, bx, by, bz, smem);
-}
-
 __global__ __launch_bounds__(256) void conv_wgrad_group_kernel(const cris_wgrad_group g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lb = wg_logical_block(blockIdx.x, gridDim.x);
@@ -737,7 +724,6 @@ static int wgrad_blocks(const cris_wgrad_params& p, int tile) { return cris_cdiv
 
 static int wgrad_lds_ready() {
     static const int rc = (int)hipFuncSetAttribute((const void*)conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) |
-                          (int)hipFuncSetAttribute((const void*)conv_wgrad_deep_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_DEEP_LDS) |
                           (int)hipFuncSetAttribute((const void*)conv_wgrad_group_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, WG_LDS) |
                           (int)hipFuncSetAttribute((const void*)conv_wgrad8_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, WG8_LDS) |
                           (int)hipFuncSetAttribute((const void*)conv_wgrad8_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, WG8_LDS) |
@@ -774,14 +760,7 @@ extern "C" int cris_conv_wgrad(const cris_wgrad_params* pp, void* stream) {
         if (w8_mi) hipLaunchKernelGGL(conv_wgrad8_kernel<true>, dim3(wgrad_blocks(p, WG8_T)), dim3(512), WG8_LDS, (hipStream_t)stream, p);
         else hipLaunchKernelGGL(conv_wgrad8_kernel<false>, dim3(wgrad_blocks(p, WG8_T)), dim3(512), WG8_LDS, (hipStream_t)stream, p);
     }
-    else {
-        // CRIS_WGRAD_DEEP=1: split problems whose blocks walk at least CRIS_WGRAD_DEEP_MIN_STEPS ring steps take the five-deep ring
-        static const int deep = cris_env_int("CRIS_WGRAD_DEEP", 0), deep_min = cris_env_int("CRIS_WGRAD_DEEP_MIN_STEPS", 8);
-        const int steps = wg_rows_per_split(p.M, p.splits) / WG_MS;
-        if (deep && p.splits > 1 && steps >= deep_min)
-            hipLaunchKernelGGL(conv_wgrad_deep_kernel, dim3(wgrad_blocks(p, WG_T)), dim3(256), WG_DEEP_LDS, (hipStream_t)stream, p);
-        else hipLaunchKernelGGL(conv_wgrad_kernel, dim3(wgrad_blocks(p, WG_T)), dim3(256), WG_LDS, (hipStream_t)stream, p);
-    }
+    else hipLaunchKernelGGL(conv_wgrad_kernel, dim3(wgrad_blocks(p, WG_T)), dim3(256), WG_LDS, (hipStream_t)stream, p);
     CRIS_LAUNCH_CHECK();
     return (p.splits > 1 && !p.defer_reduce) ? cris_wgrad_reduce(&p, stream) : 0;
 }

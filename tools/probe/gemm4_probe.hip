@@ -52,8 +52,9 @@ int main(int argc, char** argv) {
     hipMemcpy(dA, ha.data(), na * 2, hipMemcpyHostToDevice);
     hipMemcpy(dW, hw.data(), nw * 2, hipMemcpyHostToDevice);
     p.A = (const cris_bf16*)dA; p.Wt = (const cris_bf16*)dW; p.out = dO; p.colsum = cs; p.colsq = cq;
-    // BatchNorm coefficients for the -DG4_AFUSE build (A -> relu(A * scale + shift) on the operand path); with G4_AFUSE_REF the
-    // plain kernel runs on the host-transformed operand instead: the two outputs are compared through their checksums
+    // BatchNorm coefficients for the -DG4_AFUSE build of call r05b (A -> relu(A * scale + shift) on the operand path: the kernel
+    // block that build compiled is archived as profiles/r05/call_b_afuse_probe_block.hip.txt - measured, rejected and removed from
+    // csrc/gemm.hip); with G4_AFUSE_REF the plain kernel runs on the host-transformed operand: the reference of that comparison
     std::vector<float> hsc(C), hsh(C);
     for (int c = 0; c < C; ++c) { hsc[c] = 0.5f + 0.001f * (c % 97); hsh[c] = 0.1f - 0.002f * (c % 53); }
     float *dsc, *dsh;
