@@ -492,7 +492,7 @@ def main():
             # both are averages over that set; traffic_ratio compares the two per STEP (a grouped launch is one launch of
             # several problems, so launch counts of different builds are not comparable, bytes per step are)
             fam = timer.tile_family()
-            for pmf in ("r04_hbm_traffic.json", "r03_hbm_traffic.json"):
+            for pmf in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json"):
                 try:
                     pj = json.load(open(os.path.join(ROOT, "profiles", pmf)))
                     pm = pj["kernels"]["conv_gemm (all tile kernels)"]
@@ -508,7 +508,7 @@ def main():
                 except Exception:               # noqa: BLE001
                     pass
             # where the parity measurements of this path are (a pointer, not a measurement of this run)
-            out["config"]["parity"] = "profiles/parity_r04.md (teacher-forced runs of configs[1] / [3] / [4], per-stage bf16 error budget), tests/test_parity_long_gpu.py"
+            out["config"]["parity"] = "profiles/parity_r05.md (float64-teacher teacher-forced runs of configs[1] / [3] / [4] inside pytest -m gpu), profiles/parity_r04.md (per-stage bf16 error budget), tests/test_parity_long_gpu.py"
             out["roofline"]["timing"] = "HIP events around each launch, %d-step eager pass after the timed region" % timer_steps
             out["kernels"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                   "launches_per_step": v["launches"] / timer_steps} for k, v in summ.items()}

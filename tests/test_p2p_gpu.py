@@ -187,7 +187,8 @@ def test_trainer_with_peer_mailboxes_equals_torch_distributed_exchange(launch, w
     model turns one ulp of a BatchNorm statistic into up to 3e-3 of loss (bf16 rounding thresholds; the 1-rank-against-2-ranks
     comparison of tests/test_dist_gpu.py sees the same), so against it the losses are compared with that test's bound."""
     out = {}
-    modes = (False, "kernel", True) if launch == "eager" else (False, True)        # (the stand-alone exchange kernel: eager only)
+    # (the stand-alone exchange kernel: eager, two ranks - its rank-order sums at world 4 / 8 are checked bit for bit by the primitive test)
+    modes = (False, "kernel", True) if (launch == "eager" and world == 2) else (False, True)
     for p2p in modes:
         out[p2p] = _spawn(_train_worker, world, p2p, launch, steps, timeout=1200)
     for mode in modes[1:]:
