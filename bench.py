@@ -179,19 +179,7 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
     if ddp_one_rank and world == 1 and not dist.is_initialized():
         import tempfile
         pg_dir = tempfile.mkdtemp(prefix="cris_bench_pg_")
-        # (RCCL prints its version banner to fd 1 when the communicator comes up: point fd 1 at stderr meanwhile - the bench's
-        # stdout carries ONE JSON line)
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", init_method="file://" + os.path.join(pg_dir, "pg"), rank=0, world_size=1, device_id=dev)
-            t_ = torch.zeros(1, device=dev)
-            dist.all_reduce(t_)                        # the communicator is created lazily: force it while fd 1 is redirected
-            torch.cuda.synchronize()
-        finally:
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
+        dist.init_process_group("nccl", init_method="file://" + os.path.join(pg_dir, "pg"), rank=0, world_size=1, device_id=dev)
         own_pg = True
     from torch import nn
     from cris.pytorch_amd import arch, synth
@@ -321,6 +309,24 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12)}}))
     if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
+
+
+def module_path_subprocess(args, optimizer_name):
+    """`bench.py --path module --ddp-one-rank` in a process of its own; returns the record the in-process runs return"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--path", "module", "--ddp-one-rank", "--optimizer", optimizer_name, "--steps",
+           str(args.module_steps), "--warmup", "5", "--batch", str(args.batch), "--size", str(args.size), "--spec", args.spec]
+    if args.word_len is not None:
+        cmd += ["--word-len", str(args.word_len)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
+    d = json.loads(lines[0])
+    return {"ms_per_step": d["ms_per_step"], "samples_per_s": d["value"], "steps": d["steps"], "optimizer": d["config"]["optimizer"],
+            "ddp_one_rank": d["config"].get("ddp_one_rank"), "replay": d["config"].get("replay"), "final_loss": d["config"].get("final_loss"),
+            "own_process": True}
 
 
 def main():
@@ -530,12 +536,15 @@ def main():
             for key, opt_name, ddp1 in (("unchanged_loop", "torch", False), ("cris_optimizer", "cris", False),
                                         ("unchanged_loop_ddp_one_rank", "torch", True), ("cris_optimizer_ddp_one_rank", "cris", True)):
                 try:
-                    mp[key] = module_path(args, rank, world, dev, optimizer_name=opt_name, steps=args.module_steps, warmup=5,
-                                          ddp_one_rank=ddp1, emit=False)
+                    if ddp1:
+                        # a process of its own: RCCL prints its version banner on stdout when a communicator comes up, and this
+                        # process's stdout carries ONE JSON line
+                        mp[key] = module_path_subprocess(args, opt_name)
+                    else:
+                        mp[key] = module_path(args, rank, world, dev, optimizer_name=opt_name, steps=args.module_steps, warmup=5,
+                                              ddp_one_rank=False, emit=False)
                 except Exception as ex:          # noqa: BLE001 - the native line must not depend on these runs
                     mp[key] = {"error": repr(ex)[:300]}
-                    if dist.is_initialized():
-                        dist.destroy_process_group()
                 torch.cuda.empty_cache()
             mp["ms_per_step"] = mp["unchanged_loop"].get("ms_per_step")
             mp["ms_per_step_cris_optimizer"] = mp["cris_optimizer"].get("ms_per_step")

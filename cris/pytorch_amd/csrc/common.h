@@ -76,6 +76,42 @@ __device__ __forceinline__ bool cris_keep(uint32_t key, uint32_t idx, uint32_t t
     return cris_keep_h(idx * CRIS_DROP_MUL + key, thresh);
 }
 
+// n / d for 0 <= n < 2^24, 0 < d (rd = 1.0f / d): a float multiply and one correction step instead of the ~40-instruction integer
+// division sequence.  The prologue of a tile kernel ran four to eight of those per lane (pixel -> (image, row, column) of every
+// DMA row, tile index, tap of the first K-step): 1.26 us of the 5.1 us a 64x64 block of the M 5408 / N 512 / K 512 problem lives
+// (phase stamps, profiles/r05_gemm4_phases.md).  Every pixel / tile count of the supported problems is far below 2^24.
+__device__ __forceinline__ int cris_fast_div(int n, int d, float rd) {
+    int q = (int)((float)n * rd);
+    const int r = n - q * d;
+    q += r >= d ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return q;
+}
+
+// (b, y, x, cv) of a flat index over [b][Y][X][CV]: three reciprocal divisions when the index fits 24 bits (every feature map of
+// the networks up to batch 32), 64-bit divisions otherwise.  The pooling / resampling kernels spent five 64-bit divisions by
+// run-time divisors per 16-byte vector (~100 instructions each) - more than their loads and arithmetic together.
+struct cris_idx4 { int cv, x, y, b; };
+__device__ __forceinline__ cris_idx4 cris_split4(long idx, int CV, int X, int Y, bool small) {
+    cris_idx4 r;
+    if (small) {
+        const int i = (int)idx;
+        const int m = cris_fast_div(i, CV, __builtin_amdgcn_rcpf((float)CV));
+        r.cv = i - m * CV;
+        const int q = cris_fast_div(m, X, __builtin_amdgcn_rcpf((float)X));
+        r.x = m - q * X;
+        r.b = cris_fast_div(q, Y, __builtin_amdgcn_rcpf((float)Y));
+        r.y = q - r.b * Y;
+    } else {
+        r.cv = (int)(idx % CV);
+        const long m = idx / CV;
+        r.x = (int)(m % X);
+        r.y = (int)((m / X) % Y);
+        r.b = (int)(m / ((long)X * Y));
+    }
+    return r;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -19,12 +19,11 @@ __device__ __forceinline__ void st8bf(bf16_t* p, const float* f) { *reinterpret_
 // ------------------------------------------------------------------------------------------------
 __global__ void stem_im2col_kernel(const float* __restrict__ img, int Bn, int H, int W, int OH, int OW, bf16_t* __restrict__ out) {
     const long total = (long)Bn * OH * OW * 4;
+    const bool small = total < (1L << 24);
     GRID_STRIDE(idx, total) {
-        const int kc = (int)(idx & 3);
+        const cris_idx4 q = cris_split4(idx, 4, OW, OH, small);
+        const int kc = q.cv, ow = q.x, oh = q.y, b = q.b;
         const long m = idx >> 2;
-        const int ow = (int)(m % OW);
-        const int oh = (int)((m / OW) % OH);
-        const int b = (int)(m / ((long)OW * OH));
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -58,12 +57,11 @@ __global__ void avgpool2_fwd_kernel(const bf16_t* __restrict__ x, int ldx, int x
                                     bf16_t* __restrict__ y, int ldy, int ycoff) {
     const int CV = C >> 3, OH = H >> 1, OW = W >> 1;
     const long total = (long)Bn * OH * OW * CV;
+    const bool small = total < (1L << 24);
     GRID_STRIDE(idx, total) {
-        const int cv = (int)(idx % CV);
-        const long mo = idx / CV;
-        const int ow = (int)(mo % OW);
-        const int oh = (int)((mo / OW) % OH);
-        const int b = (int)(mo / ((long)OW * OH));
+        const cris_idx4 q = cris_split4(idx, CV, OW, OH, small);
+        const int cv = q.cv, ow = q.x, oh = q.y, b = q.b;
+        const long mo = ((long)b * OH + oh) * OW + ow;
         float o[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t[8];
 #pragma unroll
         for (int dy = 0; dy < 2; ++dy)
@@ -93,12 +91,11 @@ __global__ void avgpool2_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, int
                                     bf16_t* __restrict__ dx, int lddx, int dxcoff, int accum) {
     const int CV = C >> 3, OH = H >> 1, OW = W >> 1;
     const long total = (long)Bn * H * W * CV;
+    const bool small = total < (1L << 24);
     GRID_STRIDE(idx, total) {
-        const int cv = (int)(idx % CV);
-        const long m = idx / CV;
-        const int w = (int)(m % W);
-        const int h = (int)((m / W) % H);
-        const int b = (int)(m / ((long)W * H));
+        const cris_idx4 q = cris_split4(idx, CV, W, H, small);
+        const int cv = q.cv, w = q.x, h = q.y, b = q.b;
+        const long m = ((long)b * H + h) * W + w;
         float g[8];
         ld8bf(dy + (((size_t)b * OH + (h >> 1)) * OW + (w >> 1)) * lddy + dycoff + cv * 8, g);
         bf16_t* d = dx + (size_t)m * lddx + dxcoff + cv * 8;
@@ -135,12 +132,11 @@ __global__ void upsample2_fwd_kernel(const bf16_t* __restrict__ x, int ldx, int 
                                      bf16_t* __restrict__ y, int ldy, int ycoff) {
     const int CV = C >> 3, OH = H * 2, OW = W * 2;
     const long total = (long)Bn * OH * OW * CV;
+    const bool small = total < (1L << 24);
     GRID_STRIDE(idx, total) {
-        const int cv = (int)(idx % CV);
-        const long mo = idx / CV;
-        const int ow = (int)(mo % OW);
-        const int oh = (int)((mo / OW) % OH);
-        const int b = (int)(mo / ((long)OW * OH));
+        const cris_idx4 q = cris_split4(idx, CV, OW, OH, small);
+        const int cv = q.cv, ow = q.x, oh = q.y, b = q.b;
+        const long mo = ((long)b * OH + oh) * OW + ow;
         int y0, y1, x0, x1;
         float ly, lx;
         up2_src(oh, H, y0, y1, ly);
@@ -173,12 +169,11 @@ __global__ void upsample2_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, in
     // gather form: input pixel (iy,ix) collects from output rows/cols 2i-2 .. 2i+2 whose source taps hit it
     const int CV = C >> 3, OH = H * 2, OW = W * 2;
     const long total = (long)Bn * H * W * CV;
+    const bool small = total < (1L << 24);
     GRID_STRIDE(idx, total) {
-        const int cv = (int)(idx % CV);
-        const long m = idx / CV;
-        const int ix = (int)(m % W);
-        const int iy = (int)((m / W) % H);
-        const int b = (int)(m / ((long)W * H));
+        const cris_idx4 q = cris_split4(idx, CV, W, H, small);
+        const int cv = q.cv, ix = q.x, iy = q.y, b = q.b;
+        const long m = ((long)b * H + iy) * W + ix;
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const bf16_t* base = dy + (size_t)b * OH * OW * lddy + dycoff + cv * 8;
         for (int oy = max(0, 2 * iy - 2); oy <= min(OH - 1, 2 * iy + 2); ++oy) {
@@ -603,7 +598,9 @@ extern "C" int cris_dynconv_fwd(const cris_bf16* x, int Bn, int H, int W, int C,
                                 void* stream) {
     const int LP = C / 8;
     CRIS_CHECK_ARG(x && wb && pred && !(C & 7) && LP >= 1 && LP <= 64 && (LP & (LP - 1)) == 0, "C/8 must be a power of two <= 64");
-    const int ppb = 64;
+    // pixels per block: every block first gathers its 72 weights per lane (strided reads), so few pixels per block is mostly prologue
+    static const int ppb_env = cris_env_int("CRIS_DYNCONV_PPB", 128);     // (call r05e: 64 -> 128: -0.03 ms per step; 256: level)
+    const int ppb = ppb_env;
     dim3 grid(cris_cdiv(H * W, ppb), Bn);
     hipLaunchKernelGGL(dynconv_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, H, W, C, wb, ldwb, pred, ppb);
     CRIS_LAUNCH_CHECK();
@@ -640,6 +637,11 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const bf16_t* __restri
         float gx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const float g0 = dp[pix];
         if (cl == 0) dbias += g0;
+        // Both sums use the SAME nine shifted values g = dpred[ph-kh+1, pw-kw+1] (0 outside the image): the weight gradient is
+        // taken at the INPUT pixel - dw[tap] += x[ph,pw] * g - so x is read once per pixel instead of once per tap (round 5: the
+        // nine clamped reads per pixel were 9 x 44 MB through the L1 / L2, 52 us at 104 x 104; the terms summed are the same).
+        float xq[8];
+        ld8bf(x + ((size_t)b * HW + pix) * C + cl * 8, xq);
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
@@ -649,13 +651,10 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const bf16_t* __restri
                 const float okg = ((unsigned)oh < (unsigned)H && (unsigned)ow < (unsigned)W) ? 1.f : 0.f;
                 const float g = okg * dp[min(max(oh, 0), H - 1) * W + min(max(ow, 0), W - 1)];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) gx[j] += g * w[kh * 3 + kw][j];
-                const int ih = ph + kh - 1, iw = pw + kw - 1;
-                const float okx = ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) ? g0 : 0.f;
-                float v[8];
-                ld8bf(x + (((size_t)b * H + min(max(ih, 0), H - 1)) * W + min(max(iw, 0), W - 1)) * C + cl * 8, v);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) dw[kh * 3 + kw][j] += okx * v[j];
+                for (int j = 0; j < 8; ++j) {
+                    gx[j] += g * w[kh * 3 + kw][j];
+                    dw[kh * 3 + kw][j] += g * xq[j];
+                }
             }
         st8bf(dx + ((size_t)b * HW + pix) * C + cl * 8, gx);
     }

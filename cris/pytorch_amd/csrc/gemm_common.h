@@ -21,18 +21,6 @@ __device__ __forceinline__ int cris_xcd_logical_block(int bid, int total) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
-// n / d for 0 <= n < 2^24, 0 < d (rd = 1.0f / d): a float multiply and one correction step instead of the ~40-instruction integer
-// division sequence.  The prologue of a tile kernel ran four to eight of those per lane (pixel -> (image, row, column) of every
-// DMA row, tile index, tap of the first K-step): 1.26 us of the 5.1 us a 64x64 block of the M 5408 / N 512 / K 512 problem lives
-// (phase stamps, profiles/r05_gemm4_phases.md).  Every pixel / tile count of the supported problems is far below 2^24.
-__device__ __forceinline__ int cris_fast_div(int n, int d, float rd) {
-    int q = (int)((float)n * rd);
-    const int r = n - q * d;
-    q += r >= d ? 1 : 0;
-    q -= r < 0 ? 1 : 0;
-    return q;
-}
-
 __device__ __forceinline__ int lds_off(int row, int chunk) {          // bytes; rows are 128 B (64 bf16)
     return row * 128 + (((chunk ^ (row >> 1)) & 7) << 4);
 }
