@@ -88,6 +88,11 @@ __device__ __forceinline__ int cris_fast_div(int n, int d, float rd) {
     return q;
 }
 
+// n / d through the reciprocal when n is known to fit 24 bits (`small`), the plain division otherwise
+__device__ __forceinline__ int cris_div24(int n, int d, bool small) {
+    return small ? cris_fast_div(n, d, __builtin_amdgcn_rcpf((float)d)) : n / d;
+}
+
 // (b, y, x, cv) of a flat index over [b][Y][X][CV]: three reciprocal divisions when the index fits 24 bits (every feature map of
 // the networks up to batch 32), 64-bit divisions otherwise.  The pooling / resampling kernels spent five 64-bit divisions by
 // run-time divisors per 16-byte vector (~100 instructions each) - more than their loads and arithmetic together.

@@ -429,9 +429,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const cris_bn_apply_param
     const int CV = p.C >> 3;
     const int OH = p.pool ? p.H / 2 : p.H, OW = p.pool ? p.W / 2 : p.W;
     const long total = (long)p.Bn * OH * OW * CV;
+    const bool small = total < (1L << 24);           // (reciprocal index arithmetic: common.h cris_div24)
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(idx % CV);
-        const int mo = (int)(idx / CV);
+        const int mo = small ? cris_div24((int)idx, CV, true) : (int)(idx / CV);
+        const int cv = (int)(idx - (long)mo * CV);
         const int c0 = cv * 8;
         float sc[8], sh[8], o[8];
         load8f(p.scale + c0, sc);
@@ -467,9 +468,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const cris_bn_apply_param
                 for (int j = 0; j < 8; ++j) o[j] *= mu[j];
             }
         } else {
-            const int b = mo / (OH * OW);
+            const int b = cris_div24(mo, OH * OW, small);
             const int r = mo - b * OH * OW;
-            const int oh = r / OW, ow = r - oh * OW;
+            const int oh = cris_div24(r, OW, small), ow = r - oh * OW;
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = 0.f;
 #pragma unroll
@@ -618,10 +619,11 @@ __device__ __forceinline__ void bn_bwd_point(const cris_bn_bwd_params& p, int m,
     const int HW = p.H * p.W;
     int mo = m;
     float gscale = 1.f;
+    const bool small = (long)p.Bn * HW < (1L << 24);       // (pixel indices fit 24 bits: reciprocal divisions, common.h)
     if (p.pool) {
-        const int b = m / HW;
+        const int b = cris_div24(m, HW, small);
         const int r = m - b * HW;
-        const int h = r / p.W, w = r - h * p.W;
+        const int h = cris_div24(r, p.W, small), w = r - h * p.W;
         mo = (b * (p.H / 2) + (h >> 1)) * (p.W / 2) + (w >> 1);
         gscale = 0.25f;
     }
@@ -645,7 +647,7 @@ __device__ __forceinline__ void bn_bwd_point(const cris_bn_bwd_params& p, int m,
         for (int j = 0; j < 8; ++j) pos[j] = (y[j] * sc[j] + sh[j]) > 0.f;
     }
     if (p.mul) {
-        const int b = m / HW;
+        const int b = cris_div24(m, HW, small);
         float mu[8];
         load8f(p.mul + (size_t)b * p.C + c0, mu);
 #pragma unroll
@@ -736,6 +738,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_b
     const int r0 = rb * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     const int HW = p.H * p.W, W2 = p.W >> 1, HW2 = (p.H >> 1) * W2;
+    const bool small_px = M < (1 << 24);
     const float gscale = POOL ? 0.25f : 1.f;
     {
         const int cvb = chunk * chv;
@@ -773,9 +776,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_fast_kernel(const cris_bn_b
                     const int mc = min(mu, r1 - 1);
                     int mo = mc;
                     if (POOL) {
-                        const int b = mc / HW;
+                        const int b = cris_div24(mc, HW, small_px);
                         const int r = mc - b * HW;
-                        const int h = r / p.W, w = r - h * p.W;
+                        const int h = cris_div24(r, p.W, small_px), w = r - h * p.W;
                         mo = b * HW2 + (h >> 1) * W2 + (w >> 1);
                     }
                     ry[u] = *reinterpret_cast<const uint4*>(yb + (size_t)mc * p.ldy);
@@ -975,10 +978,11 @@ extern "C" int cris_bn_bwd_reduce_sync(const cris_bn_bwd_params* pp, float* loca
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const cris_bn_bwd_params p) {
     const int CV = p.C >> 3;
     const long total = (long)p.Bn * p.H * p.W * CV;
+    const bool small = total < (1L << 24);
     const float invc = 1.0f / p.count;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(idx % CV);
-        const int m = (int)(idx / CV);
+        const int m = small ? cris_div24((int)idx, CV, true) : (int)(idx / CV);
+        const int cv = (int)(idx - (long)m * CV);
         const int c0 = cv * 8;
         float g[8], xh[8], xh2[8];
         bn_bwd_point(p, m, c0, g, xh, xh2);
