@@ -89,8 +89,10 @@ __device__ __forceinline__ int cris_fast_div(int n, int d, float rd) {
 }
 
 // n / d through the reciprocal when n is known to fit 24 bits (`small`), the plain division otherwise
+// (cris_fast_div is exact while the QUOTIENT stays below 2^22 - tests/test_fast_div_model.py; below 2^24 only a divisor of 3 can
+// exceed that: divisors 1 and 2 have exact reciprocals)
 __device__ __forceinline__ int cris_div24(int n, int d, bool small) {
-    return small ? cris_fast_div(n, d, __builtin_amdgcn_rcpf((float)d)) : n / d;
+    return (small && d != 3) ? cris_fast_div(n, d, __builtin_amdgcn_rcpf((float)d)) : n / d;
 }
 
 // (b, y, x, cv) of a flat index over [b][Y][X][CV]: three reciprocal divisions when the index fits 24 bits (every feature map of
@@ -101,11 +103,11 @@ __device__ __forceinline__ cris_idx4 cris_split4(long idx, int CV, int X, int Y,
     cris_idx4 r;
     if (small) {
         const int i = (int)idx;
-        const int m = cris_fast_div(i, CV, __builtin_amdgcn_rcpf((float)CV));
+        const int m = cris_div24(i, CV, true);
         r.cv = i - m * CV;
-        const int q = cris_fast_div(m, X, __builtin_amdgcn_rcpf((float)X));
+        const int q = cris_div24(m, X, true);
         r.x = m - q * X;
-        r.b = cris_fast_div(q, Y, __builtin_amdgcn_rcpf((float)Y));
+        r.b = cris_div24(q, Y, true);
         r.y = q - r.b * Y;
     } else {
         r.cv = (int)(idx % CV);

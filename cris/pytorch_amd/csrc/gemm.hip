@@ -765,6 +765,8 @@ static int conv_gemm_check(const cris_conv_gemm_params& p) {
     CRIS_CHECK_ARG((p.ldb & 7) == 0 && (p.K & 7) == 0 && p.ldb >= p.K, "W ld / K must be multiples of 8");
     CRIS_CHECK_ARG(p.K == p.KH * p.KW * p.C, "K != KH*KW*C");
     CRIS_CHECK_ARG(p.M == p.Bn * p.OH * p.OW, "M != Bn*OH*OW");
+    CRIS_CHECK_ARG(p.M < (1 << 24) && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64) < (1L << 22),
+                   "more than 2^24 output rows / 2^22 tiles (the reciprocal index arithmetic of the prologue is exact below that)");
     CRIS_CHECK_ARG(p.out || p.outT || p.colsum, "no output");
     CRIS_CHECK_ARG(!p.bnr_y || (epilogue_kind(p) == 3 && p.colsum && p.colsq && p.bnr_mean && p.bnr_invstd && p.bnr_scale && p.bnr_shift &&
                                 (p.bnr_ldy & 7) == 0 && (size_t)p.M * p.bnr_ldy * 2 < (1UL << 31)),
