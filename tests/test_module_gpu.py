@@ -350,6 +350,34 @@ def test_fused_adam_under_distributed_data_parallel_like_train_py():
     assert max(float((pa[k] - pb[k]).abs().max()) for k in pa) < 2e-3
 
 
+def test_module_notices_a_replaced_middle_parameter():
+    """the per-step fast key looked at the first and the last parameter only - replacing a MIDDLE parameter after
+    the first forward (weight surgery, a re-initialised head) kept the engine training the old tensor through its raw pointer.
+    Now any parameter / module registration anywhere bumps an epoch the key contains, and the key sums every data_ptr: both a
+    newly assigned nn.Parameter and a re-pointed `.data` rebuild the engine on the next forward."""
+    dev = torch.device("cuda:0")
+    model, _ = build_segmenter(NS(**TINY))
+    clip, head = arch.specs_by_name("tiny")
+    model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+    model = model.to(dev).train()
+    def fwd():
+        model._steps = 0                       # (the dropout seed follows the step count: the same masks for every comparison)
+        return model(*_batch(0, dev))[2]
+    l0 = fwd()
+    name = "neck.f2_cat.0.weight"
+    holder = model.neck.f2_cat[0]
+    old = holder.weight
+    assert model._engine.P[name].data_ptr() == old.data_ptr()
+    holder.weight = torch.nn.Parameter(torch.zeros_like(old))          # (1) a new Parameter object in the middle of the tree
+    l1 = fwd()
+    assert model._engine.P[name].data_ptr() == holder.weight.data_ptr() != old.data_ptr()
+    assert float(l1) != float(l0)                                        # the zeroed layer is what ran
+    holder.weight.data = old.data.clone()                                # (2) `.data` re-pointed: no registration, new storage
+    l2 = fwd()
+    assert model._engine.P[name].data_ptr() == holder.weight.data_ptr()
+    assert float(l2) == float(l0)                                        # the original values again: the original loss, bit for bit
+
+
 def test_optional_fused_adam_skips_the_step_on_found_inf():
     """GradScaler's contract for `_step_supports_amp_scaling` optimizers: found_inf != 0 -> nothing changes, the step count
     does not advance; the gradients are divided by grad_scale inside the update"""
