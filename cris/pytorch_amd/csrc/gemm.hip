@@ -612,7 +612,9 @@ static int pick_variant(const cris_conv_gemm_params& p) {
     static const int g8 = cris_env_int("CRIS_GEMM8", 1);
     static const int g8_min = cris_env_int("CRIS_GEMM8_MIN_TILES", 150);
     static const int g8_min_k = cris_env_int("CRIS_GEMM8_MIN_K", 256);
-    static const int g8_t128_lo = cris_env_int("CRIS_GEMM8_T128_LO", 100), g8_t128_hi = cris_env_int("CRIS_GEMM8_T128_HI", 200);
+    // (upper bound 200 -> 216 in round 5: takes in the M 5408 / N 514 / K 4608 CoordConv layer, 43 x 5 tiles - 37.4 against 47.3 us
+    // standalone, 12.012 / 12.003 against 12.061 / 12.026 ms per step, call r05j)
+    static const int g8_t128_lo = cris_env_int("CRIS_GEMM8_T128_LO", 100), g8_t128_hi = cris_env_int("CRIS_GEMM8_T128_HI", 216);
     // (lean epilogues only: the general epilogue on a 64x32 .. 128x64 wave tile spills and runs 1.3 - 1.6x longer than on the
     // 4-wave tiles - 25.8 against 15.8 us for the decoder's M 5408 / N 512 / K 512 projections, in-step kernel trace of call r03f)
     if (g8 && epilogue_kind(p) != 0 && (p.C & 63) == 0 && p.N >= 128) {
@@ -653,7 +655,9 @@ static int pick_variant(const cris_conv_gemm_params& p) {
             // (<= 256) against 12.17 without - twice the waves do not pay for the two-deep rings and the combine; stays off,
             // available by name ("64x64k2")
             static const int ks2 = cris_env_int("CRIS_GEMM_KS2", 0), ks2_max = cris_env_int("CRIS_GEMM_KS2_MAX_BLOCKS", 512);
-            if (ks2 && p.K >= 256 && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64) <= ks2_max) return V_64x64_K2;
+            static const int ks2_min_k = cris_env_int("CRIS_GEMM_KS2_MIN_K", 256);
+            // (the K-split tile has no BatchNorm-backward epilogue: EPI 3 problems keep the plain 64x64 tile)
+            if (ks2 && p.K >= ks2_min_k && epilogue_kind(p) != 3 && (long)cris_cdiv(p.M, 64) * cris_cdiv(p.N, 64) <= ks2_max) return V_64x64_K2;
             return V_64x64;
         }
         return V_64x128;
