@@ -83,3 +83,27 @@ def test_eight_ranks_on_one_gpu_launch_protocol():
     assert d["n_gpus"] == 8 and d["config"]["global_batch"] == 8 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["final_loss"] == d["config"]["final_loss"]          # not NaN
     assert d["config"]["syncbn_peer_timeout"] in (False, None)
+
+
+def test_one_rank_ddp_module_run_is_parsed_from_a_noisy_stdout(monkeypatch):
+    """bench.module_path_subprocess: the one-rank DistributedDataParallel timings of the bench line run in processes of their own
+    because RCCL prints a banner on stdout; the record is the first JSON line of that stdout, whatever surrounds it"""
+    sys.path.insert(0, ROOT)
+    import bench
+    from types import SimpleNamespace as NS
+    line = json.dumps({"ms_per_step": 21.5, "value": 372.0, "steps": 20,
+                       "config": {"optimizer": "cris.pytorch_amd.optim.Adam (fused update: True)", "ddp_one_rank": True, "replay": "graph",
+                                  "final_loss": 0.5}})
+    seen = {}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"], seen["env"] = cmd, kw.get("env")
+        return NS(returncode=0, stdout="RCCL version : 2.26.6\nHIP version  : 7.0\n" + line + "\nLibrccl path : /x/librccl.so\n", stderr="")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    args = NS(module_steps=20, batch=8, size=416, spec="r50", word_len=None)
+    rec = bench.module_path_subprocess(args, "cris")
+    assert rec["ms_per_step"] == 21.5 and rec["ddp_one_rank"] is True and rec["own_process"] is True
+    assert "--ddp-one-rank" in seen["cmd"] and seen["cmd"][seen["cmd"].index("--optimizer") + 1] == "cris"
+    assert not any(k in seen["env"] for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"))
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **kw: NS(returncode=1, stdout="", stderr="boom"))
+    assert "error" in bench.module_path_subprocess(args, "torch")

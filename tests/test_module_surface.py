@@ -59,3 +59,48 @@ def test_no_cpu_fallback():
     model = CRIS(NS(**TINY))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         model(torch.zeros(1, 3, 64, 64), torch.zeros(1, 9, dtype=torch.long))
+
+
+def test_optional_optimizer_binds_only_when_the_fused_update_can_run():
+    """cris.pytorch_amd.optim.Adam (round-4 advisor findings): the module is switched to gradient-view mode - where its replayed
+    forward carries no re-pack of the bf16 operand copies - ONLY by an optimizer that holds every gradient parameter of the module with
+    hyperparameters the fused update supports; anything else leaves the module alone and is plain torch.optim.Adam."""
+    from cris.pytorch_amd import optim
+    model, groups = build_segmenter(NS(**TINY))
+    opt = optim.Adam(groups, lr=1e-4, weight_decay=0.0)               # the reference's two groups, one weight decay: eligible
+    assert opt._cris is model and model._grad_views and opt._hyper_ok()
+    assert not opt._usable()                                          # (no engine yet: nothing ran on a GPU)
+
+    model2, groups2 = build_segmenter(NS(**TINY))
+    groups2[1]["weight_decay"] = 0.01                                 # per-group weight decay: torch's Adam does that, the fused one not
+    opt2 = optim.Adam(groups2, lr=1e-4, weight_decay=0.0)
+    assert opt2._cris is model2 and not model2._grad_views and not opt2._hyper_ok()
+
+    model3, groups3 = build_segmenter(NS(**TINY))
+    opt3 = optim.Adam([groups3[1]], lr=1e-4)                          # a SUBSET of the parameters (fine-tuning the head only)
+    assert opt3._cris is None and not model3._grad_views
+
+    other = nn.Linear(4, 4)
+    opt4 = optim.Adam(other.parameters(), lr=1e-3)                    # parameters of something else: plain torch.optim.Adam
+    other(torch.ones(2, 4)).sum().backward()
+    before = other.weight.detach().clone()
+    opt4.step()
+    assert opt4._cris is None and not torch.equal(before, other.weight)
+
+    model5, groups5 = build_segmenter(NS(**TINY))
+    opt5 = optim.Adam(groups5, lr=1e-4, amsgrad=True)
+    assert not model5._grad_views                                     # amsgrad: not the fused update's arithmetic
+
+
+def test_fast_key_sees_a_replaced_middle_parameter():
+    """the per-step key of the module -> engine binding (round-4 advisor finding: it looked at the first and last parameter only)"""
+    model, _ = build_segmenter(NS(**TINY))
+    k0 = model._fast_key("cuda:0")
+    assert model._fast_key("cuda:0") == k0                            # stable while nothing changes
+    holder = model.neck.f2_cat[0]
+    old = holder.weight
+    holder.weight = nn.Parameter(old.detach().clone())                # a new Parameter object in the middle of the tree
+    k1 = model._fast_key("cuda:0")
+    assert k1 != k0
+    holder.weight.data = old.detach().clone()                         # `.data` re-pointed: no registration, new storage
+    assert model._fast_key("cuda:0") != k1
