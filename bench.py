@@ -32,6 +32,31 @@ HBM_PEAK = 8000.0                  # GB/s spec
 DUAL_CEILING = {("r50", 416): 4305.0, ("r101", 416): 3678.0, ("r50", 480): 3164.0}   # samples/s per GPU: per-layer max(MFMA, HBM) roofline
 
 
+_RESULT_FD = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (RCCL prints a five-line version banner when its
+    first communicator comes up, from C stdio: buffered until the process exits, i.e. AFTER anything Python printed).  So a rank
+    process keeps the real stdout for the result only: fd 1 is pointed at stderr for everything else, and emit_line() writes the line to
+    the saved descriptor.  Not done in the process that merely re-launches itself under torch.distributed.run (spawn_ranks): its
+    children inherit fd 1."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit_line(record):
+    line = (json.dumps(record) + "\n").encode()
+    if _RESULT_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def physical_cores():
     """physical cores of the host (lscpu: sockets x cores per socket; SURVEY.md 8d asks for physical, not logical, CPUs)"""
     import subprocess
@@ -156,8 +181,8 @@ def launch_check(rank, world, args):
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "max_rank_seen": int(t[1]), "seconds": float(t[0])}))
+        emit_line({"launch_check": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "max_rank_seen": int(t[1]), "seconds": float(t[0])})
     if world > 1:
         dist.destroy_process_group()
 
@@ -294,7 +319,7 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
         phase_ms = {ph: {"host_ms": host[k] / cnt, "device_ms": devt[k] / cnt} for k, ph in enumerate(phases)}
     if rank == 0:
         sps = world * args.batch * steps / dt
-        print(json.dumps({
+        emit_line({
             "phase_times": phase_ms,
             "metric": "train-step samples/sec, CRIS-R50 416x416 bs=64; loss parity vs ref", "value": sps, "unit": "samples/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1000.0 * dt / steps,
@@ -306,7 +331,7 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
                        "path": "module", "replay": os.environ.get("CRIS_MODULE_REPLAY", "graph"), "optimizer": "cris.pytorch_amd.optim.Adam (fused update: %s)" % fused if optimizer_name == "cris" else "torch.optim.Adam", "ddp_one_rank": bool(own_pg),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first,
                        "final_loss": r[0], "grad_scale": float(scaler.get_scale())},
-            "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12)}}))
+            "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12)}})
     if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
 
@@ -377,6 +402,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py: WORLD_SIZE=%d but --gpus %d (torch.distributed.run --nproc-per-node must equal --gpus)" % (world, args.gpus))
+    if args.path != "module":
+        # (the `--path module` form prints its line the plain way: as a child of the default run its stdout is a pipe the parent
+        # scans for the JSON line anyway)
+        claim_stdout()
     if args.launch_check:
         return launch_check(rank, world, args)
     ngpu = torch.cuda.device_count()
@@ -553,7 +582,7 @@ def main():
             out["module_path"] = mp
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.spec, args.batch, args.size, head.word_len, physical_cores())
-        print(json.dumps(out))
+        emit_line(out)
     if world > 1:
         dist.destroy_process_group()
 
