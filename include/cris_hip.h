@@ -76,6 +76,9 @@ typedef struct {
     int bnr_ldy, bnr_coff;
     int stat_ld, pad_;
 } cris_conv_gemm_params;
+/* Limits checked by every launcher: channels / leading dimensions / offsets multiples of 8, operand extents below 2 GiB (32-bit
+ * buffer offsets), and - since the prologue's index arithmetic works by reciprocal multiplication (round 5) - fewer than 2^24 output
+ * rows and 2^22 tiles (CRIS-R50 at 416x416: 346112 rows per 8 samples, i.e. up to batch 384 per launch). */
 int cris_conv_gemm(const cris_conv_gemm_params* p, void* stream);
 /* rows per BatchNorm-statistics partial written for this problem (depends on the tile variant chosen; host only) */
 int cris_conv_gemm_stat_rows(const cris_conv_gemm_params* p);
