@@ -344,7 +344,7 @@ def module_path_subprocess(args, optimizer_name):
     if args.word_len is not None:
         cmd += ["--word-len", str(args.word_len)]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)     # (a healthy run takes ~25 s)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     if r.returncode != 0 or not lines:
         return {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
