@@ -346,12 +346,12 @@ def module_path_subprocess(args, optimizer_name):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=180)     # (a healthy run takes ~25 s)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    if r.returncode != 0 or not lines:
+    if not lines:
         return {"error": "rc %d: %s" % (r.returncode, r.stderr[-300:])}
-    d = json.loads(lines[0])
+    d = json.loads(lines[0])                           # (a line that was printed is a finished measurement, whatever the teardown did)
     return {"ms_per_step": d["ms_per_step"], "samples_per_s": d["value"], "steps": d["steps"], "optimizer": d["config"]["optimizer"],
             "ddp_one_rank": d["config"].get("ddp_one_rank"), "replay": d["config"].get("replay"), "final_loss": d["config"].get("final_loss"),
-            "own_process": True}
+            "own_process": True, "exit_code": r.returncode}
 
 
 def main():
