@@ -14,7 +14,7 @@ void cris_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* cris_last_error(void) { return g_err; }
-extern "C" int cris_abi_version(void) { return 1; }
+extern "C" int cris_abi_version(void) { return CRIS_ABI_VERSION; }
 
 extern "C" int cris_sizeof(const char* name) {
 #define S(n) if (!strcmp(name, #n)) return (int)sizeof(n)

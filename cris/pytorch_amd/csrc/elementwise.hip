@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const bf16_t* __restri
     for (int pix = p0 + sub; pix < p1; pix += nsub) {
         const int ph = pix / W, pw = pix - ph * W;
         // (1) dx at this pixel: sum over taps of dpred[ph-kh+1, pw-kw+1] * w[tap]
-        // (2) dw[tap] += dpred[ph,pw] * x[ph+kh-1, pw+kw-1]
+        // (2) dw[tap] += dpred[ph-kh+1, pw-kw+1] * x[ph, pw]      (the weight gradient taken at the INPUT pixel, see below)
         float gx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         const float g0 = dp[pix];
         if (cl == 0) dbias += g0;

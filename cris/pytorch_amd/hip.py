@@ -354,6 +354,9 @@ class HipLibraryError(RuntimeError):
     pass
 
 
+ABI_VERSION = 3      # == CRIS_ABI_VERSION of include/cris_hip.h (tests/test_abi.py compares the two)
+
+
 def load():
     """Load libcris_hip.so (building is __graft_entry__.build()'s job).  Raises if it is missing."""
     global _lib
@@ -364,6 +367,11 @@ def load():
             "libcris_hip.so not found at %s - run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(there is no CPU fallback for the CRIS HIP path)" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.cris_abi_version.restype = C.c_int
+    if lib.cris_abi_version() != ABI_VERSION:
+        raise HipLibraryError("ABI mismatch: %s reports cris_abi_version() = %d, this binding was written against %d (include/cris_hip.h "
+                              "CRIS_ABI_VERSION) - a stale build; run `python -c 'import __graft_entry__ as g; g.build()'`"
+                              % (LIB_PATH, lib.cris_abi_version(), ABI_VERSION))
     for name, (res, args) in _SIGS.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res

@@ -183,9 +183,9 @@ class InferenceRunner:
             return self._body(st["img"], st["word"])
         if st["graph"] is None and self.graph_error is None:
             try:
-                torch.cuda.synchronize(self.device)
+                from . import capture
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with capture.graph(g, device=self.device):
                     out = self._body(st["img"], st["word"])
                 st["graph"], st["out"] = g, out
             except Exception as ex:          # noqa: BLE001

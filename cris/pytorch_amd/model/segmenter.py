@@ -20,7 +20,7 @@ import torch
 import torch.distributed as dist
 from torch import nn
 
-from .. import arch, ops
+from .. import arch, debug, ops
 from ..engine import Engine
 
 _FP16_ROUNDED_SUFFIXES = ("in_proj_weight", "in_proj_bias", "q_proj_weight", "k_proj_weight", "v_proj_weight")
@@ -75,8 +75,11 @@ class _CrisStep(torch.autograd.Function):
         eng = module._engine
         ctx.module = module
         ctx.direct = len(params) == 1 and params[0] is module._anchor
+        # SURVEY 8e option B: under a DistributedDataParallel wrapper that was told to ignore this module's parameters the
+        # gradient exchange is the module's own (the communicator, or None: no exchange in this step)
+        ctx.exchange = module._exchange_comm_for_this_step()
         ctx.step_id = module._steps                 # the engine keeps ONE step's saved state (tape / captured buffers)
-        st = module._graph_step(img, word, mask, seed)
+        st = module._graph_step(img, word, mask, seed, ctx.exchange)
         ctx.graph = st
         if st is not None:                       # replayed HIP graph: outputs are the capture's static buffers (fresh aliases)
             pred, msk, loss = st["pred"].view_as(st["pred"]), st["msk"].view_as(st["msk"]), st["loss"].view(())
@@ -95,20 +98,27 @@ class _CrisStep(torch.autograd.Function):
                                "overwritten - the engine keeps the activations of one step (call backward before the next "
                                "training forward; losses of several forwards cannot be back-propagated together)")
         gscale = gloss.detach().reshape(1).to(torch.float32).contiguous()        # GradScaler's factor arrives here
+        xchg = ctx.exchange
+        if xchg is not None:
+            # DistributedDataParallel divides every gradient by the world size BEFORE it adds them up over the ranks
+            # (reducer: bucket = grad / world, all-reduce SUM): the same order here, through the factor on dloss
+            gscale = gscale * (1.0 / xchg.world)
         if ctx.direct:
             module._release_engine_grads()       # before the backward pass overwrites the engine's gradient buffers
+        if xchg is not None:
+            module._exchange_stale_grads(xchg)   # gradients of no_sync() micro-batches still sitting in `.grad`
         st = ctx.graph
         if st is not None and st.get("bwd") is None:
             # command-list mode, first step with this shape: the forward was recorded while it ran, now the backward is
             st["gscale"].copy_(gscale, non_blocking=True)
-            module._record_backward(st)
+            module._record_backward(st, xchg)
             grads = st["grads"]
         elif st is not None:
             st["gscale"].copy_(gscale, non_blocking=True)
             st["bwd"].replay()
             grads = st["grads"]
         else:
-            eng.backward(gscale=gscale)
+            module._backward_and_exchange(gscale, xchg)
             grads = module._export_grads()
         if ctx.direct:
             # single process, no per-parameter hooks: the gradients ARE the engine's buffers - hand them to `.grad` directly
@@ -118,14 +128,20 @@ class _CrisStep(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(grads)
 
 
-# Bumped whenever ANY nn.Module registers a parameter or a sub-module (torch's global registration hooks; assignments through
-# __setattr__ go through them too): CRIS._fast_key re-walks its parameter list when this moved.  Round-4 advisor finding: the
-# fast key looked at the first and last parameter only, so a replaced MIDDLE parameter kept training the old tensor.
+# Bumped whenever a module that belongs to a live CRIS tree registers a parameter or a sub-module (torch's global registration
+# hooks; assignments through __setattr__ go through them too): CRIS._fast_key re-walks its parameter list when this moved.
+# Round-4 advisor finding: the fast key looked at the first and last parameter only, so a replaced MIDDLE parameter kept training
+# the old tensor.  Round-5 finding: the hooks are process-global, and a loop that builds ANY small nn.Module per step (a loss, a
+# metric with a buffer-holding child) bumped the epoch and forced the ~1.5 ms tree walk on every forward - so only modules of a
+# live CRIS tree count (`_TREE_MODULES`: every sub-module seen by the last walk of each live CRIS; a module that is being
+# CONSTRUCTED is not in it yet, and a module grafted into a tree is registered by a member of the tree, which is).
 _REGISTRATION_EPOCH = [0]
+_TREE_MODULES = weakref.WeakSet()
 
 
-def _bump_registration_epoch(*_a, **_k):
-    _REGISTRATION_EPOCH[0] += 1
+def _bump_registration_epoch(module, *_a, **_k):
+    if module in _TREE_MODULES:
+        _REGISTRATION_EPOCH[0] += 1
     return None
 
 
@@ -165,6 +181,90 @@ class CRIS(nn.Module):
         self.graph_error = None
         self._steps = 0
         self._unpack = None
+        self._ddp_asked = False             # a DistributedDataParallel constructor read _ddp_params_and_buffers_to_ignore
+        self._ddp_ref = None                # weak reference to that wrapper (its no_sync() state is honoured)
+        self._ddp_extra_ignore = []         # names a caller set through DDP's _set_params_and_buffers_to_ignore_for_model
+        self._self_exchange = False         # decided per engine (_ensure_engine)
+        self._ddp_synced = False
+
+    # ------------------------------------------------------------------------------------------------
+    # SURVEY.md 8e option B - the gradient exchange under the reference's DistributedDataParallel wrap (train.py:100-102).
+    # DDP reads `module._ddp_params_and_buffers_to_ignore` in its constructor: every parameter named there gets no
+    # AccumulateGrad hook, no bucket, no initial broadcast.  The module names ALL of its parameters but `backbone.logit_scale`
+    # (DDP refuses a module without a parameter that requires a gradient; that one receives none in the reference either) and
+    # then does what DDP would have done, on the library's own terms: rank 0's parameters and buffers are broadcast once, each
+    # backward all-reduces the flat gradient arena as eight stage-sized messages on a side stream and a communicator of their
+    # own while the earlier stages are still in backward (the exchange NativeTrainer uses), divided by the world size before
+    # the sum as DDP's reducer does, and `.grad` is handed out directly.  What this removes per step: 449 AccumulateGrad
+    # clones, DDP's bucket copies in and out, its per-forward buffer broadcast - ~7 ms of 22 at R50 / 416 / batch 8 (round 5).
+    # CRIS_DDP_SELF_EXCHANGE=0 hides the attribute: DDP then manages every parameter itself, as in rounds 2-5.
+    @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        if os.environ.get("CRIS_DDP_SELF_EXCHANGE", "1") != "1":
+            raise AttributeError("_ddp_params_and_buffers_to_ignore")
+        try:
+            import sys
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            w = sys._getframe(1).f_locals.get("self")
+            if isinstance(w, DDP):
+                self._ddp_asked = True
+                self._ddp_ref = weakref.ref(w)
+        except Exception:                        # noqa: BLE001 - no frame introspection: believe that it was a DDP constructor
+            self._ddp_asked = True
+        names = [n for n, _ in self.named_parameters() if n != "backbone.logit_scale"]
+        # BatchNorm buffers: with SyncBatchNorm every rank computes the same running statistics, DDP's per-forward broadcast of
+        # rank 0's would be 213 tensors of traffic for nothing; with plain BatchNorm under DDP the reference DOES overwrite the
+        # other ranks' statistics with rank 0's in every forward (broadcast_buffers=True) - those stay DDP's to manage
+        if isinstance(self.backbone.visual.bn1, nn.SyncBatchNorm):
+            names += [n for n, _ in self.named_buffers()]
+        return names + list(self._ddp_extra_ignore)
+
+    @_ddp_params_and_buffers_to_ignore.setter
+    def _ddp_params_and_buffers_to_ignore(self, value):
+        self._ddp_extra_ignore = list(value)
+
+    def _exchange_comm_for_this_step(self):
+        """the communicator this training step's backward exchanges gradients on, or None (not under a DDP wrapper that left
+        the parameters to the module / one rank / inside the wrapper's no_sync())"""
+        if not self._self_exchange:
+            return None
+        comm = self._engine.comm
+        if comm.world <= 1 and not debug.HOOKS.force_dist:
+            return None
+        ddp = self._ddp_ref() if self._ddp_ref is not None else None
+        if ddp is not None and not ddp.require_backward_grad_sync:
+            return None
+        return comm
+
+    def _backward_and_exchange(self, gscale, comm):
+        """the engine's backward; with a communicator each arena stage is all-reduced (SUM) on the communicator's side stream as
+        soon as backward has issued its last gradient, and the launch stream joins the exchange at the end"""
+        eng = self._engine
+        if comm is None:
+            eng.backward(gscale=gscale)
+            return
+
+        def on_stage(st):
+            lo, hi = eng.stage_ranges[st]
+            ops.torch_op(lambda: comm.allreduce_async(eng.grad_arena[lo:hi]))
+        eng.backward(gscale=gscale, on_stage_done=on_stage)
+        ops.torch_op(comm.wait_all)
+
+    def _exchange_stale_grads(self, comm):
+        """Gradients that are still in `.grad` when an exchanging backward starts were accumulated by backward passes inside the
+        wrapper's no_sync() (local, not averaged): DDP would average old + new together; here the old part is averaged now
+        (tensor by tensor: the slow form, for a case the reference's loop never enters - it zeroes with set_to_none) and the
+        new part arrives averaged.  Values that were averaged already (identical on every rank) are unchanged by this."""
+        stale = [p.grad for p in self._step_params if p.grad is not None]
+        for g in stale:
+            g.div_(comm.world)
+            comm.allreduce_sum(g)
+
+    def _sync_from_rank0(self):
+        """what DistributedDataParallel's constructor does for the parameters it manages (_sync_module_states): every rank
+        starts from rank 0's parameters and buffers (the decoder / neck / projector are randomly initialised per process)"""
+        for t in list(self.parameters()) + [b for b in self.buffers() if b.is_floating_point() or b.dtype == torch.int64]:
+            dist.broadcast(t.data, 0)
 
     # ------------------------------------------------------------------------------------------------
     def _grad_params(self):
@@ -184,11 +284,13 @@ class CRIS(nn.Module):
             # makes the cached list suspect: walk the tree again, once)
             self._plist = list(self.parameters())
             self._plist_epoch = _REGISTRATION_EPOCH[0]
+            for m in self.modules():
+                _TREE_MODULES.add(m)
         pl = self._plist
         # every parameter's storage address (`p.data = other` re-points one tensor without registering anything): ~40 us of
         # host time for the 449 tensors, against ~1.5 ms for the tree walk
         return (str(device), sum(map(_data_ptr, pl)), pl[0].data_ptr(), pl[-1].data_ptr(), len(pl), type(self.backbone.visual.bn1),
-                dist.is_available() and dist.is_initialized(), bool(self._grad_views))
+                dist.is_available() and dist.is_initialized(), bool(self._grad_views), self._ddp_asked)
 
     def _ensure_engine(self, device):
         fk = self._fast_key(device)
@@ -203,14 +305,20 @@ class CRIS(nn.Module):
         # `.grad` is DDP's averaged gradient in its own tensor, which the optimizer copies into the arena views before its
         # fused update (optim.Adam.step)
         views = bool(self._grad_views)
-        key = (str(device), sync, views, tuple(p.data_ptr() for p in params.values()), tuple(b.data_ptr() for b in buffers.values()))
+        pg = dist.is_available() and dist.is_initialized()
+        xchg = bool(self._ddp_asked and pg)
+        key = (str(device), sync, views, xchg, tuple(p.data_ptr() for p in params.values()), tuple(b.data_ptr() for b in buffers.values()))
         if self._engine is not None and key == self._engine_key:
             return self._engine
+        self._self_exchange = xchg
+        if xchg and dist.get_world_size() > 1 and not self._ddp_synced:
+            self._sync_from_rank0()
+            self._ddp_synced = True
         for n, p in params.items():
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("CRIS (HIP path) needs contiguous fp32 parameters, got %s %s" % (n, p.dtype))
         comm = None
-        if sync:
+        if sync or (xchg and (dist.get_world_size() > 1 or debug.HOOKS.force_dist)):
             from ..dist import TorchDistComm
             comm = TorchDistComm(device)
         self._engine = Engine(self.clip_spec, self.head_spec, params, buffers, device, comm=comm, sync_bn=sync)
@@ -241,7 +349,9 @@ class CRIS(nn.Module):
         off (CRIS_MODULE_DIRECT_GRAD=0)."""
         if os.environ.get("CRIS_MODULE_DIRECT_GRAD", "1") != "1":
             return False
-        if dist.is_available() and dist.is_initialized():       # (a DDP wrapper hooks the AccumulateGrad nodes, at any world size)
+        if dist.is_available() and dist.is_initialized() and not getattr(self, "_self_exchange", False):
+            # (a DDP wrapper that manages these parameters hooks their AccumulateGrad nodes, at any world size; with the
+            # module's own exchange - _ddp_params_and_buffers_to_ignore - it has no hooks on them)
             return False
         if not torch.is_grad_enabled():
             return False
@@ -286,7 +396,7 @@ class CRIS(nn.Module):
     # cannot be captured (gloo), and any capture failure (reported once in `graph_error`).
     MAX_GRAPH_SHAPES = 6
 
-    def _graph_step(self, img, word, mask, seed):
+    def _graph_step(self, img, word, mask, seed, xchg=None):
         """replay (capturing first if needed) the forward graph for this step; None = run the eager schedule"""
         if os.environ.get("CRIS_MODULE_GRAPH", "1") != "1":
             return None
@@ -295,7 +405,8 @@ class CRIS(nn.Module):
             return None
         if getattr(self, "_graphs_key", None) != self._engine_key:           # parameters moved (.cuda() / .to()): start over
             self._graphs, self._graphs_key, self._graph_seen, self.graph_error = {}, self._engine_key, set(), None
-        key = (tuple(img.shape), tuple(word.shape), tuple(mask.shape), img.dtype, mask.dtype, word.dtype)
+        # (a backward with the gradient exchange inside and one without - the wrapper's no_sync() - are different schedules)
+        key = (tuple(img.shape), tuple(word.shape), tuple(mask.shape), img.dtype, mask.dtype, word.dtype, xchg is not None)
         st = self._graphs.get(key)
         if st is None:
             if self.graph_error is not None or len(self._graphs) >= self.MAX_GRAPH_SHAPES:
@@ -309,7 +420,7 @@ class CRIS(nn.Module):
                 self._graphs[key] = st
                 return st
             try:
-                st = self._capture_graphs(img, word, mask)
+                st = self._capture_graphs(img, word, mask, xchg)
             except Exception as ex:              # noqa: BLE001 - fall back to the eager schedule, say why once
                 self.graph_error = repr(ex)
                 torch.cuda.synchronize()
@@ -377,7 +488,7 @@ class CRIS(nn.Module):
         st.update(fwd=fwd, bwd=None, pred=pred, msk=msk, loss=loss)
         return st
 
-    def _record_backward(self, st):
+    def _record_backward(self, st, xchg=None):
         from .. import hip
         eng = self._engine
         bwd = hip.CommandList()
@@ -386,7 +497,7 @@ class CRIS(nn.Module):
             with torch.cuda.use_mem_pool(st["pool"]):
                 hip.RECORDER = bwd
                 try:
-                    eng.backward(gscale=st["gscale"])
+                    self._backward_and_exchange(st["gscale"], xchg)
                     grads = self._export_grads()
                 finally:
                     hip.RECORDER = None
@@ -394,20 +505,22 @@ class CRIS(nn.Module):
             eng.seed_dev = None
         st.update(bwd=bwd, grads=grads)
 
-    def _capture_graphs(self, img, word, mask):
+    def _capture_graphs(self, img, word, mask, xchg=None):
         eng = self._engine
         st = dict(img=img.clone(), word=word.clone(), mask=mask.clone(),
                   seed=torch.zeros(1, dtype=torch.int32, device=img.device), gscale=torch.ones(1, dtype=torch.float32, device=img.device))
-        torch.cuda.synchronize()
+        from .. import capture
         pool = torch.cuda.graph_pool_handle()
         fwd, bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         eng.seed_dev = st["seed"]
         try:
             self._prepare_packs_for_capture()
-            with torch.cuda.graph(fwd, pool=pool):
+            # (capture.py: thread_local mode + drained c10d watchdog - DistributedDataParallel's all-reduces of the previous
+            # step are still on the watchdog's list when the second step captures)
+            with capture.graph(fwd, pool=pool):
                 pred, msk, loss = eng.forward(st["img"], st["word"], st["mask"], training=True, seed=0)
-            with torch.cuda.graph(bwd, pool=pool):
-                eng.backward(gscale=st["gscale"])
+            with capture.graph(bwd, pool=pool, drain=False):
+                self._backward_and_exchange(st["gscale"], xchg)
                 grads = self._export_grads()
         finally:
             eng.seed_dev = None

@@ -83,6 +83,30 @@ class Adam(torch.optim.Adam):
             m._engine.packs_current = False               # the module re-packs before its next replay (segmenter._graph_step)
         return r
 
+    def _torch_step_after_amp_handover(self):
+        """Fallback to torch's step from INSIDE a fused-eligible step (no training forward on this engine yet, or a `.grad` is
+        None - a frozen parameter, say).  GradScaler has read `_step_supports_amp_scaling` as True by then: it skipped its own
+        `unscale_` and left its scale / found_inf on the optimizer as `grad_scale` / `found_inf`, which the plain
+        torch.optim.Adam step refuses (round-5 advisor finding: an assertion deep inside torch, or - without it - an update
+        with scaled gradients).  So this does what GradScaler would have done: skip the step when a gradient is not finite,
+        else unscale the gradients in place, and run torch's step without the two attributes (they are put back afterwards -
+        GradScaler deletes them itself).  One host synchronisation; this is not the steady-state path."""
+        scale, found = getattr(self, "grad_scale", None), getattr(self, "found_inf", None)
+        if scale is None and found is None:
+            return self._torch_step(None)
+        if found is not None and float(found.sum()) > 0:
+            return None                                   # GradScaler._maybe_opt_step: no update on a non-finite gradient
+        grads = [p.grad for g in self.param_groups for p in g["params"] if p.grad is not None]
+        if scale is not None and grads:
+            inv = scale.double().reciprocal().float()
+            torch._foreach_mul_(grads, inv)
+        del self.grad_scale
+        del self.found_inf
+        try:
+            return self._torch_step(None)
+        finally:
+            self.grad_scale, self.found_inf = scale, found
+
     def _grads_into_arena(self):
         """Make the arena hold what `.grad` holds (see the module docstring).  False: some `.grad` is None - not a fused step."""
         m = self._cris
@@ -155,7 +179,7 @@ class Adam(torch.optim.Adam):
             with torch.enable_grad():
                 loss = closure()
         if getattr(self._cris, "_step_cache_key", None) != self._cris._engine_key or not self._grads_into_arena():
-            return self._torch_step(None)                 # (no training forward on this engine yet / a `.grad` is None)
+            return self._torch_step_after_amp_handover()  # (no training forward on this engine yet / a `.grad` is None)
         tab = self._table()
         lrs = [float(g["lr"]) for g in self.param_groups for p in g["params"] if p in self.state]
         if lrs != self._tab_lrs:                          # a scheduler moved the learning rates (train.py:108-110, once per epoch)

@@ -254,10 +254,12 @@ class NativeTrainer:
             self._checked_batch = b
 
     def _capture(self):
+        from . import capture
         _, s_img, s_word, s_mask = self._static
-        torch.cuda.synchronize(self.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local capture mode + a drained c10d watchdog (capture.py): the eager first step left collectives of two
+        # communicators behind whose end events the watchdog thread is still polling
+        with capture.graph(g, device=self.device):
             loss, pred, msk = self._step_body(s_img, s_word, s_mask, None)
         self._graph, self._loss, self._keep = g, loss, (pred, msk)
 

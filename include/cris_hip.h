@@ -24,6 +24,10 @@ extern "C" {
 typedef uint16_t cris_bf16;
 
 const char* cris_last_error(void);
+/* CRIS_ABI_VERSION moves whenever an exported signature or struct changes; a binding compares cris_abi_version() with the
+ * value it was written against and refuses a library of another version (a stale build loaded with new argument lists would
+ * mis-read them silently).  2: cris_step_advance took its fourth argument (round 5); 3: round 6 */
+#define CRIS_ABI_VERSION 3
 int cris_abi_version(void);
 /* sizeof() of the parameter structs, so the Python mirror (ctypes) can be checked without a GPU */
 int cris_sizeof(const char* struct_name);

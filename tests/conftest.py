@@ -15,17 +15,29 @@ def pytest_configure(config):
                                        "runs of every BASELINE configuration); select with -m 'gpu or gpu_long'")
 
 
-# GPU run order: deterministic per-kernel parity first, then the whole-network comparisons, then the statistical ones
-# (loss trajectories, multi-process runs) - under `-x` a failure in a late, noise-sensitive test must not hide the kernel tests.
-_GPU_ORDER = ["test_hip_ops", "test_engine_gpu", "test_parity_long_gpu", "test_module_gpu", "test_dist_gpu", "test_ref_loop_gpu", "test_eval_post", "test_input_pipe", "test_jpeg_gpu", "test_records_gpu", "test_p2p_gpu", "test_comm_gpu"]
+# GPU run order (round-5 review: one aborting multi-process test in the middle hid every row behind it under `-x`): the
+# deterministic single-process files first - kernels, whole network, drop-in module, inference, evaluation post-processing,
+# input pipeline, long parity runs - and EVERY file that spawns processes or builds a process group last, the RCCL one last
+# of all.  A failure in a late, noise-sensitive test cannot hide the kernel tests or the f1 / f2 rows.
+_GPU_ORDER = ["test_hip_ops", "test_engine_gpu", "test_oracle_device", "test_module_gpu", "test_infer_gpu", "test_eval_post", "test_input_pipe",
+              "test_jpeg_gpu", "test_png", "test_records_gpu", "test_parity_long_gpu",
+              # multi-process from here on
+              "test_bench_launch", "test_p2p_gpu", "test_comm_gpu", "test_ref_loop_gpu", "test_dist_gpu"]
+_LAST = len(_GPU_ORDER) + 1
 
 
 def _gpu_rank(item):
     name = os.path.basename(str(item.fspath))
+    if "gpu" not in item.keywords and "gpu_long" not in item.keywords:
+        return -1                                # CPU tests keep their place in front
     for i, stem in enumerate(_GPU_ORDER):
         if name.startswith(stem):
-            return 9 if "trajectory" in item.name else i     # the two loss-trajectory runs go last of all
-    return -1                                    # CPU-only files keep their place in front
+            if "trajectory" in item.name:
+                return len(_GPU_ORDER) - 5.5     # the loss-trajectory runs: last of the single-process part
+            if "rccl" in item.name:
+                return _LAST                     # the one test that needs a c10d RCCL group: last of all
+            return i
+    return len(_GPU_ORDER) - 5.7                 # a GPU file this list does not know: before the multi-process part
 
 
 def pytest_collection_modifyitems(config, items):

@@ -124,7 +124,8 @@ def test_rccl_collectives_inside_the_captured_graph():
                            stderr=subprocess.STDOUT, timeout=600)
         out = r.stdout.decode()
         line = [x for x in out.splitlines() if x.startswith("mode ")]
-        assert r.returncode == 0 and line, out[-2000:]
+        # (the FIRST 2 kB: an abort's cause is printed before the stack dumps that follow it)
+        assert r.returncode == 0 and line, "rc %d\n%s\n...\n%s" % (r.returncode, out[:2000], out[-1000:])
         m = re.match(r"mode (\w+) -> launch (\w+) graph_error (.*?) syncbn (.*?) \| .* losses (\[.*?\]) \.\.\. ([0-9.]+)", line[0])
         assert m, line[0]
         assert m.group(2) == mode and m.group(3) == "None", line[0]

@@ -104,3 +104,66 @@ def test_fast_key_sees_a_replaced_middle_parameter():
     assert k1 != k0
     holder.weight.data = old.detach().clone()                         # `.data` re-pointed: no registration, new storage
     assert model._fast_key("cuda:0") != k1
+
+
+def test_registrations_outside_the_tree_do_not_force_a_parameter_walk():
+    """round-5 advisor finding: the registration hooks are process-global; a module built per step anywhere in the user's
+    process (a loss or a metric with parameters / children) must not make every forward re-walk the 600-module tree"""
+    from cris.pytorch_amd.model import segmenter as S
+    model, _ = build_segmenter(NS(**TINY))
+    k0 = model._fast_key("cuda:0")
+    e0 = S._REGISTRATION_EPOCH[0]
+    for _ in range(3):
+        loss_mod = nn.Sequential(nn.Linear(3, 3), nn.BatchNorm1d(3))          # parameters, buffers and sub-modules: all foreign
+        loss_mod.extra = nn.Parameter(torch.zeros(1))
+    assert S._REGISTRATION_EPOCH[0] == e0 and model._fast_key("cuda:0") == k0
+    plist = model._plist
+    assert model._fast_key("cuda:0") == k0 and model._plist is plist        # no walk happened
+    # a graft INTO the tree is seen, and so is a later registration on the grafted module
+    model.neck.f2_cat[0] = nn.Conv2d(model.neck.f2_cat[0].in_channels, model.neck.f2_cat[0].out_channels, 1, bias=False)
+    assert S._REGISTRATION_EPOCH[0] > e0
+    k1 = model._fast_key("cuda:0")
+    assert k1 != k0 and model._plist is not plist
+    e1 = S._REGISTRATION_EPOCH[0]
+    model.neck.f2_cat[0].weight = nn.Parameter(model.neck.f2_cat[0].weight.detach().clone())
+    assert S._REGISTRATION_EPOCH[0] > e1 and model._fast_key("cuda:0") != k1
+
+
+def test_ddp_ignore_list_names_every_parameter_but_one():
+    """SURVEY.md 8e option B: what a DistributedDataParallel constructor reads from the module (it must keep one parameter
+    that requires a gradient; buffers are left to DDP unless the BatchNorms are SyncBatchNorm)"""
+    import os
+    model, _ = build_segmenter(NS(**TINY))
+    names = set(model._ddp_params_and_buffers_to_ignore)
+    assert not model._ddp_asked                                           # read by a test, not by a DDP constructor
+    pn = {n for n, _ in model.named_parameters()}
+    assert pn - names == {"backbone.logit_scale"} and not (names - pn)      # plain BatchNorm: the buffers stay DDP's
+    sync = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    assert sync is model
+    names = set(model._ddp_params_and_buffers_to_ignore)
+    assert names == (pn - {"backbone.logit_scale"}) | {n for n, _ in model.named_buffers()}
+    nn.parallel.DistributedDataParallel._set_params_and_buffers_to_ignore_for_model(model, ["backbone.logit_scale"])
+    assert "backbone.logit_scale" in model._ddp_params_and_buffers_to_ignore
+    os.environ["CRIS_DDP_SELF_EXCHANGE"] = "0"
+    try:
+        assert not hasattr(model, "_ddp_params_and_buffers_to_ignore")
+    finally:
+        del os.environ["CRIS_DDP_SELF_EXCHANGE"]
+
+
+def test_ddp_constructor_leaves_the_parameters_to_the_module(tmp_path):
+    """the wrap of train.py:100-102 on the CPU with a one-rank gloo group: DistributedDataParallel accepts the module with ONE
+    managed parameter, the module knows it was asked by a DDP constructor and holds the wrapper (for its no_sync() state)"""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method="file://" + str(tmp_path / "pg"), rank=0, world_size=1)
+    try:
+        model, _ = build_segmenter(NS(**TINY))          # (plain BatchNorm: DDP refuses SyncBatchNorm modules on the CPU)
+        ddp = nn.parallel.DistributedDataParallel(model, find_unused_parameters=True)
+        assert model._ddp_asked and model._ddp_ref() is ddp
+        assert len(ddp._module_parameters) == 1 and ddp._module_parameters[0] is model.backbone.logit_scale
+        assert len(list(ddp.parameters())) == len(list(model.parameters()))       # the optimizer still sees every parameter
+        with ddp.no_sync():
+            assert not model._ddp_ref().require_backward_grad_sync
+        assert model._ddp_ref().require_backward_grad_sync
+    finally:
+        dist.destroy_process_group()

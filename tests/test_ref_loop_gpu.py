@@ -119,3 +119,124 @@ def test_reference_recipe_two_ranks_equal_one_rank_and_the_oracle():
     with torch.no_grad():
         _, _, oloss = O.cris_forward(sd, clip, head, img, word, mask.unsqueeze(1), training=True, drop_seed=None)
     assert abs(ref[0][0] - float(oloss)) < 1e-2 and abs(r0[0][0] - float(oloss)) < 1e-2, (ref[0], r0[0], float(oloss))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# SURVEY.md 8e option B: under DistributedDataParallel the module names its parameters in `_ddp_params_and_buffers_to_ignore`
+# and exchanges the gradient arena itself (model/segmenter.py).  Pinned against the form of rounds 2-5, in which DDP manages
+# every parameter (CRIS_DDP_SELF_EXCHANGE=0): the averaged gradients must be the SAME BITS - the module divides by the world
+# size before the sum like DDP's reducer, a division by 2 is exact, and a two-term sum has one order.
+# ---------------------------------------------------------------------------------------------------------------------------
+def _grad_worker(rank, world, port, q, self_exchange, optimizer_name):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["CRIS_DDP_SELF_EXCHANGE"] = "1" if self_exchange else "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hashlib
+        from torch import nn
+        from cris.pytorch_amd import arch
+        from cris.pytorch_amd.model import build_segmenter
+        torch.cuda.set_device(0)
+        args = _cfg()
+        model, param_list = build_segmenter(args)
+        clip, head = arch.specs_by_name("tiny")
+        model.load_state_dict(arch.synthetic_state_dict(clip, dataclasses.replace(head, dropout=0.0), 0))
+        if rank == 1:
+            # DDP starts every rank from rank 0's parameters (the head is randomly initialised per process in the reference):
+            # whoever manages the parameters has to repair this
+            with torch.no_grad():
+                model.proj.txt.weight.add_(0.5)
+                model.backbone.visual.layer1[0].bn1.running_mean.add_(0.25)
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        model = nn.parallel.DistributedDataParallel(model.cuda(), device_ids=[0], find_unused_parameters=True)
+        inner = model.module
+        managed = len(list(model._module_parameters)) if hasattr(model, "_module_parameters") else -1
+        if optimizer_name == "cris":
+            from cris.pytorch_amd import optim as cris_optim
+            optimizer = cris_optim.Adam(param_list, lr=args.base_lr, weight_decay=0.0)
+        else:
+            optimizer = torch.optim.Adam(param_list, lr=args.base_lr, weight_decay=0.0)
+        scaler = torch.amp.GradScaler("cuda")
+        model.train()
+        out = {"managed_by_ddp": managed, "self_exchange": None, "digests": [], "losses": []}
+
+        def digest():
+            h = hashlib.sha256()
+            tot = 0.0
+            for n, p in inner.named_parameters():
+                if p.grad is None:
+                    assert n == "backbone.logit_scale", n
+                    continue
+                g = p.grad.detach().float().contiguous().cpu()
+                h.update(g.numpy().tobytes())
+                tot += float(g.double().abs().sum())
+            return h.hexdigest(), tot
+
+        for step in range(STEPS):
+            image, text, target = (t.cuda() for t in _shards(2, rank, world, step))
+            with torch.autocast("cuda"):
+                pred, tgt, loss = model(image, text, target.unsqueeze(1))
+            optimizer.zero_grad()
+            scaler.scale(loss).backward()
+            out["digests"].append(digest())
+            scaler.step(optimizer)
+            scaler.update()
+            out["losses"].append(float(loss))
+        # gradient accumulation through the wrapper's no_sync(): first micro-batch local, second exchanged
+        image, text, target = (t.cuda() for t in _shards(2, rank, world, STEPS))
+        optimizer.zero_grad()
+        with model.no_sync():
+            with torch.autocast("cuda"):
+                _, _, loss = model(image, text, target.unsqueeze(1))
+            scaler.scale(loss).backward()
+        image, text, target = (t.cuda() for t in _shards(2, rank, world, STEPS + 1))
+        with torch.autocast("cuda"):
+            _, _, loss = model(image, text, target.unsqueeze(1))
+        scaler.scale(loss).backward()
+        acc = torch.cat([p.grad.detach().float().flatten() for n, p in inner.named_parameters() if p.grad is not None]).cpu()
+        out["self_exchange"] = bool(getattr(inner, "_self_exchange", False))
+        torch.cuda.synchronize()
+        sd = inner.state_dict()
+        out["probe"] = {k: sd[k].double().sum().item() for k in PROBES}
+        out["rm"] = sd["backbone.visual.layer1.0.bn1.running_mean"].double().sum().item()
+        q.put((rank, out, acc))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_grad(self_exchange, optimizer_name="torch"):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q, self_exchange, optimizer_name)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize("optimizer_name", ["torch", "cris"])
+def test_own_gradient_exchange_under_ddp_equals_ddp_managed_gradients_bit_for_bit(optimizer_name):
+    own = _run_grad(True, optimizer_name)
+    ddp = _run_grad(False, optimizer_name)
+    (_, o0, a0), (_, o1, a1) = own
+    (_, d0, b0), (_, d1, b1) = ddp
+    assert o0["self_exchange"] and o1["self_exchange"] and not d0["self_exchange"]
+    assert o0["managed_by_ddp"] == 1 and d0["managed_by_ddp"] > 100, (o0["managed_by_ddp"], d0["managed_by_ddp"])
+    print("own", o0["losses"], "ddp", d0["losses"])
+    # every rank holds the same averaged gradient, and it is the one DDP's reducer produces - the same bits, every step (the
+    # later steps also cover the optimizer having seen the same gradients and rank 1's repaired parameters)
+    assert o0["digests"] == o1["digests"]
+    assert d0["digests"] == d1["digests"]
+    assert o0["digests"] == d0["digests"], (o0["digests"], d0["digests"])
+    assert o0["losses"] == d0["losses"] and o1["losses"] == d1["losses"]
+    assert o0["probe"] == o1["probe"] == d0["probe"] and o0["rm"] == o1["rm"] == d0["rm"]
+    # no_sync() accumulation: old (local) + new (exchanged) parts are averaged separately here, together by DDP - equal up to
+    # the rounding of one addition
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+    rel = float((a0 - b0).norm() / b0.norm())
+    assert rel < 1e-6, rel
