@@ -48,7 +48,10 @@ def main(fetch_db, write_db, out, steps=0):
     for a in res.values():
         a["traffic_bytes_per_launch"] = a["fetch_bytes_per_launch"] + a["write_bytes_per_launch"]
     total = sum(a["traffic_bytes_per_launch"] * a["launches"] for k, a in res.items() if k != "conv_gemm (all tile kernels)")
-    json.dump({"note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported; eager launches, %s" % fetch_db,
+    import os
+    stamp = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".source_commit")
+    commit = open(stamp).read().strip() if os.path.exists(stamp) else None      # (written by tools/gpurun.sh before the snapshot)
+    json.dump({"commit": commit, "note": "FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE as reported; eager launches, %s" % fetch_db,
                "steps": steps, "total_bytes_per_step": total / steps if steps else None, "kernels": res}, open(out, "w"), indent=1)
     if steps:
         print("whole step: %.2f GB memory-side traffic per step (%d steps traced)" % (total / steps / 1e9, steps))
