@@ -517,6 +517,8 @@ def main():
                        "launch": tr.launch, "graph_captured": tr._graph is not None, "graph_error": tr.graph_error,
                        "syncbn_exchange": tr.syncbn_exchange, "comm": type(comm).__name__ if comm is not None else None,
                        "syncbn_peer_timeout": (bool(int(comm.p2p.err.item())) if getattr(comm, "p2p", None) is not None else None),
+                       "source_commit": (open(os.path.join(ROOT, ".source_commit")).read().strip()
+                                         if os.path.exists(os.path.join(ROOT, ".source_commit")) else None),
                        "gpu_state_start": smi0, "gpu_state_end": smi1},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12),
                               "hbm_frac_alg": (sps / world * ALG_BYTES_PER_SAMPLE + steps_s * ADAM_BYTES_PER_STEP) / (HBM_PEAK * 1e9)},

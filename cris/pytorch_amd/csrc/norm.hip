@@ -50,9 +50,20 @@ __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__
     const int i_begin = s * pps, i_end = min(nparts, (s + 1) * pps), last = nparts - 1;
     const float n_full = (float)rows_per_part, n_last = (float)(M - last * rows_per_part);
     const float n_slice = (float)(min(M, i_end * rows_per_part) - i_begin * rows_per_part);
-    // both columns of this lane's entries are requested up front (a slice is a few entries per lane)
+    // both columns of this lane's first four entries (a slice is a few entries per lane: normally ALL of them) are requested up
+    // front and kept in registers for the second pass (round 6: its M2 loads used to wait for the mean - a second cold round trip)
+    float ps0[4], pq0[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const size_t o = (size_t)min(i_begin + pl + 16 * u, i_end - 1) * C + cc;
+        ps0[u] = psum[o];
+        pq0[u] = pm2[o];
+    }
     float t = 0.f;
-    for (int i0 = i_begin + pl; i0 < i_end; i0 += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if (i_begin + pl + 16 * u < i_end) t += ps0[u];
+    for (int i0 = i_begin + pl + 64; i0 < i_end; i0 += 64) {
         float ps[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) ps[u] = psum[(size_t)min(i0 + 16 * u, i_end - 1) * C + cc];
@@ -64,7 +75,15 @@ __global__ __launch_bounds__(256) void bn_merge_kernel(const float* __restrict__
     const float mean = total / n_slice;
     const float inv_full = 1.f / n_full, inv_last = 1.f / n_last;
     float q = 0.f;
-    for (int i0 = i_begin + pl; i0 < i_end; i0 += 64) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int i = i_begin + pl + 16 * u;
+        if (i < i_end) {
+            const float d = ps0[u] * (i == last ? inv_last : inv_full) - mean;
+            q += pq0[u] + (i == last ? n_last : n_full) * d * d;
+        }
+    }
+    for (int i0 = i_begin + pl + 64; i0 < i_end; i0 += 64) {
         float ps[4], pq[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -130,36 +149,33 @@ __global__ __launch_bounds__(16 * PL) void bn_finalize_kernel(const float* psum,
         if (rmean) { rm0 = rmean[c]; rv0 = rvar[c]; }
     }
     if (!global_stats) {
-        float s = 0.f;
-        for (int i0 = pl; i0 < nparts; i0 += 8 * PL) {
-            float ps[8];
+        // Round 6: the launcher guarantees nparts <= 8 * PL (longer lists come through bn_merge_kernel), so each lane owns at
+        // most eight entries: BOTH columns of all of them are requested up front and kept in registers - the second pass used to
+        // issue its M2 loads only after the mean was known, a second cold round trip to memory (the partials were written by
+        // other CUs' GEMM epilogues) in a kernel that is nothing but latency.  Same operations in the same order: same bits.
+        float ps[8], pq[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) ps[u] = psum[(size_t)min(i0 + PL * u, nparts - 1) * C + cc];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (i0 + PL * u < nparts) s += ps[u];
+        for (int u = 0; u < 8; ++u) {
+            const size_t o = (size_t)min(pl + PL * u, nparts - 1) * C + cc;
+            ps[u] = psum[o];
+            pq[u] = pm2[o];
         }
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (pl + PL * u < nparts) s += ps[u];
         const float total = bn_lane_sum<PL>(sh, s, pl, cl);
         mean = total / count_local;
         const int last = nparts - 1;
         const float n_full = (float)rows_per_part, n_last = count_local - (float)last * n_full;
         const float inv_full = 1.f / n_full, inv_last = 1.f / n_last;
         float q = 0.f;
-        for (int i0 = pl; i0 < nparts; i0 += 8 * PL) {
-            float ps[8], pq[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const size_t o = (size_t)min(i0 + PL * u, nparts - 1) * C + cc;
-                ps[u] = psum[o];
-                pq[u] = pm2[o];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = i0 + PL * u;
-                if (i < nparts) {
-                    const float d = ps[u] * (i == last ? inv_last : inv_full) - mean;
-                    q += pq[u] + (i == last ? n_last : n_full) * d * d;
-                }
+        for (int u = 0; u < 8; ++u) {
+            const int i = pl + PL * u;
+            if (i < nparts) {
+                const float d = ps[u] * (i == last ? inv_last : inv_full) - mean;
+                q += pq[u] + (i == last ? n_last : n_full) * d * d;
             }
         }
         m2 = bn_lane_sum<PL>(sh, q, pl, cl);
@@ -284,6 +300,7 @@ static int bn_finalize_launch(const float* psum, const float* pm2, int nparts, i
         nparts = slices;
         rows_per_part *= pps;
     }
+    CRIS_CHECK_ARG(global_stats || nparts <= 8 * 64, "partial list longer than one finalize launch covers");
     if (!global_stats && nparts > BN_WIDE_MIN)
         hipLaunchKernelGGL(bn_finalize_kernel<64>, dim3(cris_cdiv(C, 16)), dim3(1024), 0, (hipStream_t)stream, psum, pm2, nparts, rows_per_part,
                            count_local, count, gamma, beta, running_mean, running_var, momentum, eps, C, scale, shift, mean, invstd,

@@ -84,7 +84,7 @@ class _CrisStep(torch.autograd.Function):
         if st is not None:                       # replayed HIP graph: outputs are the capture's static buffers (fresh aliases)
             pred, msk, loss = st["pred"].view_as(st["pred"]), st["msk"].view_as(st["msk"]), st["loss"].view(())
         else:
-            pred, msk, loss = eng.forward(img, word, mask, training=True, seed=seed)
+            pred, msk, loss = module._training_forward(img, word, mask, seed)
         ctx.mark_non_differentiable(pred, msk)
         return pred, msk, loss
 
@@ -148,6 +148,7 @@ def _bump_registration_epoch(module, *_a, **_k):
 nn.modules.module.register_module_parameter_registration_hook(_bump_registration_epoch)
 nn.modules.module.register_module_module_registration_hook(_bump_registration_epoch)
 _data_ptr = torch.Tensor.data_ptr
+_PEER_CHECK_EVERY = int(os.environ.get("CRIS_PEER_CHECK_EVERY", "200"))
 
 
 class CRIS(nn.Module):
@@ -186,6 +187,7 @@ class CRIS(nn.Module):
         self._ddp_extra_ignore = []         # names a caller set through DDP's _set_params_and_buffers_to_ignore_for_model
         self._self_exchange = False         # decided per engine (_ensure_engine)
         self._ddp_synced = False
+        self._xgen_dev, self.syncbn_exchange = None, "none"
 
     # ------------------------------------------------------------------------------------------------
     # SURVEY.md 8e option B - the gradient exchange under the reference's DistributedDataParallel wrap (train.py:100-102).
@@ -235,6 +237,23 @@ class CRIS(nn.Module):
         if ddp is not None and not ddp.require_backward_grad_sync:
             return None
         return comm
+
+    def _training_forward(self, img, word, mask, seed):
+        """the engine's training forward; with the SyncBN mailboxes the exchange generation advances first (a launch of its own,
+        so that a captured / recorded forward advances it on every replay)"""
+        if self._xgen_dev is not None:
+            ops.counter_advance(self._xgen_dev)
+        return self._engine.forward(img, word, mask, training=True, seed=seed)
+
+    def _check_peers(self):
+        """COLLECTIVE, every CRIS_PEER_CHECK_EVERY-th training forward (default 200; 0 = never): raise on every rank when a
+        mailbox exchange of any rank gave up waiting for a peer (dist.TorchDistComm.check_peer_timeout) - a rank that lost a
+        peer must not train on alone on poisoned statistics (round-5 advisor finding: nothing ever called the check)."""
+        every = _PEER_CHECK_EVERY
+        if every > 0 and self._xgen_dev is not None and self._steps % every == 0 and self._steps > 0:
+            chk = getattr(self._engine.comm, "check_peer_timeout", None)
+            if chk is not None:
+                chk()
 
     def _backward_and_exchange(self, gscale, comm):
         """the engine's backward; with a communicator each arena stage is all-reduced (SUM) on the communicator's side stream as
@@ -323,6 +342,22 @@ class CRIS(nn.Module):
             comm = TorchDistComm(device)
         self._engine = Engine(self.clip_spec, self.head_spec, params, buffers, device, comm=comm, sync_bn=sync)
         self._engine_key = key
+        # SyncBN statistics (142 exchanges of a few KB per step, all on the critical path): through the peer-mapped mailboxes,
+        # inside the BatchNorm launches, as under NativeTrainer - when allocation, IPC mapping and a self-test with known data
+        # succeed on EVERY rank; otherwise (and with CRIS_SYNCBN_P2P=0) one RCCL all-reduce per exchange.  Round 6: until now
+        # the drop-in module always took the collectives - ~20 us each over xGMI, ~3 ms of every 8-GPU step.
+        self._xgen_dev, self.syncbn_exchange = None, "none" if not self._engine.sync_bn else "collective"
+        if (self._engine.sync_bn and comm is not None and os.environ.get("CRIS_SYNCBN_P2P", "1") == "1"
+                and torch.device(device).type == "cuda" and hasattr(comm, "enable_p2p")):
+            e_ = self._engine
+            self._xgen_dev = torch.zeros(1, dtype=torch.int32, device=device)       # generation of the exchanges: +1 per training forward, never rewound
+            cmax = max(e_.P[pfx + ".weight"].numel() for pfx in e_.bn_prefixes)
+            why = comm.enable_p2p(slots=2 * len(e_.bn_prefixes) + 8, max_floats=4 * cmax, gen_dev=self._xgen_dev)
+            if why is None:
+                self.syncbn_exchange = ("p2p mailboxes, exchanged inside the BatchNorm launches" if getattr(comm, "_fused", False)
+                                        else "p2p mailboxes, one exchange kernel per BatchNorm")
+            else:
+                self._xgen_dev, self.syncbn_exchange = None, "collective (mailboxes refused: %s)" % why
         # parameter-layout gradient buffers for the tensors whose HIP gradient lives in the GEMM layout
         e = self._engine
         srcs, dsts, lays = [], [], []
@@ -480,7 +515,7 @@ class CRIS(nn.Module):
             with torch.cuda.use_mem_pool(st["pool"]):
                 hip.RECORDER = fwd
                 try:
-                    pred, msk, loss = eng.forward(st["img"], st["word"], st["mask"], training=True, seed=0)
+                    pred, msk, loss = self._training_forward(st["img"], st["word"], st["mask"], 0)
                 finally:
                     hip.RECORDER = None
         finally:
@@ -518,7 +553,7 @@ class CRIS(nn.Module):
             # (capture.py: thread_local mode + drained c10d watchdog - DistributedDataParallel's all-reduces of the previous
             # step are still on the watchdog's list when the second step captures)
             with capture.graph(fwd, pool=pool):
-                pred, msk, loss = eng.forward(st["img"], st["word"], st["mask"], training=True, seed=0)
+                pred, msk, loss = self._training_forward(st["img"], st["word"], st["mask"], 0)
             with capture.graph(bwd, pool=pool, drain=False):
                 self._backward_and_exchange(st["gscale"], xchg)
                 grads = self._export_grads()
@@ -535,6 +570,7 @@ class CRIS(nn.Module):
         if self.training:
             if mask is None:
                 raise ValueError("training forward needs the mask")
+            self._check_peers()
             seed = self._steps * 7919 + 17
             self._steps += 1
             if getattr(self, "_step_cache_key", None) != self._engine_key:       # (module traversals cost ~1 ms per step)

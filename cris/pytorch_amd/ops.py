@@ -743,6 +743,11 @@ def step_advance(step, seed, exchange_gen=None):
     hip.call("cris_step_advance", ptr(step), ptr(seed), ptr(exchange_gen), _stream())
 
 
+def counter_advance(counter, skip=None):
+    """counter[0] += 1 on the device (unless skip[0] != 0)"""
+    hip.call("cris_counter_advance_unless", ptr(counter), ptr(skip), _stream())
+
+
 def axpy_f32(dst, src, alpha=1.0):
     hip.call("cris_axpy_f32", ptr(dst), ptr(src), float(alpha), dst.numel(), _stream())
 

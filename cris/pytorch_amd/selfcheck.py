@@ -33,6 +33,19 @@ BOUNDS = {
 }
 
 
+def assert_worst_tensors(rep_all_cos, table, band=0.02):
+    """Per-tensor regression guard (round-5 review: `grad_cos_min >= 0.75 .. 0.90` would not notice a real regression in one
+    tensor): `table` = the committed ten worst gradient cosines of this configuration [[name, cosine], ...]; every one of
+    them must still be within +-band of its committed value, and no tensor outside the table may have fallen below the
+    table's best entry minus the band."""
+    names = {n for n, _ in table}
+    for n, c in table:
+        assert abs(rep_all_cos[n] - c) <= band, (n, rep_all_cos[n], c)
+    floor = max(c for _, c in table) - band
+    low = {n: c for n, c in rep_all_cos.items() if n not in names and c < floor}
+    assert not low, low
+
+
 def assert_parity(rep, family):
     b = BOUNDS[family]
     assert rep["mask_equal"], "nearest mask resize is an index op: must be bit exact"
@@ -43,7 +56,7 @@ def assert_parity(rep, family):
     assert rep["grad_cos_min"] >= b["grad_cos_min"], rep
 
 
-def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", word_len=None, emul=False):
+def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", word_len=None, emul=False, return_all_cos=False):
     """Returns a dict of parity figures: HIP engine vs fp32 oracle (emul=True: also vs the oracle run with bf16 storage
     rounding, the noise floor every bf16 implementation shares - informative only, no bound depends on it)."""
     from . import arch, synth
@@ -80,7 +93,11 @@ def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", wo
         "pred_rel_vs_fp32": _rel(pred, opred.detach()),
         "grad_cos_min": coss[worst], "grad_cos_min_name": worst,
         "grad_cos_median": med(coss), "n_grads": len(coss),
+        # the ten worst tensors by name (tests/golden/grad_cos_r50_config1.json pins them for configs[1]: a regression in ONE
+        # tensor moves neither the median nor - unless it becomes the worst - the minimum)
+        "grad_cos_worst10": sorted(coss.items(), key=lambda kv: kv[1])[:10],
     }
+    rep_all = coss
     if emul:
         # the oracle again with bf16 storage rounding at the points where the HIP path stores bf16 (forward AND the
         # gradients flowing back through the same casts): the noise floor any bf16 implementation of this network shares
@@ -100,6 +117,8 @@ def run(spec="tiny", batch=4, size=64, dropout=0.1, seed=11, device="cuda:0", wo
     torch.cuda.synchronize(dev)
     rep["loss_step2"] = float(l2)
     rep["params_finite"] = all(bool(torch.isfinite(p).all()) for p in e.P.values())
+    if return_all_cos:
+        rep["grad_cos_all"] = rep_all
     return rep
 
 

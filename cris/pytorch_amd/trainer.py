@@ -129,6 +129,8 @@ class NativeTrainer:
         self._static = None
         self._eager_steps = 0
         self.graph_error = None
+        self._host_steps = 0
+        self._peer_check_every = int(os.environ.get("CRIS_PEER_CHECK_EVERY", "200"))
 
     def _build_adam(self, lrs):
         e, names = self.engine, self.names
@@ -192,6 +194,11 @@ class NativeTrainer:
     def train_step(self, img, word, mask, seed: Optional[int] = None):
         """One optimizer step.  Returns (loss 0-dim device tensor, metric [IoU%, Pr@50%] device tensor); both are
         overwritten by the next call."""
+        # COLLECTIVE, every CRIS_PEER_CHECK_EVERY-th step (default 200; 0 = never): a rank whose SyncBN mailbox exchange gave up
+        # waiting for a peer raises on EVERY rank instead of training on alone (round-5 advisor finding: nothing called the check)
+        self._host_steps += 1
+        if self._peer_check_every > 0 and self._host_steps % self._peer_check_every == 0 and getattr(self.comm, "p2p", None) is not None:
+            self.check_peer_timeout()
         if not self.use_graph or seed is not None or ops.KERNEL_TIMER is not None:
             self._check_equal_batch(img.shape[0])
             loss, _, _ = self._step_body(img, word, mask, seed)

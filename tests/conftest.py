@@ -9,6 +9,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# The CPU oracle is the checker of most GPU tests, and on the GPU box's 128 cores torch's default (one thread per core) runs it
+# 3.5x SLOWER than 32 threads do (bench.py cpu_baseline, round 5: 11.7 s against 3.3 s per R50 train step) - a third of the GPU
+# suite's wall time was oversubscribed CPU work.  Children (spawned ranks, subprocess tests) inherit the environment variable.
+if (os.cpu_count() or 1) > 32:
+    os.environ.setdefault("OMP_NUM_THREADS", "32")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run via gpurun / the driver's GPU tier)")
     config.addinivalue_line("markers", "gpu_long: GPU parity runs of a minute or more each (100-step trajectories, teacher-forced "
@@ -42,6 +49,8 @@ def _gpu_rank(item):
 
 def pytest_collection_modifyitems(config, items):
     import torch
+    if (os.cpu_count() or 1) > 32 and torch.get_num_threads() > 32:
+        torch.set_num_threads(32)
     items.sort(key=_gpu_rank)                    # stable sort: the order inside a file is unchanged
     if torch.cuda.is_available():
         return

@@ -71,9 +71,13 @@ def test_r50_long_text_small_step_matches_oracle():
 def test_config1_r50_416_batch8_step_matches_oracle():
     """BASELINE.json configs[1]: CRIS-R50, 416x416, per-GPU batch 8, 17 tokens - the benchmarked shape (128x128 / 64x128
     GEMM tiles, 676-token decoder attention, split weight gradients all run here)."""
-    rep = selfcheck.run("r50", batch=8, size=416, dropout=0.0, seed=3)
+    rep = selfcheck.run("r50", batch=8, size=416, dropout=0.0, seed=3, return_all_cos=True)
+    allcos = rep.pop("grad_cos_all")
     print(rep)
     selfcheck.assert_parity(rep, "r50_full")
+    # per-tensor guard: the ten worst gradient cosines of this state, committed with +-0.02 bands (tools/grad_cos_table.py)
+    table = json.load(open(os.path.join(GOLDEN, "grad_cos_r50_config1.json")))
+    selfcheck.assert_worst_tensors(allcos, table["worst10"], band=table["band"])
 
 
 @pytest.mark.parametrize("batch,size,word_len", [(1, 416, 17), (5, 320, 17), (2, 512, 22), (3, 352, 9)])
