@@ -210,16 +210,19 @@ class TorchDistComm:
     def allreduce_sum(self, t):
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
+    supports_max_u8 = True       # allreduce_async(op="max") on uint8 tensors (the Adam row marks of the token embedding)
+
     # gradient exchange: overlapped
-    def allreduce_async(self, t):
+    def allreduce_async(self, t, op="sum"):
+        rop = dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX
         if self.side is None:
-            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.grad_group, async_op=True))
+            self._pending.append(dist.all_reduce(t, op=rop, group=self.grad_group, async_op=True))
             return
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
         with torch.cuda.stream(self.side):
-            self._pending.append(dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.grad_group, async_op=True))
+            self._pending.append(dist.all_reduce(t, op=rop, group=self.grad_group, async_op=True))
 
     def wait_all(self):
         for w in self._pending:

@@ -397,6 +397,8 @@ class CRIS(nn.Module):
         an existing tensor -> += (gradient accumulation over several backward passes).  `.grad` is never the engine's buffer
         here: _release_engine_grads() has replaced such a reference by a copy before this backward pass overwrote the buffer."""
         for p_, g in zip(self._step_params, grads):
+            if not p_.requires_grad:
+                continue                         # a frozen parameter keeps `.grad` None, as under autograd (optimizers skip it)
             if p_.grad is None:
                 p_.grad = g
             else:

@@ -80,11 +80,13 @@ class NativeTrainer:
         self.base_lr, self.lr_multi, self.weight_decay = base_lr, lr_multi, weight_decay
         # Rows of the token embedding (49408 x 512: 17% of the parameters) that have never received a gradient keep g = m = v = 0
         # and Adam leaves them exactly as they are (while weight_decay == 0): the embedding backward marks the rows of each
-        # batch's tokens and the update skips the rest - bit-identical to the dense update.  One process only: with more
-        # ranks the all-reduced gradient has the other ranks' rows too, which this rank's marks do not cover.
+        # batch's tokens and the update skips the rest - bit-identical to the dense update.  With more ranks the all-reduced
+        # gradient has the other ranks' rows too: the marks (sticky bytes) are then all-reduced with MAX next to the text
+        # encoder's gradient stage (round 6; 49 KB per step on the gradient communicator), so every rank skips exactly the rows
+        # no rank ever touched - communicators without a byte-wise MAX (dist.RcclComm) keep the dense update.
         # CRIS_ADAM_ROW_SKIP=0 switches it off.
-        if (self.comm.world == 1 and weight_decay == 0.0 and os.environ.get("CRIS_ADAM_ROW_SKIP", "1") == "1"
-                and torch.device(device).type == "cuda"):
+        if ((self.comm.world == 1 or getattr(self.comm, "supports_max_u8", False)) and weight_decay == 0.0
+                and os.environ.get("CRIS_ADAM_ROW_SKIP", "1") == "1" and torch.device(device).type == "cuda"):
             e.embed_live = torch.zeros(e.P["backbone.token_embedding.weight"].shape[0], dtype=torch.uint8, device=device)
         self._build_adam([base_lr] * len(names))
         self.metric = torch.zeros(2, device=device)
@@ -182,6 +184,9 @@ class NativeTrainer:
             def on_stage(st):
                 lo, hi = e.stage_ranges[st]
                 ops.torch_op(lambda: self.comm.allreduce_async(e.grad_arena[lo:hi]))
+                if st == 4 and e.embed_live is not None and getattr(self.comm, "supports_max_u8", False):
+                    # (stage 4 = the text encoder, whose backward marked this batch's rows of the token embedding)
+                    ops.torch_op(lambda: self.comm.allreduce_async(e.embed_live, op="max"))
             e.backward(on_stage_done=on_stage)
             ops.torch_op(self.comm.wait_all)
         else:

@@ -208,6 +208,50 @@ def test_optional_fused_adam_matches_torch_adam_under_the_reference_loop():
     assert worst < 2e-3, worst                                        # five steps of lr 1e-4: the two runs took the same steps
 
 
+def _frozen_backbone_loop(opt_cls, steps=3):
+    dev = torch.device("cuda:0")
+    model, groups = build_segmenter(NS(**TINY))
+    clip, head = arch.specs_by_name("tiny")
+    model.load_state_dict(arch.synthetic_state_dict(clip, head, 0))
+    model = model.to(dev).train()
+    for p in model.backbone.parameters():                            # fine-tuning the head: the whole CLIP backbone frozen,
+        p.requires_grad_(False)                                      # every parameter still handed to the optimizer (train.py:105)
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt = opt_cls(groups, lr=1e-4, weight_decay=0.0)
+    sc = torch.amp.GradScaler("cuda")
+    for step in range(steps):
+        img, word, mask = _batch(step, dev)
+        with torch.autocast("cuda"):
+            _, _, loss = model(img, word, mask)
+        opt.zero_grad()
+        sc.scale(loss).backward()
+        sc.step(opt)
+        sc.update()
+    torch.cuda.synchronize()
+    return model, before, float(sc.get_scale())
+
+
+def test_fused_adam_with_frozen_parameters_falls_back_without_tripping_gradscaler():
+    """round-5 advisor finding: GradScaler reads `_step_supports_amp_scaling` as True, skips its own unscale_ and leaves
+    grad_scale / found_inf on the optimizer - and a step that THEN falls back to torch's Adam (a `.grad` is None: frozen
+    parameters) hit an assertion inside torch (or would have stepped with scaled gradients).  The fallback now unscales itself:
+    frozen parameters stay bit-identical, the others take the steps torch.optim.Adam takes."""
+    from cris.pytorch_amd import optim
+    ma, before, scale_a = _frozen_backbone_loop(optim.Adam)
+    mb, _, scale_b = _frozen_backbone_loop(torch.optim.Adam)
+    assert scale_a == scale_b
+    pa, pb = dict(ma.named_parameters()), dict(mb.named_parameters())
+    moved = 0
+    for k, v in pa.items():
+        if k.startswith("backbone."):
+            assert torch.equal(v, before[k]), k                      # frozen: untouched
+            assert v.grad is None
+        else:
+            assert float((v - pb[k]).abs().max()) < 1e-3, k          # three steps of lr 1e-4, the same steps as torch's Adam
+            moved += int(not torch.equal(v, before[k]))
+    assert moved > 50
+
+
 def _accumulate_params(opt_cls, zero_style, steps=3):
     """two micro-batches per optimizer step under `opt_cls`; returns the parameters after `steps` optimizer steps"""
     dev = torch.device("cuda:0")
