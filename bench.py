@@ -312,13 +312,14 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax)
     fused = bool(optimizer._usable()) if optimizer_name == "cris" else None
+    inner = model.module if hasattr(model, "module") else model
     if own_pg:
         dist.destroy_process_group()
     if not emit:
         return {"ms_per_step": 1000.0 * dt / steps, "samples_per_s": world * args.batch * steps / dt, "steps": steps,
                 "optimizer": "cris.pytorch_amd.optim.Adam" if optimizer_name == "cris" else "torch.optim.Adam", "fused_update": fused,
                 "ddp_one_rank": bool(own_pg), "replay": os.environ.get("CRIS_MODULE_REPLAY", "graph"), "final_loss": r[0],
-                "graph_error": getattr(model.module if hasattr(model, "module") else model, "graph_error", None)}
+                "graph_error": getattr(inner, "graph_error", None)}
     phase_ms = None
     if args.phase_times and marks:
         # per phase: host time spent in it, and device time between the events recorded at its two ends (the device works
@@ -344,7 +345,11 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
                                    % ("; SyncBatchNorm + DistributedDataParallel" if world > 1 else "", args.size, args.size, args.batch, word_len),
                        "path": "module", "replay": os.environ.get("CRIS_MODULE_REPLAY", "graph"), "optimizer": "cris.pytorch_amd.optim.Adam (fused update: %s)" % fused if optimizer_name == "cris" else "torch.optim.Adam", "ddp_one_rank": bool(own_pg),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first,
-                       "final_loss": r[0], "grad_scale": float(scaler.get_scale())},
+                       "final_loss": r[0], "grad_scale": float(scaler.get_scale()),
+                       "graph_error": getattr(inner, "graph_error", None), "syncbn_exchange": getattr(inner, "syncbn_exchange", None),
+                       "own_gradient_exchange": bool(getattr(inner, "_self_exchange", False)),
+                       "gradient_exchange_in_this_run": inner._exchange_comm_for_this_step() is not None,
+                       "ddp_managed_parameters": len(model._module_parameters) if hasattr(model, "_module_parameters") else None},
             "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12)}})
     if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
@@ -365,7 +370,8 @@ def module_path_subprocess(args, optimizer_name):
     d = json.loads(lines[0])                           # (a line that was printed is a finished measurement, whatever the teardown did)
     return {"ms_per_step": d["ms_per_step"], "samples_per_s": d["value"], "steps": d["steps"], "optimizer": d["config"]["optimizer"],
             "ddp_one_rank": d["config"].get("ddp_one_rank"), "replay": d["config"].get("replay"), "final_loss": d["config"].get("final_loss"),
-            "own_process": True, "exit_code": r.returncode}
+            "own_process": True, "exit_code": r.returncode, "graph_error": d["config"].get("graph_error"),
+            "own_gradient_exchange": d["config"].get("own_gradient_exchange"), "ddp_managed_parameters": d["config"].get("ddp_managed_parameters")}
 
 
 def main():

@@ -318,8 +318,9 @@ class CRIS(nn.Module):
         self._engine_fast_key = fk
         params = {n: p.data for n, p in self.named_parameters()}
         buffers = {n: b for n, b in self.named_buffers() if n.endswith(("running_mean", "running_var"))}
+        # (CRIS_FORCE_DIST=1: the multi-rank code paths with a world of one - what one GPU can run of them under RCCL)
         sync = (any(isinstance(m, nn.SyncBatchNorm) for m in self.modules()) and dist.is_available()
-                and dist.is_initialized() and dist.get_world_size() > 1)
+                and dist.is_initialized() and (dist.get_world_size() > 1 or debug.HOOKS.force_dist))
         # gradient-view mode (cris.pytorch_amd.optim.Adam bound): also under a process group / DistributedDataParallel - there
         # `.grad` is DDP's averaged gradient in its own tensor, which the optimizer copies into the arena views before its
         # fused update (optim.Adam.step)

@@ -133,3 +133,33 @@ def test_rccl_collectives_inside_the_captured_graph():
         assert "inside the BatchNorm launches" in m.group(4), line[0]
         got[mode] = (m.group(5), m.group(6))
     assert got["graph"] == got["cmdlist"] == got["eager"], got
+
+
+def test_rccl_drop_in_module_under_ddp_with_the_multi_rank_paths_forced():
+    """The drop-in module under the reference's recipe (one-rank RCCL group + SyncBatchNorm + DistributedDataParallel, bench.py
+    --path module --ddp-one-rank) with CRIS_FORCE_DIST=1: what one GPU can run of the N-rank module path - the module's own
+    gradient exchange (eight all-reduces on their own communicator and stream) captured INSIDE the backward HIP graph while
+    DistributedDataParallel's process group and its c10d watchdog are alive, SyncBatchNorm's statistics through the peer
+    mailboxes inside the BatchNorm launches of both captured graphs.  Against the same command without the switch (no exchange
+    at a world of one): no capture error, the same losses up to the rounding of the single-exchange statistics."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    recs = {}
+    for forced in (True, False):
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "CRIS_FORCE_DIST")}
+        if forced:
+            env["CRIS_FORCE_DIST"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--path", "module", "--ddp-one-rank", "--optimizer", "cris",
+                            "--steps", "4", "--warmup", "3"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert r.returncode == 0 and lines, "rc %d\n%s\n...\n%s" % (r.returncode, r.stderr[:2000], r.stderr[-1500:])
+        recs[forced] = json.loads(lines[0])["config"]
+    f, p = recs[True], recs[False]
+    print("forced", f, "plain", p)
+    assert f["graph_error"] is None and p["graph_error"] is None
+    assert f["own_gradient_exchange"] and f["gradient_exchange_in_this_run"] and f["ddp_managed_parameters"] == 1
+    assert p["own_gradient_exchange"] and not p["gradient_exchange_in_this_run"]
+    assert "inside the BatchNorm launches" in f["syncbn_exchange"], f["syncbn_exchange"]
+    assert abs(f["first_loss"] - p["first_loss"]) < 2e-3 and abs(f["final_loss"] - p["final_loss"]) < 2e-2, (f, p)

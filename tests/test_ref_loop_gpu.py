@@ -198,6 +198,7 @@ def _grad_worker(rank, world, port, q, self_exchange, optimizer_name):
         # only pick up while this process is alive)
         acc = torch.cat([p.grad.detach().float().flatten() for n, p in inner.named_parameters() if p.grad is not None]).cpu().numpy()
         out["self_exchange"] = bool(getattr(inner, "_self_exchange", False))
+        out["syncbn_exchange"] = getattr(inner, "syncbn_exchange", None)
         torch.cuda.synchronize()
         sd = inner.state_dict()
         out["probe"] = {k: sd[k].double().sum().item() for k in PROBES}
@@ -228,6 +229,8 @@ def test_own_gradient_exchange_under_ddp_equals_ddp_managed_gradients_bit_for_bi
     (_, o0, a0), (_, o1, a1) = own
     (_, d0, b0), (_, d1, b1) = ddp
     assert o0["self_exchange"] and o1["self_exchange"] and not d0["self_exchange"]
+    # (round 6: the drop-in module's SyncBN statistics travel through the peer mailboxes, inside the BatchNorm launches)
+    assert "p2p mailboxes" in o0["syncbn_exchange"] and "p2p mailboxes" in d0["syncbn_exchange"], (o0["syncbn_exchange"], d0["syncbn_exchange"])
     assert o0["managed_by_ddp"] == 1 and d0["managed_by_ddp"] > 100, (o0["managed_by_ddp"], d0["managed_by_ddp"])
     print("own", o0["losses"], "ddp", d0["losses"])
     # every rank holds the same averaged gradient, and it is the one DDP's reducer produces - the same bits, every step (the
