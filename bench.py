@@ -227,6 +227,7 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
     word_len = args.word_len if args.word_len is not None else (22 if args.size == 480 else 17)
     cfg = NS(clip_pretrain="synthetic", word_len=word_len, fpn_in=[512, 1024, 1024], fpn_out=[256, 512, 1024], num_layers=3, vis_dim=512,
              num_head=8, dim_ffn=2048, dropout=0.1, intermediate=False, word_dim=1024, base_lr=1e-4, lr_multi=0.1, sync_bn=True)
+    torch.manual_seed(1234)                                                               # (train.py:56-57 seeds from the yaml: the head is randomly initialised)
     model, param_list = build_segmenter(cfg)                                              # train.py:96
     if world > 1 or own_pg:
         model = nn.SyncBatchNorm.convert_sync_batchnorm(model)                             # train.py:97-98
