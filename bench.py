@@ -569,7 +569,7 @@ def main():
                 except Exception:               # noqa: BLE001
                     pass
             # where the parity measurements of this path are (a pointer, not a measurement of this run)
-            out["config"]["parity"] = "profiles/parity_r05.md (float64-teacher teacher-forced runs of configs[1] / [3] / [4] inside pytest -m gpu), profiles/parity_r04.md (per-stage bf16 error budget), tests/test_parity_long_gpu.py"
+            out["config"]["parity"] = "profiles/parity_r05.md + profiles/r06/teacher_forced_r50_fp64_call_e_final.json (float64-teacher TEACHER-FORCED runs of configs[1] / [3] / [4] inside pytest -m gpu: mean abs(dloss) over the 100 states of configs[1] 9.15e-4, bound 1.0e-3; the free-running curve is gpu_long and is NOT within 1e-3), profiles/parity_r04.md (per-stage bf16 error budget), tests/test_parity_long_gpu.py, tests/golden/grad_cos_r50_config1.json (ten worst gradient tensors, +-0.02 bands)"
             out["roofline"]["timing"] = "HIP events around each launch, %d-step eager pass after the timed region" % timer_steps
             out["kernels"] = {k: {"ms_per_step": v["ms"] / timer_steps, "tflops": v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                   "launches_per_step": v["launches"] / timer_steps} for k, v in summ.items()}
