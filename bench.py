@@ -522,7 +522,7 @@ def main():
                                       "" if world == 1 else "; x%d GPUs = configs[2] recipe: SyncBN + gradient all-reduce over RCCL" % world),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first_loss, "final_loss": loss_v,
                        "launch": tr.launch, "graph_captured": tr._graph is not None, "graph_error": tr.graph_error,
-                       "syncbn_exchange": tr.syncbn_exchange, "comm": type(comm).__name__ if comm is not None else None,
+                       "syncbn_exchange": tr.syncbn_exchange, "grad_exchange": tr.grad_exchange, "comm": type(comm).__name__ if comm is not None else None,
                        "syncbn_peer_timeout": (bool(int(comm.p2p.err.item())) if getattr(comm, "p2p", None) is not None else None),
                        "source_commit": (open(os.path.join(ROOT, ".source_commit")).read().strip()
                                          if os.path.exists(os.path.join(ROOT, ".source_commit")) else None),

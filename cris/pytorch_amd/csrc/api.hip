@@ -33,6 +33,7 @@ extern "C" int cris_sizeof(const char* name) {
     S(cris_adam_desc);
     S(cris_p2p_params);
     S(cris_p2p_link);
+    S(cris_p2p_arena_params);
     S(cris_zero_ranges);
     S(cris_sample_desc);
     S(cris_jpeg_info);

@@ -196,3 +196,142 @@ extern "C" int cris_p2p_ll_allreduce_sum(const cris_p2p_link* lp, float* data, i
     CRIS_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------------
+// Gradient exchange over the peer-mapped gradient arenas (include/cris_hip.h: cris_p2p_arena_allreduce; opt-in).
+//
+// xGMI on an 8 x MI355X node is a full mesh of point-to-point links: a ring all-reduce is bound by ONE link per hop, a direct
+// exchange uses all seven at once.  Two-shot form, in place, over 8-byte words (two floats):
+//   reduce-scatter  rank r owns slice r of the range; for every word of its slice it reads the word from every rank's arena in
+//                   RANK ORDER (its own through the local pointer, the peers' through their IPC mappings: system-scope loads,
+//                   nothing of a remote arena may be served from this GPU's L2) and stores the sum into its own arena with a
+//                   system-scope store (written through: the peers read it next);
+//   all-gather      every rank copies the other ranks' reduced slices into its own arena.
+// Every element is summed once, on its owner, in one fixed order: all ranks end with the same bits, and the same bits as a
+// sequential sum over the ranks (tests/test_p2p_gpu.py).  Barriers = one LL word per (rank, barrier) in the peer mailboxes
+// (p2p_ll.h): written by block 0, polled by one thread of every block.
+//   ready    before a peer's arena is read: its backward has issued the range (kernels of one stream run in order, and a
+//            kernel's end writes its stores back to memory);
+//   reduced  before a reduced slice is read;
+//   done     before the arena may be overwritten (the next backward) every peer has finished reading - waited for by the third
+//            launch, so the exchange as a whole is complete when its last kernel is.
+// ------------------------------------------------------------------------------------------------------------------------
+#define ARENA_U 4                       // words in flight per thread and peer
+
+__device__ __forceinline__ unsigned long long arena_load_sys(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void arena_store_sys(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// announce (block 0) and wait for every rank's word of barrier `which` of this exchange; returns false when a peer is missing
+__device__ __forceinline__ bool arena_barrier(const cris_p2p_arena_params& p, int which, int* s_bad) {
+    if (threadIdx.x == 0) {
+        cris_p2p_link L = p.link;
+        L.slot = p.link.slot + which;
+        const int gen = p2p_link_gen(L);
+        if (blockIdx.x == 0) p2p_ll_send(L, gen, 0, 0.f);
+        bool bad = false;
+        (void)p2p_ll_recv_sum(L, gen, 0, bad);
+        *s_bad = bad ? 1 : 0;
+        if (bad && L.err) L.err[0] = 1;
+    }
+    __syncthreads();
+    return *s_bad == 0;
+}
+// words [w0, w1) of the range that rank q owns
+__device__ __forceinline__ void arena_slice(long words, int world, int q, long& w0, long& w1) {
+    const long chunk = (words + world - 1) / world;
+    w0 = min(words, (long)q * chunk);
+    w1 = min(words, w0 + chunk);
+}
+
+__global__ __launch_bounds__(256) void p2p_arena_reduce_scatter_kernel(const cris_p2p_arena_params p) {
+    __shared__ int s_bad;
+    const bool ok = arena_barrier(p, 0, &s_bad);
+    const int W = p.link.world, r = p.link.rank;
+    long w0, w1;
+    arena_slice(p.n >> 1, W, r, w0, w1);
+    unsigned long long* mine = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(p.arenas[r]) + p.lo);
+    const long stride = (long)gridDim.x * 256;
+    if (!ok) {                                       // a missing peer must not pass silently: this rank's slice becomes NaN
+        for (long i = w0 + (long)blockIdx.x * 256 + threadIdx.x; i < w1; i += stride) mine[i] = 0x7fc000007fc00000ull;
+        return;
+    }
+    for (long i0 = w0 + (long)blockIdx.x * 256 + threadIdx.x; i0 < w1; i0 += stride * ARENA_U) {
+        float ax[ARENA_U], ay[ARENA_U];
+#pragma unroll
+        for (int u = 0; u < ARENA_U; ++u) { ax[u] = 0.f; ay[u] = 0.f; }
+        for (int q = 0; q < W; ++q) {
+            const unsigned long long* src = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const float*>(p.arenas[q]) + p.lo);
+            unsigned long long w[ARENA_U];
+#pragma unroll
+            for (int u = 0; u < ARENA_U; ++u) {
+                const long i = min(i0 + u * stride, w1 - 1);
+                w[u] = q == r ? mine[i] : arena_load_sys(src + i);
+            }
+#pragma unroll
+            for (int u = 0; u < ARENA_U; ++u) {
+                ax[u] += __uint_as_float((unsigned)w[u]);
+                ay[u] += __uint_as_float((unsigned)(w[u] >> 32));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < ARENA_U; ++u) {
+            const long i = i0 + u * stride;
+            if (i < w1) arena_store_sys(mine + i, ((unsigned long long)__float_as_uint(ay[u]) << 32) | (unsigned long long)__float_as_uint(ax[u]));
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void p2p_arena_all_gather_kernel(const cris_p2p_arena_params p) {
+    __shared__ int s_bad;
+    if (!arena_barrier(p, 1, &s_bad)) return;
+    const int W = p.link.world, r = p.link.rank;
+    const long words = p.n >> 1;
+    unsigned long long* mine = reinterpret_cast<unsigned long long*>(reinterpret_cast<float*>(p.arenas[r]) + p.lo);
+    const long stride = (long)gridDim.x * 256;
+    for (int d = 1; d < W; ++d) {
+        const int q = (r + d) % W;                   // every rank starts with a different peer: all links busy from the start
+        long w0, w1;
+        arena_slice(words, W, q, w0, w1);
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(reinterpret_cast<const float*>(p.arenas[q]) + p.lo);
+        for (long i0 = w0 + (long)blockIdx.x * 256 + threadIdx.x; i0 < w1; i0 += stride * ARENA_U) {
+            unsigned long long w[ARENA_U];
+#pragma unroll
+            for (int u = 0; u < ARENA_U; ++u) w[u] = arena_load_sys(src + min(i0 + u * stride, w1 - 1));
+#pragma unroll
+            for (int u = 0; u < ARENA_U; ++u) {
+                const long i = i0 + u * stride;
+                if (i < w1) mine[i] = w[u];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void p2p_arena_done_kernel(const cris_p2p_arena_params p) {
+    __shared__ int s_bad;
+    (void)arena_barrier(p, 2, &s_bad);
+}
+
+extern "C" int cris_p2p_arena_allreduce(const cris_p2p_arena_params* pp, void* stream) {
+    CRIS_CHECK_ARG(pp && pp->arenas && pp->link.boxes, "null operand");
+    const cris_p2p_arena_params& p = *pp;
+    const cris_p2p_link& l = p.link;
+    CRIS_CHECK_ARG(l.world >= 1 && l.world <= 64 && l.rank >= 0 && l.rank < l.world, "rank / world");
+    CRIS_CHECK_ARG(l.slot >= 0 && l.slot + 3 <= l.slots && l.max_floats >= 1, "three barrier slots out of the mailbox geometry");
+    CRIS_CHECK_ARG(p.n > 0 && (p.n & 1) == 0 && p.lo >= 0 && (p.lo & 1) == 0, "range: lo and n must be even");
+    static const int def_blocks = cris_env_int("CRIS_P2P_ARENA_BLOCKS", 64);
+    int blocks = p.blocks > 0 ? p.blocks : def_blocks;
+    const long per_rank = ((p.n >> 1) + l.world - 1) / l.world;
+    const int need = (int)((per_rank + 256L * ARENA_U - 1) / (256L * ARENA_U));
+    if (blocks > need) blocks = need > 0 ? need : 1;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(p2p_arena_reduce_scatter_kernel, dim3(blocks), dim3(256), 0, s, p);
+    CRIS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(p2p_arena_all_gather_kernel, dim3(blocks), dim3(256), 0, s, p);
+    CRIS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(p2p_arena_done_kernel, dim3(1), dim3(64), 0, s, p);
+    CRIS_LAUNCH_CHECK();
+    return 0;
+}

@@ -129,6 +129,9 @@ class TorchDistComm:
         self.grad_group = dist.new_group(ranks=list(range(self.world)))
         self.capturable = dist.get_backend() == "nccl"       # RCCL kernels can be captured into a HIP graph; gloo cannot
         self.p2p, self._gen_dev, self._slot, self._fused = None, None, 0, False
+        self._arena, self._arena_ptrs, self._arena_slot0, self._arena_calls, self._arena_opened = None, None, 0, 0, []
+
+    ARENA_STAGES = 10         # gradient-arena exchanges per step the mailbox reserves barrier slots for (three each; the engine has eight stages)
 
     def enable_p2p(self, slots, max_floats, gen_dev):
         """Route the SyncBN exchanges through peer mailboxes; `gen_dev` = the trainer's device counter of exchange generations (advances with every step, never rewound - unlike the optimizer step).  Collective: every
@@ -139,7 +142,9 @@ class TorchDistComm:
         import os
         box, err, handle = None, None, None
         try:
-            box = PeerMailboxes(self.rank, self.world, self.device, slots + 1, max_floats)     # (+1: the self-test's slot)
+            # (+ the barrier slots of the opt-in arena exchange, + 1: the self-test's slot, which is the last one)
+            box = PeerMailboxes(self.rank, self.world, self.device, slots + 3 * self.ARENA_STAGES + 1, max_floats)
+            self._arena_slot0 = slots
             handle = box.alloc_and_export()
         except Exception as ex:              # noqa: BLE001 - e.g. no fine-grained memory, no IPC export
             err = "rank %d: %r" % (self.rank, ex)
@@ -167,6 +172,96 @@ class TorchDistComm:
         self._fused = os.environ.get("CRIS_SYNCBN_FUSED", "1") == "1"
         return None
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # opt-in (CRIS_GRAD_EXCHANGE=p2p): the gradient all-reduce as a direct reduce-scatter + all-gather over the peer-mapped
+    # gradient arenas (csrc/p2p.hip, include/cris_hip.h cris_p2p_arena_allreduce) instead of RCCL - every rank reads from all
+    # peers at once (xGMI is a full mesh of point-to-point links), every element is summed once, on its owner, in rank order.
+    # Never run on more than one GPU: correct by construction and bit-exact against a sequential sum with 2 / 4 / 8 ranks
+    # sharing one device (tests/test_p2p_gpu.py), which says nothing about the links - hence not the default.
+    # ------------------------------------------------------------------------------------------------------------------
+    def enable_arena_exchange(self, arena):
+        """Collective (the same sequence of host all-gathers on every rank whatever fails locally).  Maps every rank's `arena`
+        (flat fp32 tensor, the same size everywhere) into this process and self-tests the exchange on a small range.  Returns
+        None when allreduce_async() will take the direct path for ranges of `arena`, else the reason it will not."""
+        if self.p2p is None:
+            return "no peer mailboxes"
+        lib, hip = self.p2p.lib, self.p2p.hip
+        err, handle = None, None
+        try:
+            assert arena.dtype == torch.float32 and arena.is_contiguous() and arena.data_ptr() % 8 == 0
+            h = (ctypes.c_ubyte * 64)()
+            hip.check(lib.cris_p2p_export(ctypes.c_void_p(arena.data_ptr()), h), "cris_p2p_export(arena)")
+            handle = bytes(h)
+        except Exception as ex:              # noqa: BLE001
+            err = "rank %d: %r" % (self.rank, ex)
+        got = self.all_gather_object((err, handle, int(arena.numel())))
+        errs = [e for e, _, _ in got if e]
+        if not errs and any(n != got[0][2] for _, _, n in got):
+            errs = ["arena sizes differ across ranks: %s" % [n for _, _, n in got]]
+        ptrs, opened = [], []
+        if not errs:
+            try:
+                for q, (_, hq, _) in enumerate(got):
+                    if q == self.rank:
+                        ptrs.append(arena.data_ptr())
+                        continue
+                    peer = ctypes.c_void_p()
+                    hip.check(lib.cris_p2p_import((ctypes.c_ubyte * 64).from_buffer_copy(hq), ctypes.byref(peer)), "cris_p2p_import(arena)")
+                    opened.append(peer.value)
+                    ptrs.append(peer.value)
+            except Exception as ex:          # noqa: BLE001
+                err = "rank %d: %r" % (self.rank, ex)
+        errs = errs or [e for e in self.all_gather_object(err) if e]
+        ok = False
+        if not errs:
+            self._arena, self._arena_ptrs = arena, torch.tensor(ptrs, dtype=torch.int64, device=arena.device)
+            ok = self._arena_self_test()
+            errs = ["rank %d: arena exchange self-test failed" % q for q, o in enumerate(self.all_gather_object(ok)) if not o]
+        if errs:
+            self._arena, self._arena_ptrs = None, None
+            for p_ in opened:
+                try:
+                    lib.cris_p2p_close(p_)
+                except Exception:            # noqa: BLE001
+                    pass
+            return "; ".join(errs)[:300]
+        self._arena_opened = opened
+        return None
+
+    def _arena_launch(self, lo, n, slot, gen_dev=None, gen_host=0, spin_limit=0):
+        prm = self.p2p.hip.P2PArenaParams()
+        prm.arenas, prm.lo, prm.n, prm.blocks = self._arena_ptrs.data_ptr(), lo, n, 0
+        l = self.p2p.link(slot, gen_dev=gen_dev, gen_host=gen_host, spin_limit=spin_limit)
+        prm.link = l
+        self.p2p.hip.check(self.p2p.lib.cris_p2p_arena_allreduce(ctypes.byref(prm), torch.cuda.current_stream().cuda_stream),
+                           "cris_p2p_arena_allreduce")
+
+    def _arena_self_test(self, spin_limit=1 << 21):
+        """two generations of the exchange on the arena's first words with known data (rank q contributes q + 1 + i / 7, then twice
+        that): the result must be the sequential sum over the ranks, bit for bit, and no peer may be reported missing.  The words
+        are restored afterwards (the exchange's last barrier says that every peer has finished reading them)."""
+        a = self._arena
+        n = min(int(a.numel()) & ~1, 4096)
+        if n < 2:
+            return False
+        keep = a[:n].clone()
+        idx = torch.arange(n, device=a.device, dtype=torch.float32) / 7.0
+        ok = True
+        for t in range(2):
+            a[:n] = (float(self.rank + 1) + idx) * float(t + 1)
+            torch.cuda.synchronize()
+            self.all_gather_object(0)                          # every rank's pattern is in place before anybody reads
+            self._arena_launch(0, n, self._arena_slot0, gen_host=3000 + t, spin_limit=spin_limit)
+            torch.cuda.synchronize()
+            want = torch.zeros(n, device=a.device)
+            for q in range(self.world):
+                want = want + (float(q + 1) + idx) * float(t + 1)
+            ok = ok and bool(torch.equal(a[:n], want)) and int(self.p2p.err.item()) == 0
+        a[:n] = keep
+        torch.cuda.synchronize()
+        self.p2p.err.zero_()
+        return ok
+
     def check_peer_timeout(self):
         """COLLECTIVE (host all-gather; every rank must call it, e.g. at a logging interval or an epoch boundary - it costs one
         device synchronisation): raises RuntimeError on EVERY rank when a mailbox exchange of ANY rank gave up waiting for a peer
@@ -190,6 +285,7 @@ class TorchDistComm:
 
     def begin_step(self):
         self._slot = 0
+        self._arena_calls = 0
 
     def allreduce_sum_op(self, t):
         if self.p2p is None:
@@ -215,6 +311,21 @@ class TorchDistComm:
     # gradient exchange: overlapped
     def allreduce_async(self, t, op="sum"):
         rop = dist.ReduceOp.SUM if op == "sum" else dist.ReduceOp.MAX
+        a = getattr(self, "_arena", None)
+        if a is not None and op == "sum" and t.dtype == torch.float32 and t.is_contiguous() and self.side is not None:
+            # a range of the mapped gradient arena: the direct exchange (three launches on the side stream, no c10d work).  The
+            # decision depends on the range and the call count only - identical on every rank
+            lo = (t.data_ptr() - a.data_ptr()) // 4
+            n = int(t.numel())
+            if 0 <= lo and lo + n <= a.numel() and lo % 2 == 0 and n % 2 == 0 and n > 0 and self._arena_calls < self.ARENA_STAGES:
+                slot = self._arena_slot0 + 3 * self._arena_calls      # exchange number inside the step, fixed at schedule time
+                self._arena_calls += 1
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.side.wait_event(ev)
+                with torch.cuda.stream(self.side):
+                    self._arena_launch(lo, n, slot, gen_dev=self._gen_dev)
+                return
         if self.side is None:
             self._pending.append(dist.all_reduce(t, op=rop, group=self.grad_group, async_op=True))
             return

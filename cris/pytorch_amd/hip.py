@@ -216,10 +216,14 @@ class P2PLink(C.Structure):
                 ("slot", I), ("slots", I), ("max_floats", I), ("spin_limit", I)]
 
 
+class P2PArenaParams(C.Structure):
+    _fields_ = [("arenas", P), ("lo", C.c_long), ("n", C.c_long), ("link", P2PLink), ("blocks", I)]
+
+
 STRUCTS = {
     "cris_conv_gemm_params": ConvGemmParams, "cris_conv_gemm_group": ConvGemmGroup, "cris_wgrad_params": WgradParams, "cris_wgrad_group": WgradGroup, "cris_pack_desc": PackDesc,
     "cris_bn_apply_params": BnApplyParams, "cris_bn_bwd_params": BnBwdParams, "cris_ln_fwd_params": LnFwdParams,
-    "cris_ln_bwd_params": LnBwdParams, "cris_sum_entry": SumEntry, "cris_sum_group": SumGroup, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams, "cris_p2p_link": P2PLink, "cris_zero_ranges": ZeroRanges,
+    "cris_ln_bwd_params": LnBwdParams, "cris_sum_entry": SumEntry, "cris_sum_group": SumGroup, "cris_attn_params": AttnParams, "cris_adam_desc": AdamDesc, "cris_p2p_params": P2PParams, "cris_p2p_link": P2PLink, "cris_p2p_arena_params": P2PArenaParams, "cris_zero_ranges": ZeroRanges,
     "cris_sample_desc": SampleDesc, "cris_jpeg_info": JpegInfo, "cris_jpeg_image": JpegImage,
 }
 
@@ -324,6 +328,7 @@ _SIGS = {
     "cris_p2p_close": (I, [P]),
     "cris_p2p_allreduce_sum": (I, [P, P]),
     "cris_p2p_ll_allreduce_sum": (I, [P, P, I, P]),
+    "cris_p2p_arena_allreduce": (I, [P, P]),
     "cris_bn_finalize_sync": (I, [P, P, I, I, F, F, P, P, P, P, F, F, I, P, P, P, P, P, P]),
     "cris_bn_bwd_reduce_sync": (I, [P, P, P, P]),
     "cris_bn_bwd_sum": (I, [P, I, P]),

@@ -188,6 +188,7 @@ class CRIS(nn.Module):
         self._self_exchange = False         # decided per engine (_ensure_engine)
         self._ddp_synced = False
         self._xgen_dev, self.syncbn_exchange = None, "none"
+        self.grad_exchange = "rccl"
 
     # ------------------------------------------------------------------------------------------------
     # SURVEY.md 8e option B - the gradient exchange under the reference's DistributedDataParallel wrap (train.py:100-102).
@@ -357,6 +358,8 @@ class CRIS(nn.Module):
             if why is None:
                 self.syncbn_exchange = ("p2p mailboxes, exchanged inside the BatchNorm launches" if getattr(comm, "_fused", False)
                                         else "p2p mailboxes, one exchange kernel per BatchNorm")
+                if os.environ.get("CRIS_GRAD_EXCHANGE", "rccl") == "p2p":      # opt-in: the direct exchange over the mapped arenas
+                    self.grad_exchange = comm.enable_arena_exchange(e_.grad_arena) or "p2p"
             else:
                 self._xgen_dev, self.syncbn_exchange = None, "collective (mailboxes refused: %s)" % why
         # parameter-layout gradient buffers for the tensors whose HIP gradient lives in the GEMM layout

@@ -109,6 +109,15 @@ class NativeTrainer:
                 self.syncbn_exchange = "p2p mailboxes, exchanged inside the BatchNorm launches" if fused else "p2p mailboxes, one exchange kernel per BatchNorm"
             else:
                 self.syncbn_exchange = "collective (mailboxes refused: %s)" % why
+        # gradient exchange: RCCL through torch.distributed (the default: eight staged all-reduces on their own communicator and
+        # stream); CRIS_GRAD_EXCHANGE=p2p: the direct reduce-scatter + all-gather over the peer-mapped gradient arenas
+        # (dist.TorchDistComm.enable_arena_exchange) when mapping and self-test succeed on every rank, else RCCL
+        self.grad_exchange = "none" if (self.comm.world == 1 and not debug.HOOKS.force_dist) else "rccl"
+        if (os.environ.get("CRIS_GRAD_EXCHANGE", "rccl") == "p2p" and getattr(self.comm, "p2p", None) is not None
+                and hasattr(self.comm, "enable_arena_exchange")):
+            why = self.comm.enable_arena_exchange(e.grad_arena)
+            self.grad_exchange = ("p2p: reduce-scatter + all-gather over the peer-mapped gradient arenas" if why is None
+                                  else "rccl (arena exchange refused: %s)" % why)
         if launch is None:
             launch = os.environ.get("CRIS_LAUNCH")
         if launch is None:

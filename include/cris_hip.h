@@ -568,6 +568,26 @@ int cris_bn_bwd_reduce_sync(const cris_bn_bwd_params* p, float* local_sums, cons
 /* nparts > 0: the partial rows are already in p->part (cris_bn_bwd_sum's case), only the summation + exchange launch runs */
 int cris_bn_bwd_sum_sync(const cris_bn_bwd_params* p, int nparts, float* local_sums, const cris_p2p_link* link, void* stream);
 
+/* ---- Gradient exchange over the peer-mapped gradient arenas (csrc/p2p.hip; opt-in: CRIS_GRAD_EXCHANGE=p2p) ---------------
+ * What DistributedDataParallel's bucketed all-reduce does for the reference (train.py:100-102), as SURVEY.md section 5 / 8e asks
+ * for it on a fully connected xGMI node: a direct reduce-scatter + all-gather in which every rank talks to all seven peers at once,
+ * instead of RCCL's schedule.  Every rank's gradient arena (one flat fp32 tensor) is mapped into every other process (HIP-IPC);
+ * for one range [lo, lo + n) of the arena, in place:
+ *   launch 1  barrier "my gradients of this range are final" - then rank r sums slice r of the range over the ranks IN RANK ORDER
+ *             (reads of the peers' arenas over the links, bit-identical results on every rank, no atomics) into its own arena;
+ *   launch 2  barrier "my slice is reduced" - then every rank copies the other ranks' reduced slices into its own arena;
+ *   launch 3  barrier "I have finished reading" - returns when every peer has: the arena may be written again.
+ * The barriers are LL words of the peer mailboxes (cris_p2p_link; three consecutive slots per exchange, generation = the step).
+ * All three launches go to `stream` (the communicator's side stream: the exchange overlaps the rest of backward) and can be
+ * captured into a HIP graph.  A peer that never arrives: bounded poll, link.err set, this rank's slice poisoned with NaN. */
+typedef struct {
+    void* const* arenas;      /* DEVICE array [world]: base address of every rank's arena as mapped in THIS process (own: its own) */
+    long lo, n;               /* range in floats; both even (8-byte words travel) */
+    cris_p2p_link link;       /* link.slot = the first of this exchange's three barrier slots */
+    int blocks;               /* blocks per launch, 0 = default */
+} cris_p2p_arena_params;
+int cris_p2p_arena_allreduce(const cris_p2p_arena_params* p, void* stream);
+
 /* ---- Data-parallel exchanges on library-owned RCCL communicators (csrc/comm.hip) ---------------------------------------
  * What the reference gets from `dist.init_process_group("nccl")` + `DistributedDataParallel` + `SyncBatchNorm`
  * (train.py:80-102; SURVEY.md 8b "comm entry points"), without torch.distributed on the data path.  One cris_comm per

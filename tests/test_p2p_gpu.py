@@ -136,6 +136,61 @@ def test_peer_that_never_arrives_raises_on_every_rank(world):
             assert flagged and poisoned, res
 
 
+def _arena_worker(rank, world, port, q):
+    """the opt-in gradient exchange over the peer-mapped arenas (cris_p2p_arena_allreduce): an "arena" of odd size sub-allocated
+    by torch's caching allocator (an interior pointer of its block - what a small model's arena is), three steps x four ranges
+    (a tiny one, one smaller than the world's slices, a large one, the unaligned tail), device generation counter"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cris.pytorch_amd.dist import TorchDistComm
+        dev = torch.device("cuda:0")
+        torch.cuda.set_device(dev)
+        comm = TorchDistComm(dev)
+        gen = torch.zeros(1, dtype=torch.int32, device=dev)
+        assert comm.enable_p2p(slots=2, max_floats=64, gen_dev=gen) is None
+        pad = torch.empty(12345, device=dev)                     # noqa: F841 - pushes the arena off the start of its block
+        N = 1_500_002
+        arena = torch.zeros(N, device=dev)
+        why = comm.enable_arena_exchange(arena)
+        assert why is None, why
+        ranges = [(0, 2), (10, 6), (1000, 1_200_000), (1_300_000, 200_002)]
+        ok = True
+        for step in range(3):
+            gen.fill_(step + 10)
+            g = torch.Generator().manual_seed(step)
+            full = torch.randn(world, N, generator=g)
+            arena.copy_(full[rank])
+            torch.cuda.synchronize()
+            dist.barrier()
+            comm.begin_step()
+            for lo, n in ranges:
+                comm.allreduce_async(arena[lo:lo + n])
+            comm.wait_all()
+            torch.cuda.synchronize()
+            want = full[rank].clone()
+            for lo, n in ranges:
+                acc = full[0, lo:lo + n].clone()
+                for r in range(1, world):
+                    acc = acc + full[r, lo:lo + n]               # rank order, like the kernel
+                want[lo:lo + n] = acc
+            ok = ok and torch.equal(arena.cpu(), want)            # exchanged ranges: the rank-order sum; everything else untouched
+            dist.barrier()
+        ok = ok and int(comm.p2p.err.item()) == 0 and comm._arena_calls == len(ranges)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [pytest.param(2, marks=gpu), pytest.param(4, marks=gpu), pytest.param(8, marks=pytest.mark.gpu_long)])
+def test_arena_gradient_exchange_ranks_share_one_gpu(world):
+    """direct reduce-scatter + all-gather over the IPC-mapped arenas: every rank ends with the sum taken in RANK ORDER, bit for
+    bit, in place, and nothing outside the exchanged ranges changes"""
+    res = _spawn(_arena_worker, world)
+    assert all(ok for _, ok in res), res
+
+
 def _train_worker(rank, world, port, p2p, launch, steps, q):
     """p2p: False = exchange through torch.distributed; "kernel" = mailboxes, the exchange a kernel of its own between the
     BatchNorm launches (CRIS_SYNCBN_FUSED=0); True = mailboxes, the exchange inside the BatchNorm launches (the default)"""
@@ -152,9 +207,11 @@ def _train_worker(rank, world, port, p2p, launch, steps, q):
         torch.cuda.set_device(dev)
         clip, head = arch.specs_by_name("tiny")
         head = dataclasses.replace(head, dropout=0.0)      # mask indices are rank-local: compare without dropout
+        os.environ["CRIS_GRAD_EXCHANGE"] = "p2p" if p2p == "arena" else "rccl"
         tr = NativeTrainer(clip, head, arch.synthetic_state_dict(clip, head, 0), dev, comm=TorchDistComm(dev), sync_bn=True,
                            launch=launch)
         assert (tr.comm.p2p is not None) == bool(p2p)
+        assert tr.grad_exchange.startswith("p2p") == (p2p == "arena"), tr.grad_exchange
         losses = []
         for step in range(steps):
             img, word, mask = (t.to(dev) for t in synth.make_batch(4, 64, 9, rank, step))
@@ -188,7 +245,9 @@ def test_trainer_with_peer_mailboxes_equals_torch_distributed_exchange(launch, w
     comparison of tests/test_dist_gpu.py sees the same), so against it the losses are compared with that test's bound."""
     out = {}
     # (the stand-alone exchange kernel: eager, two ranks - its rank-order sums at world 4 / 8 are checked bit for bit by the primitive test)
-    modes = (False, "kernel", True) if (launch == "eager" and world == 2) else (False, True)
+    # ("arena": the default SyncBN form + the gradients through the direct exchange over the mapped arenas, CRIS_GRAD_EXCHANGE=p2p -
+    # two ranks: a + b has one order, so the whole run must equal the torch.distributed one bit for bit)
+    modes = (False, "kernel", True, "arena") if (launch == "eager" and world == 2) else (False, True)
     for p2p in modes:
         out[p2p] = _spawn(_train_worker, world, p2p, launch, steps, timeout=1200)
     for mode in modes[1:]:
