@@ -392,6 +392,10 @@ def main():
                     help="N > 1: torch = torch.distributed process groups (RCCL through c10d; the default: the only one that has run on "
                          "more than one rank - two ranks over gloo); native = dist.RcclComm, communicators owned by libcris_hip.so "
                          "(cris_comm_*: exercised with one rank only so far)")
+    ap.add_argument("--grad-exchange", default=None, choices=["rccl", "p2p"],
+                    help="N > 1: rccl = eight staged all-reduces through torch.distributed (the default); p2p = the direct reduce-scatter + "
+                         "all-gather over the peer-mapped gradient arenas (csrc/p2p.hip; sets CRIS_GRAD_EXCHANGE: opt-in, never run on "
+                         "more than one GPU)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo lets two ranks share one GPU in tests)")
     ap.add_argument("--shape-table", default=None, help="write the per-shape GEMM timing table (tsv) here")
     ap.add_argument("--path", default="native", choices=["native", "module"],
@@ -416,6 +420,8 @@ def main():
                          "line from rank 0) without touching a GPU - what tests/test_bench_launch.py runs on the CPU")
     args = ap.parse_args()
 
+    if args.grad_exchange is not None:
+        os.environ["CRIS_GRAD_EXCHANGE"] = args.grad_exchange
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))

@@ -137,10 +137,11 @@ __global__ __launch_bounds__(256) void p2p_allreduce_sum_kernel(const cris_p2p_p
     } else if ((int)threadIdx.x < p.world) {
         const int* flag = reinterpret_cast<const int*>(reinterpret_cast<float*>(p.boxes[p.rank]) + data_floats) + entry + threadIdx.x;
         long spins = 0;
-        const long limit = p.spin_limit > 0 ? (long)p.spin_limit : P2P_SPIN_LIMIT;
+        const long limit = (long)p.spin_limit;
+        const long long t0 = (long long)wall_clock64();
         while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != gen) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > limit) {
+            if (p2p_wait_expired(limit, ++spins, t0)) {
                 s_bad = 1;
                 break;
             }

@@ -17,7 +17,18 @@
 #include "common.h"
 #include "../../../include/cris_hip.h"
 
-#define P2P_SPIN_LIMIT (1L << 25)      // several seconds of polling: a peer that never arrives raises an error instead of hanging the GPU
+// A peer that never arrives raises an error instead of hanging the GPU.  The default limit is WALL TIME (round 6; it was a poll
+// count worth 5 - 30 s depending on the memory path, and four ranks time-slicing one GPU lost a peer to the start-up skew of the
+// first step - code objects load lazily, seconds per process - once in seven runs of tests/test_p2p_gpu.py): P2P_TIMEOUT_TICKS of
+// the constant 100 MHz counter (wall_clock64) = 120 s.  A positive spin_limit in the link / parameter block is still a poll
+// count (the start-up self-test and the missing-peer test use fractions of a second).
+#define P2P_SPIN_LIMIT (1L << 25)
+#define P2P_TIMEOUT_TICKS (120LL * 100000000LL)
+// true when the wait that began at `t0` (wall_clock64 ticks) with `spins` polls so far has to give up
+__device__ __forceinline__ bool p2p_wait_expired(long spin_limit, long spins, long long t0) {
+    if (spin_limit > 0) return spins > spin_limit;
+    return (spins & 1023) == 0 && (long long)wall_clock64() - t0 > P2P_TIMEOUT_TICKS;
+}
 
 static inline __host__ __device__ size_t p2p_flag_region_bytes(int world, int slots, int max_floats) {
     return ((size_t)2 * slots * world * max_floats + (size_t)2 * slots * world) * 4;
@@ -47,7 +58,7 @@ __device__ __forceinline__ void p2p_ll_send(const cris_p2p_link& L, int gen, int
 // sum over the ranks of value `idx`, added in rank order (the same order on every rank: bit-identical results everywhere);
 // a peer that never arrives within the poll limit sets `bad`
 __device__ __forceinline__ float p2p_ll_recv_sum(const cris_p2p_link& L, int gen, int idx, bool& bad) {
-    const long limit = L.spin_limit > 0 ? (long)L.spin_limit : P2P_SPIN_LIMIT;
+    const long limit = (long)L.spin_limit;
     // a peer already timed out in an EARLIER launch of this rank (the flag is only read here; kernels of one stream run in order):
     // do not wait again - one timeout, not one per exchange, until the host looks at the flag (the values are NaN from here on)
     if (L.err && L.err[0] != 0) {
@@ -59,9 +70,11 @@ __device__ __forceinline__ float p2p_ll_recv_sum(const cris_p2p_link& L, int gen
         const unsigned long long* src = p2p_ll_row(L, L.rank, q, gen) + idx;
         unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         long spins = 0;
+        long long t0 = 0;
         while ((unsigned)(w >> 32) != (unsigned)gen) {
+            if (spins == 0) t0 = (long long)wall_clock64();
             __builtin_amdgcn_s_sleep(2);
-            if (++spins > limit) {
+            if (p2p_wait_expired(limit, ++spins, t0)) {
                 bad = true;
                 break;
             }

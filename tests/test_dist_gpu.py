@@ -118,9 +118,11 @@ def test_rccl_collectives_inside_the_captured_graph():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for i, mode in enumerate(("graph", "cmdlist", "eager")):
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist1_check.py"), mode, "4"], env=env, stdout=subprocess.PIPE,
+    # ("graph+p2p": the same capture with the gradients through the opt-in direct exchange over the mapped arenas - 24 more kernel
+    # nodes instead of 8 RCCL collectives; at a world of one it must not change a bit)
+    for i, mode in enumerate(("graph", "cmdlist", "eager", "graph+p2p")):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), CRIS_GRAD_EXCHANGE="p2p" if mode.endswith("+p2p") else "rccl")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "dist1_check.py"), mode.split("+")[0], "4"], env=env, stdout=subprocess.PIPE,
                            stderr=subprocess.STDOUT, timeout=600)
         out = r.stdout.decode()
         line = [x for x in out.splitlines() if x.startswith("mode ")]
@@ -128,11 +130,12 @@ def test_rccl_collectives_inside_the_captured_graph():
         assert r.returncode == 0 and line, "rc %d\n%s\n...\n%s" % (r.returncode, out[:2000], out[-1000:])
         m = re.match(r"mode (\w+) -> launch (\w+) graph_error (.*?) syncbn (.*?) \| .* losses (\[.*?\]) \.\.\. ([0-9.]+)", line[0])
         assert m, line[0]
-        assert m.group(2) == mode and m.group(3) == "None", line[0]
+        assert m.group(2) == mode.split("+")[0] and m.group(3) == "None", line[0]
+        assert ("gradients: p2p" in line[0]) == mode.endswith("+p2p"), line[0]
         # (with a world of one the mailboxes are in use as well: the BatchNorm kernels exchange with themselves inside their launches)
         assert "inside the BatchNorm launches" in m.group(4), line[0]
         got[mode] = (m.group(5), m.group(6))
-    assert got["graph"] == got["cmdlist"] == got["eager"], got
+    assert got["graph"] == got["cmdlist"] == got["eager"] == got["graph+p2p"], got
 
 
 def test_rccl_drop_in_module_under_ddp_with_the_multi_rank_paths_forced():

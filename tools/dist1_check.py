@@ -37,7 +37,7 @@ for i in range(steps):
     loss, _ = tr.train_step(*batches[i % 4])
 torch.cuda.synchronize()
 dt = (time.time() - t0) / steps
-print("mode %s -> launch %s graph_error %s syncbn %s | %.2f ms/step | losses %s ... %.4f" % (
-    mode, tr.launch, tr.graph_error, tr.syncbn_exchange, dt * 1e3, [round(x, 4) for x in losses], float(loss)), flush=True)
+print("mode %s -> launch %s graph_error %s syncbn %s | %.2f ms/step | losses %s ... %.4f | gradients: %s" % (
+    mode, tr.launch, tr.graph_error, tr.syncbn_exchange, dt * 1e3, [round(x, 4) for x in losses], float(loss), tr.grad_exchange), flush=True)
 # (the result line is out before the teardown: a watchdog that dies in destroy_process_group cannot take it along)
 dist.destroy_process_group()
