@@ -127,10 +127,11 @@ def test_reference_recipe_two_ranks_equal_one_rank_and_the_oracle():
 # every parameter (CRIS_DDP_SELF_EXCHANGE=0): the averaged gradients must be the SAME BITS - the module divides by the world
 # size before the sum like DDP's reducer, a division by 2 is exact, and a two-term sum has one order.
 # ---------------------------------------------------------------------------------------------------------------------------
-def _grad_worker(rank, world, port, q, self_exchange, optimizer_name):
+def _grad_worker(rank, world, port, q, self_exchange, optimizer_name, grad_exchange="rccl"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["CRIS_DDP_SELF_EXCHANGE"] = "1" if self_exchange else "0"
+    os.environ["CRIS_GRAD_EXCHANGE"] = grad_exchange
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import hashlib
@@ -199,6 +200,7 @@ def _grad_worker(rank, world, port, q, self_exchange, optimizer_name):
         acc = torch.cat([p.grad.detach().float().flatten() for n, p in inner.named_parameters() if p.grad is not None]).cpu().numpy()
         out["self_exchange"] = bool(getattr(inner, "_self_exchange", False))
         out["syncbn_exchange"] = getattr(inner, "syncbn_exchange", None)
+        out["grad_exchange"] = getattr(inner, "grad_exchange", None)
         torch.cuda.synchronize()
         sd = inner.state_dict()
         out["probe"] = {k: sd[k].double().sum().item() for k in PROBES}
@@ -208,11 +210,11 @@ def _grad_worker(rank, world, port, q, self_exchange, optimizer_name):
         dist.destroy_process_group()
 
 
-def _run_grad(self_exchange, optimizer_name="torch"):
+def _run_grad(self_exchange, optimizer_name="torch", grad_exchange="rccl"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q, self_exchange, optimizer_name)) for r in range(2)]
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q, self_exchange, optimizer_name, grad_exchange)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=900) for _ in procs), key=lambda t: t[0])
@@ -246,3 +248,16 @@ def test_own_gradient_exchange_under_ddp_equals_ddp_managed_gradients_bit_for_bi
     assert np.array_equal(a0, a1) and np.array_equal(b0, b1)
     rel = float(np.linalg.norm(a0.astype(np.float64) - b0) / np.linalg.norm(b0.astype(np.float64)))
     assert rel < 1e-6, rel
+
+
+def test_own_gradient_exchange_over_the_mapped_arenas_equals_ddp_managed_gradients():
+    """the same pin for the opt-in direct exchange (CRIS_GRAD_EXCHANGE=p2p: reduce-scatter + all-gather over the IPC-mapped gradient
+    arenas, csrc/p2p.hip) under the DDP wrapper: with two ranks its rank-order sum (g0 / 2 + g1 / 2) has the bits of DDP's"""
+    own = _run_grad(True, "cris", "p2p")
+    ddp = _run_grad(False, "cris")
+    (_, o0, a0), (_, o1, a1) = own
+    (_, d0, b0), (_, d1, b1) = ddp
+    assert o0["grad_exchange"] == "p2p" and o1["grad_exchange"] == "p2p", (o0["grad_exchange"], o1["grad_exchange"])
+    assert o0["self_exchange"] and not d0["self_exchange"]
+    assert o0["digests"] == o1["digests"] == d0["digests"] == d1["digests"]
+    assert o0["losses"] == d0["losses"] and o0["probe"] == d0["probe"] and o0["rm"] == d0["rm"]
