@@ -359,7 +359,8 @@ class CRIS(nn.Module):
                 self.syncbn_exchange = ("p2p mailboxes, exchanged inside the BatchNorm launches" if getattr(comm, "_fused", False)
                                         else "p2p mailboxes, one exchange kernel per BatchNorm")
                 if os.environ.get("CRIS_GRAD_EXCHANGE", "rccl") == "p2p":      # opt-in: the direct exchange over the mapped arenas
-                    self.grad_exchange = comm.enable_arena_exchange(e_.grad_arena) or "p2p"
+                    refused = comm.enable_arena_exchange(e_.grad_arena)
+                    self.grad_exchange = "p2p" if refused is None else "rccl (arena exchange refused: %s)" % refused
             else:
                 self._xgen_dev, self.syncbn_exchange = None, "collective (mailboxes refused: %s)" % why
         # parameter-layout gradient buffers for the tensors whose HIP gradient lives in the GEMM layout
