@@ -344,7 +344,7 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
                                    "GradScaler, fp16 autocast outside / bf16 HIP engine inside, trainMetricGPU + .item() syncs%s), "
                                    "CRIS-R50 %dx%d, per-GPU bs=%d, %d-token text, batches resident in HBM"
                                    % ("; SyncBatchNorm + DistributedDataParallel" if world > 1 else "", args.size, args.size, args.batch, word_len),
-                       "path": "module", "replay": os.environ.get("CRIS_MODULE_REPLAY", "graph"), "optimizer": "cris.pytorch_amd.optim.Adam (fused update: %s)" % fused if optimizer_name == "cris" else "torch.optim.Adam", "ddp_one_rank": bool(own_pg),
+                       "path": "module", "replay": os.environ.get("CRIS_MODULE_REPLAY", "graph"), "optimizer": "cris.pytorch_amd.optim.Adam (fused update: %s)" % fused if optimizer_name == "cris" else "torch.optim.Adam(param_list, lr, weight_decay) as train.py:105 builds it (torch's fused implementation: %s - asked for by the parameter groups build_segmenter returns)" % bool(optimizer.param_groups[0].get("fused")), "ddp_one_rank": bool(own_pg),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world, "first_loss": first,
                        "final_loss": r[0], "grad_scale": float(scaler.get_scale()),
                        "graph_error": getattr(inner, "graph_error", None), "syncbn_exchange": getattr(inner, "syncbn_exchange", None),

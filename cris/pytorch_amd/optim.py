@@ -35,6 +35,11 @@ from . import hip, ops
 class Adam(torch.optim.Adam):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, **kw):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+        # (build_segmenter's groups ask torch.optim.Adam for its fused implementation; this class has its own fused update, and its
+        # fallback to torch's step must take strided `.grad` views of the gradient arena, which torch's fused kernel refuses)
+        for g in self.param_groups:
+            if not kw.get("fused"):
+                g["fused"] = None
         self._cris = None            # the bound module (decided at the first step)
         self._cris_checked = False
         self._tab = None

@@ -25,6 +25,8 @@ def test_r50_keys_and_param_groups_match_reference():
     assert sum(p.numel() for p in model.parameters()) == 146849122
     assert len(groups[0]["params"]) == 325 and len(groups[1]["params"]) == 124     # SURVEY.md a12 [probe]
     assert groups[0]["initial_lr"] == pytest.approx(1e-5) and groups[1]["initial_lr"] == pytest.approx(1e-4)
+    # (round 6: the groups also ask torch.optim.Adam for its fused implementation - same class, same constructor call as train.py:105)
+    assert all(set(g) == {"params", "initial_lr", "fused"} and g["fused"] is True for g in groups)
     names0 = {id(p) for p in groups[0]["params"]}
     for k, p in model.named_parameters():
         expect0 = k.startswith("backbone") and "positional_embedding" not in k
