@@ -883,19 +883,21 @@ __device__ __forceinline__ void adam_pack_tile(const cris_adam_desc& d, int lb, 
         }
     }
     __syncthreads();
-    if (d.dstF) {                                  // F[(n*PT + tap)*Cpad + c]: consecutive threads = consecutive channels
+    if (d.dstF) {                                  // F[n*ldF + tap*Cpad + c]: consecutive threads = consecutive channels
         const int cpadF = d.cpad;
+        const long ldF = d.ldF > 0 ? d.ldF : (long)PT * cpadF;        // (row stride: cris_pack_desc.ldF)
         for (int i = threadIdx.x; i < rows * PT * AP_T; i += 256) {
             const int c_l = i & (AP_T - 1), r = i >> 6;
             const int n_l = r / PT, tap = r - n_l * PT;
-            if (c_l < cw) d.dstF[((long)(n0 + n_l) * PT + tap) * cpadF + c0 + c_l] = tile[n_l * LROW + c_l * PT + tap];
+            if (c_l < cw) d.dstF[(long)(n0 + n_l) * ldF + (long)tap * cpadF + c0 + c_l] = tile[n_l * LROW + c_l * PT + tap];
         }
     }
-    if (d.dstD) {                                  // D[(c*PT + PT-1-tap)*Npad + n]: consecutive threads = consecutive rows n
+    if (d.dstD) {                                  // D[c*ldD + (PT-1-tap)*Npad + n]: consecutive threads = consecutive rows n
+        const long ldD = d.ldD > 0 ? d.ldD : (long)PT * d.npad;
         for (int i = threadIdx.x; i < cw * PT * TN; i += 256) {
             const int n_l = i & (TN - 1), r = i / TN;
             const int c_l = r / PT, tapf = r - c_l * PT;
-            if (n_l < rows) d.dstD[((long)(c0 + c_l) * PT + tapf) * d.npad + n0 + n_l] = tile[n_l * LROW + c_l * PT + (PT - 1 - tapf)];
+            if (n_l < rows) d.dstD[(long)(c0 + c_l) * ldD + (long)tapf * d.npad + n0 + n_l] = tile[n_l * LROW + c_l * PT + (PT - 1 - tapf)];
         }
     }
 }

@@ -895,7 +895,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const cris_pack_desc*
             float v = 0.f;
             if (c < d.Cin) v = d.src_transposed ? d.src[(size_t)c * d.N + n] : d.src[((size_t)n * d.Cin + c) * d.taps + tap];
             if (d.row_scale) v *= d.row_scale[n];
-            d.dstF[i] = f2bf(v);
+            const long ldF = d.ldF > 0 ? d.ldF : (long)d.taps * d.Cpad;      // (row stride: see cris_pack_desc.ldF)
+            d.dstF[(long)n * ldF + (long)tap * d.Cpad + c] = f2bf(v);
         }
     } else {
         // D layout: dst[(c*taps + (taps-1-tap))*Npad + n]: 64(n) x 64(c) tile transpose through LDS per tap
@@ -922,7 +923,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const cris_pack_desc*
         __syncthreads();
         for (int rr = ty; rr < 64; rr += 4) {
             const int c = ct * 64 + rr, n = nt * 64 + tx;
-            if (c < d.Cin && n < d.Npad) d.dstD[((size_t)c * d.taps + tapf) * d.Npad + n] = f2bf(tile[tx][rr]);
+            const size_t ldD = d.ldD > 0 ? (size_t)d.ldD : (size_t)d.taps * d.Npad;
+            if (c < d.Cin && n < d.Npad) d.dstD[(size_t)c * ldD + (size_t)tapf * d.Npad + n] = f2bf(tile[tx][rr]);
         }
     }
 }

@@ -67,7 +67,7 @@ class WgradGroup(C.Structure):
 class PackDesc(C.Structure):
     _fields_ = [("src", P), ("dstF", P), ("dstD", P), ("row_scale", P),
                 ("N", I), ("Cin", I), ("taps", I), ("Cpad", I), ("Npad", I), ("src_transposed", I),
-                ("block_start", I), ("pad_", I)]
+                ("block_start", I), ("ldF", I), ("ldD", I), ("pad_", I)]
 
 
 class BnApplyParams(C.Structure):
@@ -169,8 +169,8 @@ class AdamDesc(C.Structure):
                 ("cin", I), ("cpad", I),
                 ("dstF", P), ("dstD", P),
                 ("N", I), ("npad", I),
-                ("transposed", I), ("pad2_", I),
-                ("row_live", P), ("row_len", I), ("pad3_", I)]
+                ("transposed", I), ("ldF", I),
+                ("row_live", P), ("row_len", I), ("ldD", I)]
 
 
 ZERO_RANGES_MAX = 16
@@ -359,7 +359,7 @@ class HipLibraryError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3      # == CRIS_ABI_VERSION of include/cris_hip.h (tests/test_abi.py compares the two)
+ABI_VERSION = 4      # == CRIS_ABI_VERSION of include/cris_hip.h (tests/test_abi.py compares the two)
 
 
 def load():

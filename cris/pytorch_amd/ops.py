@@ -410,6 +410,17 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
     hip.call("cris_conv_wgrad", C.byref(p), _stream())
 
 
+PACK_SKEW = os.environ.get("CRIS_PACK_SKEW", "1") == "1"
+
+
+def pack_row_stride(k):
+    """row stride (elements) of a bf16 weight pack whose rows hold `k` values.  Rows a multiple of 256 B apart land on few of an
+    L2's sixteen 128-byte-interleaved channels (K = 4608: 9216 B = 72 lines, every row on one of two channels); one more line
+    makes the count odd and the rows walk through all of them.  Measured (tools/stride_skew_probe.py, call r06p): the K = 4608
+    convolutions -5 ... -10 %, everything else within +-1 %.  CRIS_PACK_SKEW=0: dense rows."""
+    return k + 64 if (PACK_SKEW and k % 128 == 0) else k
+
+
 class PackTable:
     """Device-resident table of cris_pack_desc: one launch repacks every fp32 weight into its bf16
     forward (F) / dgrad (D) layouts."""
@@ -424,11 +435,14 @@ class PackTable:
     def add(self, src, N, Cin, taps, Cpad=None, Npad=None, want_F=True, want_D=True, src_transposed=False, row_scale=None):
         Cpad = Cpad if Cpad is not None else pad8(Cin)
         Npad = Npad if Npad is not None else pad8(N)
-        dstF = torch.zeros(N, taps * Cpad, dtype=BF16, device=src.device) if want_F else None
-        dstD = torch.zeros(Cin, taps * Npad, dtype=BF16, device=src.device) if want_D else None
+        # row strides of an ODD number of 128-byte lines (pack_row_stride): the GEMMs read the packs with ldb = shape[1]
+        ldF, ldD = pack_row_stride(taps * Cpad), pack_row_stride(taps * Npad)
+        dstF = torch.zeros(N, ldF, dtype=BF16, device=src.device) if want_F else None
+        dstD = torch.zeros(Cin, ldD, dtype=BF16, device=src.device) if want_D else None
         d = hip.PackDesc()
         d.src, d.dstF, d.dstD, d.row_scale = ptr(src), ptr(dstF), ptr(dstD), ptr(row_scale)
         d.N, d.Cin, d.taps, d.Cpad, d.Npad, d.src_transposed = N, Cin, taps, Cpad, Npad, int(src_transposed)
+        d.ldF, d.ldD = ldF, ldD
         self.descs.append(d)
         self.keep.append((src, dstF, dstD, row_scale))
         self.info.append((dstF, dstD, N, Cin, taps, Cpad, Npad, bool(src_transposed)))
@@ -966,6 +980,8 @@ class AdamTable:
                     assert d.taps == ptaps or (d.taps == 0 and ptaps == 1), "a 9-tap packed weight takes its gradient in the GEMM layout"
                     d.dstF, d.dstD = ptr(dstF), ptr(dstD)
                     d.N, d.cin, d.cpad, d.npad, d.transposed = N, Cin, Cpad, Npad, int(transposed)
+                    d.ldF = dstF.shape[1] if dstF is not None else 0       # (row strides of the packs: ops.pack_row_stride)
+                    d.ldD = dstD.shape[1] if dstD is not None else 0
                 if row_live is not None and i in row_live:
                     assert pk is None and d.taps == 0 and p.dim() == 2 and row_live[i].numel() == p.shape[0]
                     d.row_live, d.row_len = ptr(row_live[i]), p.shape[1]

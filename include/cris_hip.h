@@ -26,8 +26,8 @@ typedef uint16_t cris_bf16;
 const char* cris_last_error(void);
 /* CRIS_ABI_VERSION moves whenever an exported signature or struct changes; a binding compares cris_abi_version() with the
  * value it was written against and refuses a library of another version (a stale build loaded with new argument lists would
- * mis-read them silently).  2: cris_step_advance took its fourth argument (round 5); 3: round 6 */
-#define CRIS_ABI_VERSION 3
+ * mis-read them silently).  2: cris_step_advance took its fourth argument (round 5); 3, 4: round 6 (arena exchange; row strides of the weight packs) */
+#define CRIS_ABI_VERSION 4
 int cris_abi_version(void);
 /* sizeof() of the parameter structs, so the Python mirror (ctypes) can be checked without a GPU */
 int cris_sizeof(const char* struct_name);
@@ -172,6 +172,11 @@ typedef struct {
                               * BatchNorm folded into its convolution (gamma / sqrt(running_var + eps), cris_bn_eval_coeffs) */
     int N, Cin, taps, Cpad, Npad, src_transposed;
     int block_start;         /* first block of this tensor in the launch grid (prefix sum) */
+    int ldF;                 /* row stride of dstF in elements, 0 = dense (taps * Cpad).  Round 6: the packs are allocated with a row
+                              * stride of an ODD number of 128-byte lines (taps * Cpad + 64 when that is a multiple of 128 elements): rows
+                              * 9216 B apart (K = 4608) land on two of an L2's sixteen channels, rows 9344 B apart on all of them - the
+                              * K = 4608 convolutions run 5 - 10 % faster (profiles/r06/stride_skew_probe.log); the GEMMs take it as ldb */
+    int ldD;                 /* the same for dstD, 0 = dense (taps * Npad) */
     int pad_;
 } cris_pack_desc;
 int cris_pack_weights(const cris_pack_desc* dev_table, int n_desc, int total_blocks, void* stream);
@@ -460,13 +465,13 @@ typedef struct {
     int cin; int cpad;
     cris_bf16* dstF; cris_bf16* dstD;
     int N; int npad;                 /* packed tensors: rows, padded rows of the D layout (cin / cpad above) */
-    int transposed; int pad2_;       /* packed: parameter stored [cin][N] (one tap) */
+    int transposed; int ldF;         /* packed: parameter stored [cin][N] (one tap); ldF / ldD: row strides of dstF / dstD in elements */
     const unsigned char* row_live;   /* optional (plain tensors, weight_decay == 0): byte r != 0 <=> row r (row_len elements) has ever
                                         had a non-zero gradient.  Rows that never had one are skipped: with g = m = v = 0 the
                                         Adam update is the identity (p - step * 0 / (0 + eps) = p), so the result is bit-identical
                                         to the dense update - the token embedding is 17% of CRIS-R50's parameters and a step
                                         touches at most B*L of its 49408 rows. */
-    int row_len; int pad3_;
+    int row_len; int ldD;            /* (ldF / ldD: 0 = dense, as in cris_pack_desc) */
 } cris_adam_desc;
 int cris_adam_step(const cris_adam_desc* dev_table, int n_desc, int total_blocks, float beta1, float beta2, float eps,
                    float weight_decay, float bias_corr1, float bias_corr2, float grad_scale, const int32_t* step_dev,

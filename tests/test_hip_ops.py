@@ -158,7 +158,8 @@ def test_conv_gemm_folded_batchnorm_epilogue(case):
     tab.run()
     s_ref = gamma / torch.sqrt(rvar + 1e-5)
     check(scale, s_ref, 1e-6, "eval scale")
-    check(wf.view(N, k * k, ops.pad8(C_))[:, :, :C_], (w * s_ref.view(N, 1, 1, 1)).permute(0, 2, 3, 1).reshape(N, k * k, C_), 4e-3, "row-scaled pack")
+    # (the pack's row stride may exceed its k * k * Cpad values: ops.pack_row_stride)
+    check(wf[:, :k * k * ops.pad8(C_)].reshape(N, k * k, ops.pad8(C_))[:, :, :C_], (w * s_ref.view(N, 1, 1, 1)).permute(0, 2, 3, 1).reshape(N, k * k, C_), 4e-3, "row-scaled pack")
     xin = x if ops.pad8(C_) == C_ else F.pad(x, (0, ops.pad8(C_) - C_))
     gk = Geom(B, H, W, ops.pad8(C_), k, k, 1, pad)
     y = F.batch_norm(conv_ref(x, w, 1, pad).t().reshape(1, N, -1), rmean, rvar, gamma, beta, False, 0.0, 1e-5).reshape(N, -1).t()
@@ -599,6 +600,53 @@ def test_pack_weights():
     wtb = wt.to(BF).float().cpu()
     assert torch.equal(ft.float().cpu(), wtb.t().contiguous())
     assert torch.equal(dt.float().cpu(), wtb)
+
+
+def test_pack_row_stride_skew():
+    """round 6: packs whose rows would be a multiple of 256 B apart get one more 128-byte line per row (ops.pack_row_stride: the
+    rows then walk through all L2 channels).  The values sit where the GEMMs look for them (ldb = shape[1]), the padding stays
+    zero, a convolution / its input gradient through the skewed packs equal torch's, and the packs the fused Adam writes equal
+    cris_pack_weights' (same row strides)."""
+    assert ops.pack_row_stride(4608) == 4672 and ops.pack_row_stride(2304) == 2368 and ops.pack_row_stride(576) == 576
+    assert ops.pack_row_stride(128) == 192 and ops.pack_row_stride(64) == 64 and ops.pack_row_stride(216) == 216
+    B, H, W, C_, N = 2, 12, 12, 128, 256                        # 3x3: K = 1152 = 9 lines... x 2 B = 18 lines (even) -> skewed
+    w = (rnd(N, C_, 3, 3) / math.sqrt(C_ * 9)).to(BF).float()
+    wl = rnd(96, 256, seed=1).to(BF).float()                    # linear, K = 256
+    tab = ops.PackTable()
+    f3, d3 = tab.add(w.to(DEV).view(N, C_, 9), N, C_, 9)
+    fl, dl = tab.add(wl.to(DEV).view(96, 256, 1), 96, 256, 1)
+    tab.run()
+    torch.cuda.synchronize()
+    assert f3.shape == (N, 9 * C_ + 64) and d3.shape == (C_, 9 * N + 64) and fl.shape == (96, 256 + 64) and dl.shape == (256, 96)
+    assert torch.equal(f3[:, :9 * C_].float().cpu().view(N, 9, C_), w.permute(0, 2, 3, 1).reshape(N, 9, C_))
+    assert torch.equal(d3[:, :9 * N].float().cpu().view(C_, 9, N), w.flip(2, 3).permute(1, 2, 3, 0).reshape(C_, 9, N))
+    assert torch.equal(fl[:, :256].float().cpu(), wl) and torch.equal(dl.float().cpu(), wl.t().contiguous())
+    assert float(f3[:, 9 * C_:].abs().max()) == 0.0 and float(d3[:, 9 * N:].abs().max()) == 0.0 and float(fl[:, 256:].abs().max()) == 0.0
+    x = rnd(B, H, W, C_, seed=2).to(BF).float()
+    dy = rnd(B, H, W, N, seed=3).to(BF).float()
+    y = torch.empty(B * H * W, N, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(x), f3, Geom(B, H, W, C_, 3, 3, 1, 1), N, out=y)
+    xt = x.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yr = F.conv2d(xt, w, padding=1)
+    check(y, yr.permute(0, 2, 3, 1).reshape(-1, N), 6e-3, "forward through the skewed F pack")
+    dx = torch.empty(B * H * W, C_, dtype=BF, device=DEV)
+    ops.conv_gemm(bf(dy), d3, Geom(B, H, W, N, 3, 3, 1, 1), C_, out=dx)
+    yr.backward(dy.permute(0, 3, 1, 2))
+    check(dx, xt.grad.permute(0, 2, 3, 1).reshape(-1, C_), 6e-3, "dgrad through the skewed D pack")
+    # the fused Adam writes the same packs
+    params = [w.to(DEV).clone(), wl.to(DEV).clone()]
+    tab2 = ops.PackTable()
+    tab2.add(params[0].view(N, C_, 9), N, C_, 9)
+    tab2.add(params[1].view(96, 256, 1), 96, 256, 1)
+    g3 = rnd(N, C_, 3, 3, seed=5)
+    grads = [g3.permute(0, 2, 3, 1).reshape(N, 9 * C_).contiguous().to(DEV), rnd(96, 256, seed=6).to(DEV)]
+    adam = ops.AdamTable(params, grads, [1e-3] * 2, layouts=[(N, C_, 9, C_), None], packs=tab2.info)
+    adam.step()
+    got = [(f.clone(), d.clone()) for f, d, *_ in tab2.info]
+    tab2.run()
+    torch.cuda.synchronize()
+    for (f, d, *_), (gf, gd) in zip(tab2.info, got):
+        assert torch.equal(f, gf) and torch.equal(d, gd)
 
 
 def test_dgrad_via_packed_weights():
