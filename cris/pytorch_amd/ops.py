@@ -410,14 +410,17 @@ def conv_wgrad(dY, X, g: Geom, N: int, dW, *, ldy=None, y_coff=0, N_ld=None, ldx
     hip.call("cris_conv_wgrad", C.byref(p), _stream())
 
 
-PACK_SKEW = os.environ.get("CRIS_PACK_SKEW", "1") == "1"
+PACK_SKEW = os.environ.get("CRIS_PACK_SKEW", "0") == "1"
 
 
 def pack_row_stride(k):
     """row stride (elements) of a bf16 weight pack whose rows hold `k` values.  Rows a multiple of 256 B apart land on few of an
     L2's sixteen 128-byte-interleaved channels (K = 4608: 9216 B = 72 lines, every row on one of two channels); one more line
-    makes the count odd and the rows walk through all of them.  Measured (tools/stride_skew_probe.py, call r06p): the K = 4608
-    convolutions -5 ... -10 %, everything else within +-1 %.  CRIS_PACK_SKEW=0: dense rows."""
+    makes the count odd and the rows walk through all of them.  Measured STANDALONE (tools/stride_skew_probe.py, call r06p: operands
+    hot in L2): the K = 4608 convolutions -5 ... -10 %, everything else within +-1 %.  Measured IN THE STEP (call r06q, three
+    interleaved runs each): 11.726 / 11.745 / 11.745 ms with, 11.722 / 11.737 / 11.760 without - nothing: in the step the weights
+    come from HBM, not from a warm L2, and the channel spread of a resident panel is not what bounds the launch.  Hence OFF by
+    default (CRIS_PACK_SKEW=1 switches it on; results are bit-identical either way)."""
     return k + 64 if (PACK_SKEW and k % 128 == 0) else k
 
 

@@ -172,10 +172,10 @@ typedef struct {
                               * BatchNorm folded into its convolution (gamma / sqrt(running_var + eps), cris_bn_eval_coeffs) */
     int N, Cin, taps, Cpad, Npad, src_transposed;
     int block_start;         /* first block of this tensor in the launch grid (prefix sum) */
-    int ldF;                 /* row stride of dstF in elements, 0 = dense (taps * Cpad).  Round 6: the packs are allocated with a row
-                              * stride of an ODD number of 128-byte lines (taps * Cpad + 64 when that is a multiple of 128 elements): rows
-                              * 9216 B apart (K = 4608) land on two of an L2's sixteen channels, rows 9344 B apart on all of them - the
-                              * K = 4608 convolutions run 5 - 10 % faster (profiles/r06/stride_skew_probe.log); the GEMMs take it as ldb */
+    int ldF;                 /* row stride of dstF in elements, 0 = dense (taps * Cpad); the GEMMs take it as ldb.  Round 6, opt-in
+                              * (CRIS_PACK_SKEW=1): a row stride of an ODD number of 128-byte lines (taps * Cpad + 64 when that is a
+                              * multiple of 128 elements) spreads a resident panel's rows over all L2 channels: the K = 4608 convolutions
+                              * 5 - 10 % faster standalone, nothing in the step (profiles/r06/stride_skew_probe.log, r06_ab_experiments.md) */
     int ldD;                 /* the same for dstD, 0 = dense (taps * Npad) */
     int pad_;
 } cris_pack_desc;

@@ -602,11 +602,12 @@ def test_pack_weights():
     assert torch.equal(dt.float().cpu(), wtb)
 
 
-def test_pack_row_stride_skew():
-    """round 6: packs whose rows would be a multiple of 256 B apart get one more 128-byte line per row (ops.pack_row_stride: the
-    rows then walk through all L2 channels).  The values sit where the GEMMs look for them (ldb = shape[1]), the padding stays
-    zero, a convolution / its input gradient through the skewed packs equal torch's, and the packs the fused Adam writes equal
-    cris_pack_weights' (same row strides)."""
+def test_pack_row_stride_skew(monkeypatch):
+    """round 6 (opt-in, CRIS_PACK_SKEW=1): packs whose rows would be a multiple of 256 B apart get one more 128-byte line per row
+    (ops.pack_row_stride: the rows then walk through all L2 channels).  The values sit where the GEMMs look for them (ldb =
+    shape[1]), the padding stays zero, a convolution / its input gradient through the skewed packs equal torch's, and the packs
+    the fused Adam writes equal cris_pack_weights' (same row strides)."""
+    monkeypatch.setattr(ops, "PACK_SKEW", True)
     assert ops.pack_row_stride(4608) == 4672 and ops.pack_row_stride(2304) == 2368 and ops.pack_row_stride(576) == 576
     assert ops.pack_row_stride(128) == 192 and ops.pack_row_stride(64) == 64 and ops.pack_row_stride(216) == 216
     B, H, W, C_, N = 2, 12, 12, 128, 256                        # 3x3: K = 1152 = 9 lines... x 2 B = 18 lines (even) -> skewed
