@@ -25,6 +25,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FLOP_PER_SAMPLE = 395.0e9          # fwd+bwd, contractions only, R50/416/L17 (SURVEY.md 8d / BASELINE.md 2)
+# the other BASELINE configurations (fwd+bwd 395.0 / 469.2 / 529.6 GFLOP per sample); anything else: None
+FLOP_PER_SAMPLE_BY_CONFIG = {("r50", 416): 395.0e9, ("r101", 416): 469.2e9, ("r50", 480): 529.6e9}
 ALG_BYTES_PER_SAMPLE = 0.98e9      # bf16 contraction operands+outputs under perfect fusion
 ADAM_BYTES_PER_STEP = 4.11e9
 MFMA_PEAK = 2500.0                 # TFLOP/s dense bf16 (MI355X_MICROARCH.md)
@@ -351,7 +353,7 @@ def module_path(args, rank, world, dev, optimizer_name=None, steps=None, warmup=
                        "own_gradient_exchange": bool(getattr(inner, "_self_exchange", False)),
                        "gradient_exchange_in_this_run": inner._exchange_comm_for_this_step() is not None,
                        "ddp_managed_parameters": len(model._module_parameters) if hasattr(model, "_module_parameters") else None},
-            "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12)}})
+            "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE_BY_CONFIG.get((args.spec, args.size), FLOP_PER_SAMPLE) / (MFMA_PEAK * 1e12)}})
     if world > 1 and dist.is_initialized():
         dist.destroy_process_group()
 
@@ -533,8 +535,12 @@ def main():
                        "source_commit": (open(os.path.join(ROOT, ".source_commit")).read().strip()
                                          if os.path.exists(os.path.join(ROOT, ".source_commit")) else None),
                        "gpu_state_start": smi0, "gpu_state_end": smi1},
-            "step_roofline": {"mfma_frac": sps / world * FLOP_PER_SAMPLE / (MFMA_PEAK * 1e12),
-                              "hbm_frac_alg": (sps / world * ALG_BYTES_PER_SAMPLE + steps_s * ADAM_BYTES_PER_STEP) / (HBM_PEAK * 1e9)},
+            "step_roofline": {"mfma_frac": (sps / world * FLOP_PER_SAMPLE_BY_CONFIG[(args.spec, args.size)] / (MFMA_PEAK * 1e12)
+                                            if (args.spec, args.size) in FLOP_PER_SAMPLE_BY_CONFIG else None),
+                              "flop_per_sample": FLOP_PER_SAMPLE_BY_CONFIG.get((args.spec, args.size)),
+                              # (the algorithmic byte count exists for the benchmarked configuration only)
+                              "hbm_frac_alg": ((sps / world * ALG_BYTES_PER_SAMPLE + steps_s * ADAM_BYTES_PER_STEP) / (HBM_PEAK * 1e9)
+                                               if (args.spec, args.size) == ("r50", 416) else None)},
         }
         if (args.spec, args.size) in DUAL_CEILING and args.batch == 8:
             # the per-layer dual (MFMA / HBM) roofline of SURVEY.md 8d for this configuration at 8 samples per GPU
