@@ -14,7 +14,10 @@ the matrix is inverted in double (no WARP_INVERSE_MAP flag), source coordinates 
 and quantised to 1/32 pixel (INTER_BITS 5), the 4x4 bicubic weights (A = -0.75) come from a 32 x 32 table of float
 products, taps outside the image contribute borderValue 0 - and is **parity unpinned** against cv2 itself.  Its anchors
 are properties any correct warp has (identity, integer translations, the dataset's own forward/inverse matrix pair
-`utils/dataset.py:190-205`), asserted in the tests.
+`utils/dataset.py:190-205`) and - round 6 - an INDEPENDENT implementation of the same sampling rule: torch's
+F.grid_sample(bicubic, zeros, align_corners=True) (Keys kernel A = -0.75, integer pixel coordinates, zero border) on exact
+coordinates, which the restatement matches to OpenCV's own 1/32-pixel coordinate quantisation under letter-box, rotation and
+anisotropic matrices (tests/test_eval_post.py).  That pins the algorithm class, not cv2's bits.
 """
 import numpy as np
 

@@ -42,6 +42,47 @@ def test_oracle_warp_cubic_table_and_half_pixel():
     assert np.allclose(out[:, 2:17], src[:, 2:17] + 0.5, atol=1e-5)
 
 
+def test_oracle_warp_against_an_independent_bicubic_sampler():
+    """A second, independent implementation of the same sampling rule beside the restatement (round 6; cv2 itself stays absent,
+    so this does not lift "parity unpinned" - it pins the algorithm CLASS): torch's F.grid_sample(mode="bicubic",
+    padding_mode="zeros", align_corners=True) uses the same Keys kernel (A = -0.75), integer pixel coordinates and zero border
+    that cv2.warpAffine(INTER_CUBIC, borderValue=0) uses, in float arithmetic on exact coordinates; OpenCV quantises the source
+    coordinate to 1/32 pixel and takes its weights from a table.  On a smooth image, under the matrices the dataset produces
+    (letter-box inverse: scale + translation, `utils/dataset.py:190-205`) and under a rotation + anisotropic scale, the two must
+    agree to the quantisation error: |d| <= max gradient x 1/64 pixel x (|x| + |y| parts) + rounding."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    H, W = 61, 83
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    src = (0.5 + 0.25 * np.sin(xx / 7.0) * np.cos(yy / 5.0) + 0.2 * np.sin((xx + yy) / 11.0)).astype(np.float32)      # smooth, in [0, 1]
+    gmax = float(max(np.abs(np.diff(src, axis=0)).max(), np.abs(np.diff(src, axis=1)).max()))
+    th = 0.3
+    mats = [np.array([[1 / 0.832, 0, -10.0 / 0.832], [0, 1 / 0.832, -33.5 / 0.832]], np.float64),          # a letter-box inverse
+            np.array([[1.7 * np.cos(th), -1.1 * np.sin(th), 6.3], [1.7 * np.sin(th), 1.1 * np.cos(th), -4.2]], np.float64),
+            np.array([[0.61, 0.0, 3.37], [0.0, 0.61, 1.91]], np.float64)]
+    for mat, (wo, ho) in zip(mats, ((97, 71), (120, 90), (50, 40))):
+        got = EP.warp_affine_cubic(src, mat, wo, ho, 0.0)
+        A = np.vstack([mat, [0, 0, 1]])
+        Ai = np.linalg.inv(A)                                     # cv2.warpAffine without WARP_INVERSE_MAP: dst -> src through M^-1
+        oy, ox = np.mgrid[0:ho, 0:wo].astype(np.float64)
+        sx = Ai[0, 0] * ox + Ai[0, 1] * oy + Ai[0, 2]
+        sy = Ai[1, 0] * ox + Ai[1, 1] * oy + Ai[1, 2]
+        grid = torch.from_numpy(np.stack([2 * sx / (W - 1) - 1, 2 * sy / (H - 1) - 1], -1)[None]).float()
+        ref = F.grid_sample(torch.from_numpy(src)[None, None], grid, mode="bicubic", padding_mode="zeros", align_corners=True)[0, 0].numpy()
+        inside = (sx >= 2) & (sx <= W - 3) & (sy >= 2) & (sy <= H - 3)         # all 16 taps inside: the border rule aside
+        d = np.abs(got - ref)
+        bound = 2.0 * gmax / 64.0 * 1.3 + 1e-4                    # 1/64 pixel in x and in y, cubic overshoot 1.3
+        assert d[inside].max() <= bound, (d[inside].max(), bound)
+        assert d[inside].mean() <= 0.35 * bound
+        # at the border both take zero for the taps outside the image: same rule, same order of magnitude of agreement
+        assert d.max() <= 4.0 * bound + 0.02, d.max()
+        # outside the source (beyond two pixels) both give exactly the border value
+        far = (sx < -2) | (sx > W + 1) | (sy < -2) | (sy > H + 1)
+        assert np.all(got[far] == 0.0) and np.all(ref[far] == 0.0)
+    _ = rng
+
+
 def test_oracle_dataset_matrix_pair_round_trip():
     """utils/dataset.py:190-205: an original 300 x 500 image letter-boxed into 416 x 416 and back: a mask that is constant
     inside the valid area comes back constant in the interior of the original frame"""

@@ -63,6 +63,39 @@ def test_constant_image_stays_constant_and_border_colour_is_rounded():
     assert (out[0:10] == np.array([123, 117, 104], np.uint8)).all()
 
 
+def test_u8_warps_against_an_independent_sampler():
+    """beside the restatement of OpenCV's 8-bit warps, an independent implementation of the same sampling rules (round 6; does
+    not lift "parity unpinned" - cv2 stays absent - but pins the algorithm class): torch's F.grid_sample with the Keys kernel
+    A = -0.75 (`bicubic`) / `bilinear`, integer pixel coordinates (align_corners=True), on exact coordinates in float.  OpenCV
+    quantises coordinates to 1/32 pixel and weights to 15 bits and rounds to 8 bits: on a smooth image under the dataset's
+    letter-box matrix (`utils/dataset.py:190-205`) the two agree to a gray level or two in the interior."""
+    import torch.nn.functional as F
+    h, w, S = 97, 141, 160
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.stack([127 + 100 * np.sin(yy / 9.0 + c) * np.cos(xx / 11.0) for c in range(3)], -1)
+    img = np.clip(np.rint(img), 0, 255).astype(np.uint8)
+    mask = (((yy - 40) ** 2 / 900.0 + (xx - 70) ** 2 / 2500.0) < 1.0).astype(np.uint8) * 255
+    mat, _ = ip.get_transform_mat((h, w), (S, S), True)
+    A = np.vstack([mat, [0, 0, 1]])
+    Ai = np.linalg.inv(A)
+    oy, ox = np.mgrid[0:S, 0:S].astype(np.float64)
+    sx = Ai[0, 0] * ox + Ai[0, 1] * oy + Ai[0, 2]
+    sy = Ai[1, 0] * ox + Ai[1, 1] * oy + Ai[1, 2]
+    grid = torch.from_numpy(np.stack([2 * sx / (w - 1) - 1, 2 * sy / (h - 1) - 1], -1)[None]).float()
+    inside = (sx >= 2) & (sx <= w - 3) & (sy >= 2) & (sy <= h - 3)
+    got = ip.warp_affine_u8(img, mat, S, S, ip.INTER_CUBIC, ip.BORDER_RGB).astype(np.float64)
+    ref = F.grid_sample(torch.from_numpy(img.astype(np.float32)).permute(2, 0, 1)[None], grid, mode="bicubic", padding_mode="zeros",
+                        align_corners=True)[0].permute(1, 2, 0).numpy().clip(0, 255)
+    d = np.abs(got - ref)[inside]
+    assert d.max() <= 1.5 and d.mean() <= 0.4, (d.max(), d.mean())          # measured: max 0.69, mean 0.26 gray levels (rounding to 8 bits)
+    gotm = ip.warp_affine_u8(mask, mat, S, S, ip.INTER_LINEAR, 0.).astype(np.float64)
+    refm = F.grid_sample(torch.from_numpy(mask.astype(np.float32))[None, None], grid, mode="bilinear", padding_mode="zeros",
+                         align_corners=True)[0, 0].numpy()
+    dm = np.abs(gotm - refm)[inside]
+    # (a 0 / 255 step edge: 1/32 pixel of coordinate quantisation is up to 255 / 32 = 8 gray levels ON the edge, nothing elsewhere)
+    assert dm.max() <= 255.0 / 32.0 + 1.0 and dm.mean() <= 0.1, (dm.max(), dm.mean())        # measured: max 5.3 (on the edge), mean 0.044
+
+
 def test_letterbox_matrix():
     for (h, w), S in (((480, 640), 416), ((640, 427), 416), ((50, 37), 96), ((416, 416), 416)):
         mat, inv = ip.get_transform_mat((h, w), (S, S), True)
