@@ -14,7 +14,9 @@ oracle/eval_post.py, then `remap` with the 16-bit weight tables of `initInterTab
 x 2^15, rounded, their sum pulled to 2^15 by correcting one entry - including that routine's quirk of searching the 2x2
 window that STARTS at tap ksize/2, which for the bilinear table reaches into the following, not yet initialised entry), taps
 outside the image read the border colour,
-result `(sum + 2^14) >> 15` saturated to 8 bits - and is **parity unpinned** against cv2 itself.  `get_affine_transform`
+result `(sum + 2^14) >> 15` saturated to 8 bits - and is **parity unpinned** against cv2 itself (round 6: an independent sampler with
+the same kernel and conventions, torch's F.grid_sample, agrees to 0.7 gray levels on a smooth image under the letter-box matrix -
+tests/test_input_pipe.py - which pins the algorithm class, not cv2's bits).  `get_affine_transform`
 solves the same 3-point system as cv2.getAffineTransform but with numpy's LU instead of OpenCV's SVD, so the matrix can
 differ in the last bits.  Anchors asserted in tests/test_input_pipe.py: identity and integer translations copy pixels
 exactly, weights are non-negative for INTER_LINEAR and every table row sums to 2^15, a constant image stays constant,
